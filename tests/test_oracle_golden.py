@@ -1,0 +1,210 @@
+"""The CPU oracle against the vectors the REFERENCE produced (tests/golden/*.npz,
+made by tests/golden/gen_golden.py in the build container).  Runs anywhere."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import supnerf_oracle as O
+
+
+def same(a, b, tol=0.0):
+    a, b = torch.as_tensor(a).detach().double(), torch.as_tensor(b).detach().double()
+    assert a.shape == b.shape
+    assert float((a - b).abs().max()) <= tol if a.numel() else True
+
+
+def test_weights_are_reproducible(golden, oracle_params):
+    h = hashlib.sha256()
+    for k in sorted(oracle_params):
+        h.update(k.encode())
+        h.update(oracle_params[k].numpy().astype(np.float32).tobytes())
+    assert h.hexdigest() == str(golden("decoder_b1_s32")["weights_sha256"])
+    assert list(oracle_params.keys()) == list(O.decoder_param_names())
+
+
+def test_positional_encoding_order(golden):
+    g = golden("pe")
+    same(O.positional_encoding(g["x"], 10), g["pe10"])
+    same(O.positional_encoding(g["x"], 4), g["pe4"])
+    assert g["pe10"].shape[-1] == 63 and g["pe4"].shape[-1] == 27
+
+
+@pytest.mark.parametrize("tag", ["b1_s32", "b3_s64", "b2_s7"])
+def test_decoder(golden, oracle_params, tag):
+    g = golden("decoder_" + tag)
+    with torch.no_grad():
+        sig, rgb = O.decoder_forward(oracle_params, g["xyz"], g["viewdir"], g["shapecode"], g["texturecode"])
+    same(sig, g["sigmas"], 1e-6)
+    same(rgb, g["rgbs"], 1e-6)
+
+
+def test_composite_family(golden):
+    g = golden("composite")
+    for a, k in zip(O.volume_rendering2(g["sigmas"], g["rgbs"], g["z_shared"]), ("vr2_rgb", "vr2_depth", "vr2_acc")):
+        same(a, g[k])
+    for a, k in zip(O.composite(g["sigmas"].squeeze(-1), g["rgbs"], g["z_ray"], white_bkgd=True),
+                    ("white_rgb", "white_depth", "white_acc")):
+        same(a, g[k])
+    for a, k in zip(O.volume_rendering3(g["sigmas"], g["rgbs"], g["z_ray"]), ("vr3_rgb", "vr3_depth", "vr3_acc")):
+        same(a, g[k])
+    B, S = g["z_obj"].shape
+    out = O.volume_rendering_batch(g["sigmas"].view(B, -1, S, 1), g["rgbs"].view(B, -1, S, 3), g["z_obj"])
+    for a, k in zip(out, ("batch_rgb", "batch_depth", "batch_acc")):
+        same(a, g[k])
+    # acc_trans excludes the last (1e10 wide) sample; an empty ray keeps it at ~1
+    assert abs(float(g["vr2_acc"][0]) - 1.0) < 1e-5
+    assert float(g["vr2_acc"][1]) < 1e-6
+
+
+def test_composite_gradients(golden):
+    g = golden("composite_grad")
+    sig, rgb, z = [g[k].clone().requires_grad_() for k in ("sigmas", "rgbs", "z")]
+    r = O.volume_rendering3(sig, rgb, z, white_bkgd=True)
+    ((r[0] * g["w_rgb"]).sum() + (r[1] * g["w_depth"]).sum() + (r[2] * g["w_acc"]).sum()).backward()
+    same(sig.grad, g["d_sigmas"], 1e-6)
+    same(rgb.grad, g["d_rgbs"], 1e-6)
+    same(z.grad, g["d_z"], 1e-5)
+
+
+def test_rays(golden):
+    g = golden("rays")
+    o, d = O.pixel_rays(g["K"], g["cam_pose"], g["roi"], uv_steps=[8, 8])
+    same(o, g["rays_o"]); same(d, g["viewdir"])
+    o, d = O.pixel_rays(g["K"], g["cam_pose"], g["roi_small"])
+    same(o, g["rays_o_small"]); same(d, g["viewdir_small"])
+    o, d = O.pixel_rays_at(g["K"], g["cam_pose"], g["x_vec"].numpy() + int(g["roi"][0]), g["y_vec"].numpy() + int(g["roi"][1]))
+    same(d, g["viewdir_spec"])
+
+
+@pytest.mark.parametrize("tag", ["a_nusc", "a_demo", "a_kitti"])
+def test_family_a_end_to_end(golden, oracle_params, tag):
+    g = golden("render_" + tag)
+    with torch.no_grad():
+        out = O.render_rays_v2(oracle_params, g["img"], g["mask_occ"], g["cam_pose"], np.float32(g["obj_diag"]), g["K"],
+                               g["roi"], int(g["n_samples"]), g["shapecode"], g["texturecode"],
+                               bool(g["shapenet_obj_cood"]), kitti2nusc=bool(g["kitti2nusc"]),
+                               im_sz=int(g["im_sz"]), jitter=g["jitter"])
+    for a, k in zip(out, ("rgb", "depth", "acc", "rgb_tgt", "occ")):
+        same(a, g[k], 2e-6)
+
+
+def test_family_a_flip_and_subset(golden, oracle_params):
+    g = golden("render_a_flip_subset")
+    with torch.no_grad():
+        out = O.render_rays_v2(oracle_params, g["img"], g["mask_occ"], g["cam_pose"], np.float32(g["obj_diag"]), g["K"],
+                               g["roi"], 64, g["shapecode"], g["texturecode"], True, sym_flip=True, im_sz=8,
+                               ray_ids=g["ray_ids"].numpy(), jitter=g["jitter"])
+    for a, k in zip(out, ("rgb", "depth", "acc", "rgb_tgt", "occ")):
+        same(a, g[k], 2e-6)
+
+
+def test_resize_targets(golden):
+    g = golden("resize_targets")
+    im, mk = O.resize_targets(g["img"], g["mask_occ"], 8)
+    same(im.reshape(-1, 3), g["rgb_tgt"]); same(mk.reshape(-1, 1), g["occ"])
+    assert set(np.unique(mk.numpy()).tolist()) <= {-1.0, 0.0, 1.0}
+
+
+def test_family_a_specified(golden, oracle_params):
+    g = golden("render_a_specified")
+    with torch.no_grad():
+        out = O.render_rays_specified(oracle_params, g["img"], g["mask_occ"], g["cam_pose"], np.float32(g["obj_diag"]),
+                                      g["K"], g["roi"], g["x_vec"].numpy(), g["y_vec"].numpy(), 64, g["shapecode"],
+                                      g["texturecode"], True, jitter=g["jitter"])
+    for a, k in zip(out, ("rgb", "depth", "acc", "rgb_tgt", "occ")):
+        same(a, g[k], 2e-6)
+
+
+def test_prepare_pixel_samples(golden):
+    g = golden("prepare_pixel_samples")
+    out = O.prepare_pixel_samples(g["img"], g["mask_occ"], g["cam_pose"], np.float32(g["obj_diag"]), g["K"], g["roi"], 20,
+                                  64, True, im_sz=8, ray_ids=g["ray_ids"].numpy(), jitter=g["jitter"])
+    for a, k in zip(out, ("xyz", "viewdir", "z_vals", "rgb_tgt", "occ")):
+        same(a, g[k])
+
+
+def test_render_full_img(golden, oracle_params):
+    g = golden("render_full_img")
+    with torch.no_grad():
+        img, depth = O.render_full_img(oracle_params, g["cam_pose"], g["wlh"].numpy(), g["K"], g["roi"], 64, g["shapecode"],
+                                       g["texturecode"], True, out_depth=True, jitter=g["jitter"])
+    same(img, g["img"], 2e-6); same(depth, g["depth"], 2e-5)
+
+
+@pytest.mark.parametrize("tag", ["b_hit", "b_s32"])
+def test_family_b_end_to_end(golden, oracle_params, tag):
+    g = golden("render_" + tag)
+    with torch.no_grad():
+        out = O.nerf_renderer_render_rays(oracle_params, g["img"], g["mask_occ"], g["cam_pose"], g["wlh"].numpy(), g["K"],
+                                          g["roi"], g["shapecode"], g["texturecode"], n_samples=int(g["n_samples"]),
+                                          white_bkgd=True, im_sz=int(g["im_sz"]), jitter=g["jitter"])
+        ro, vd = O.pixel_rays(g["K"], g["cam_pose"], g["roi"], uv_steps=[int(g["im_sz"])] * 2)
+        _, _, zv, hit = O.aabb_sampled_rays(ro, vd, g["wlh"].numpy(), int(g["n_samples"]), g["jitter"])
+    for a, k in zip(out, ("rgb", "depth", "acc", "rgb_tgt", "occ")):
+        same(a, g[k], 2e-6)
+    assert torch.equal(hit, g["hit"].bool())
+    same(zv, g["z_vals"], 1e-6)
+    # rays that miss: all samples collapse to z = diag/2 and only the white background shows
+    miss = ~hit
+    assert miss.any() and hit.any()
+
+
+def test_render_rays_v3(golden, oracle_params):
+    g, g3 = golden("render_b_hit"), golden("render_v3_b_hit")
+    with torch.no_grad():
+        out = O.render_rays_v3(oracle_params, g["img"], g["mask_occ"], g["cam_pose"], g["wlh"].numpy(), g["K"], g["roi"],
+                               64, g["shapecode"], g["texturecode"], True, im_sz=8, adjust_scale=float(g3["adjust_scale"]),
+                               jitter=g3["jitter"])
+    for a, k in zip(out[:3], ("rgb", "depth", "acc")):
+        same(a, g3[k], 3e-5)
+    with pytest.raises(ValueError):
+        O.render_rays_v3(oracle_params, g["img"], g["mask_occ"], g["cam_pose"], g["wlh"].numpy(), g["K"], g["roi"], 32,
+                         g["shapecode"], g["texturecode"], True, im_sz=8)
+
+
+def test_gradients_family_a(golden, oracle_params):
+    g = golden("grads_family_a")
+    sc, tc, pose = [g[k].clone().requires_grad_() for k in ("shapecode", "texturecode", "cam_pose")]
+    p = {k: v.clone().requires_grad_() for k, v in oracle_params.items()}
+    out = O.render_rays_v2(p, g["img"], g["mask_occ"], pose, np.float32(g["obj_diag"]), g["K"], g["roi"], 64, sc, tc, True,
+                           im_sz=8, jitter=g["jitter"])
+    loss, l_rgb, l_occ, psnr = O.optimise_losses(out[0], out[2], g["img"].reshape(-1, 3), g["mask_occ"].reshape(-1, 1), 0.1)
+    loss.backward()
+    same(loss, g["loss"], 1e-6); same(psnr, g["psnr"], 1e-4)
+    same(sc.grad, g["d_shapecode"], 1e-7); same(tc.grad, g["d_texturecode"], 1e-7); same(pose.grad, g["d_cam_pose"], 1e-6)
+    for k, v in p.items():
+        key = k.replace(".", "_")
+        s = g["dWsum_" + key]
+        assert abs(float(v.grad.double().sum()) - float(s[0])) <= 1e-5 * max(1.0, float(s[1]))
+        if v.dim() == 2:
+            same(v.grad[0], g["dWrow0_" + key], 1e-6)
+
+
+def test_gradients_family_b(golden, oracle_params):
+    g = golden("grads_family_b")
+    sc, tc, pose = [g[k].clone().requires_grad_() for k in ("shapecode", "texturecode", "cam_pose")]
+    out = O.nerf_renderer_render_rays(oracle_params, g["img"], g["mask_occ"], pose, g["wlh"].numpy(), g["K"], g["roi"], sc, tc,
+                                      n_samples=32, white_bkgd=True, im_sz=8, jitter=g["jitter"])
+    loss = O.optimise_losses(out[0], out[2], out[3], out[4], 0.1)[0] + 0.01 * out[1].sum()
+    loss.backward()
+    same(loss, g["loss"], 1e-6)
+    same(sc.grad, g["d_shapecode"], 1e-7); same(pose.grad, g["d_cam_pose"], 1e-6)
+
+
+def test_training_shape_step(golden, oracle_params):
+    g = golden("train_step")
+    B, n, S = g["xyz"].shape[:3]
+    sc, tc = g["shapecode"].clone().requires_grad_(), g["texturecode"].clone().requires_grad_()
+    p = {k: v.clone().requires_grad_() for k, v in oracle_params.items()}
+    sig, rgb = O.decoder_forward(p, g["xyz"].flatten(0, 1), g["viewdir"].flatten(0, 1), sc, tc)
+    out = O.volume_rendering_batch(sig.view(B, n, S, 1), rgb.view(B, n, S, 3), g["z_vals"])
+    loss = ((out[0] - g["tgt"]) ** 2).mean() + 0.1 * out[2].mean()
+    loss.backward()
+    same(loss, g["loss"], 1e-6)
+    same(sc.grad, g["d_shapecode"], 1e-7)
+    for k, v in p.items():
+        key = k.replace(".", "_")
+        if v.dim() == 2:
+            same(v.grad[0], g["dWrow0_" + key], 1e-6)
