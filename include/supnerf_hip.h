@@ -1,0 +1,174 @@
+/*
+ * supnerf_hip.h -- C ABI of libsupnerf_hip.so: the MI355X (gfx950) implementation of
+ * SUP-NeRF's volumetric rendering hot path.
+ *
+ * The reference (abhi1kumar/SUP-NeRF) has no FFI/plugin layer: its callers bind ordinary
+ * Python functions by name.  The entry points below are therefore
+ * what a ctypes/cffi stub inside the reference's src/utils.py, src/renderer.py and
+ * src/model_supnerf.py would bind to replace the bodies of those functions; each one cites
+ * the reference lines it replaces (paths relative to the reference repo).  INTEGRATION.md
+ * shows the binding.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. a torch allocation),
+ *     fp32, contiguous, 16-byte aligned where noted; the library never allocates or frees
+ *     caller-visible memory and never synchronises with the host;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - returns 0 on success or a negative SNR_E_* code; nothing is thrown across the ABI;
+ *   - re-entrant and thread-safe: no global mutable state.
+ *
+ * Layout vocabulary:  N rays, S samples per ray, P = N*S sample points, B objects
+ * (object-major: ray r belongs to object r / (N/B), src/model_supnerf.py:246-249),
+ * W = 256 hidden width / latent width, NLAT = shape_blocks + texture_blocks latent terms.
+ */
+#ifndef SUPNERF_HIP_H
+#define SUPNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNR_ABI_VERSION 1
+
+enum {
+    SNR_OK = 0,
+    SNR_E_ARG = -1,        /* null pointer / bad size / unsupported hyper-parameter */
+    SNR_E_SHAPE = -2,      /* sizes inconsistent with each other */
+    SNR_E_WORKSPACE = -3,  /* workspace too small */
+    SNR_E_LAUNCH = -4,     /* hipLaunchKernel failed (see snr_last_hip_error) */
+    SNR_E_UNSUPPORTED = -5
+};
+
+/* how per-sample depths are laid out */
+enum { SNR_Z_SHARED = 0 /* (S,) */, SNR_Z_PER_OBJECT = 1 /* (B,S) */, SNR_Z_PER_RAY = 2 /* (N,S) */ };
+
+/* flags for the render / composite entry points */
+enum {
+    SNR_WHITE_BKGD = 1,    /* rgb += 1 - sum(w)            (src/renderer.py:60-63,374-377) */
+    SNR_METRIC_Z   = 2     /* composite depth = |t*d|*z_scale (src/renderer.py:114) instead of t */
+};
+
+int snr_abi_version(void);
+/* text of the last HIP runtime error seen by this thread (for SNR_E_LAUNCH) */
+const char* snr_last_hip_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Decoder weights.  The decoder is src/model_supnerf.py:184-199 (== model_codenerf.py:22-37):
+ * width 256, latent 256, num_xyz_freq 10, num_dir_freq 4 (every shipped config).
+ * `tensors` is a HOST array of 2*(shape_blocks+texture_blocks+6) DEVICE pointers holding the
+ * per-point layers in this order, weight then bias, nn.Linear layout (out,in):
+ *   encoding_xyz.0, shape_layer_1.0 .. shape_layer_SB.0, encoding_shape, sigma.0,
+ *   encoding_viewdir.0, texture_layer_1.0 .. texture_layer_TB.0, rgb.0, rgb.2
+ * (the *_latent_layer_* tensors are per-object work and stay with the caller).
+ * The packed buffer holds the k-chunked forward stream, the transposed stream for the
+ * backward pass and the small vectors; its size in bytes is snr_packed_bytes().
+ * ---------------------------------------------------------------------------------- */
+size_t snr_packed_bytes(int shape_blocks, int texture_blocks);
+int snr_pack_weights(const float* const* tensors, int n_tensors, int shape_blocks, int texture_blocks,
+                     float* packed, void* stream);
+/* inverse map for training: scatter a packed-layout gradient buffer back to nn.Linear layout
+ * (adds the forward-stream and nothing else); tensors as above. */
+int snr_unpack_weight_grads(const float* packed_grad, float* const* tensors, int n_tensors,
+                            int shape_blocks, int texture_blocks, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Decoder on explicit sample points: replaces SUPNeRF.forward / CodeNeRF.forward
+ * (src/model_supnerf.py:241-269, src/model_codenerf.py:39-63).
+ *   xyz, viewdir : (P,3)   object-frame points and unit directions
+ *   latent       : (B,NLAT,256) z_j = ReLU(Lin_j(code)), the terms added before each block
+ *   points_per_obj = P / B
+ *   sigmas (P), rgbs (P,3) outputs (softplus density, raw linear colour)
+ *   relu_masks   : NULL, or snr_mask_bytes(P,...) bytes that the backward pass needs
+ * ---------------------------------------------------------------------------------- */
+size_t snr_mask_bytes(int64_t n_points, int shape_blocks, int texture_blocks);
+int snr_decoder_fwd(const float* xyz, const float* viewdir, const float* latent, const float* packed,
+                    int64_t n_points, int64_t points_per_obj, int shape_blocks, int texture_blocks,
+                    float* sigmas, float* rgbs, void* relu_masks, void* stream);
+/* gradients wrt latent (B,NLAT,256), xyz (P,3), viewdir (P,3) [each nullable] given d_sigmas (P)
+ * and d_rgbs (P,3).  workspace: snr_decoder_bwd_ws_bytes(). */
+size_t snr_decoder_bwd_ws_bytes(int64_t n_points, int shape_blocks, int texture_blocks);
+int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent, const float* packed,
+                    const void* relu_masks, const float* sigmas, const float* d_sigmas, const float* d_rgbs,
+                    int64_t n_points, int64_t points_per_obj, int shape_blocks, int texture_blocks,
+                    float* d_latent, float* d_xyz, float* d_viewdir,
+                    void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused render: sample points on rays -> frame transform -> PE -> decoder -> composite.
+ * Replaces the body of render_rays_v2 / render_rays_specified / render_rays /
+ * render_full_img after ray generation (src/utils.py:468-500, 523-549, 400-431, 566-600) and
+ * of NeRFRenderer.render_rays / render_rays_v3 after the box test
+ * (src/renderer.py:108-114,155-166,433-468).
+ *   rays_o, rays_d : (N,3) origin and unit direction in the sampling frame
+ *   t_vals         : depths along the ray, layout z_mode
+ *   xyz_div        : (B,) points are DIVIDED by this (family A: obj_diag, src/utils.py:472)
+ *   xyz_mul        : scalar multiplier applied next (render_rays_v3 adjust_scale, src/renderer.py:441)
+ *   frame          : 9 floats, row-major 3x3 applied to points and directions afterwards
+ *                    (sym flip, kitti2nusc, shapenet_obj_cood: src/utils.py:475-495)
+ *   z_scale        : (B,) metric scale for SNR_METRIC_Z (family B: obj_diag/2), else unused
+ *   rgb (N,3), depth (N), acc_trans (N) outputs; sigmas (P) / rgbs (P,3) optional per-point outputs
+ * ---------------------------------------------------------------------------------- */
+typedef struct snr_render_args {
+    const float* rays_o;
+    const float* rays_d;
+    const float* t_vals;
+    const float* xyz_div;
+    const float* z_scale;
+    const float* latent;
+    const float* packed;
+    float frame[9];
+    float xyz_mul;
+    int32_t z_mode;
+    int32_t flags;
+    int64_t n_rays;
+    int64_t rays_per_obj;
+    int32_t n_samples;
+    int32_t shape_blocks;
+    int32_t texture_blocks;
+    int32_t reserved;
+} snr_render_args;
+
+int snr_render_fwd(const snr_render_args* a, float* rgb, float* depth, float* acc_trans,
+                   float* sigmas, float* rgbs, void* relu_masks, void* stream);
+/* backward of the above: upstream d_rgb (N,3), d_depth (N), d_acc (N) [each nullable = zero]
+ * -> d_latent (B,NLAT,256), d_rays_o (N,3), d_rays_d (N,3), d_t (layout of t_vals, SNR_Z_PER_RAY only)
+ * [each nullable].  Needs sigmas/rgbs/relu_masks saved by the forward. */
+size_t snr_render_bwd_ws_bytes(const snr_render_args* a);
+int snr_render_bwd(const snr_render_args* a, const float* sigmas, const float* rgbs, const void* relu_masks,
+                   const float* d_rgb, const float* d_depth, const float* d_acc,
+                   float* d_latent, float* d_rays_o, float* d_rays_d, float* d_t,
+                   void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Alpha composite alone: replaces volume_rendering2 / volume_rendering_batch
+ * (src/utils.py:202-233), NeRFRenderer.volume_render (src/renderer.py:43-65) and
+ * volume_rendering3 (src/renderer.py:355-379).
+ *   sigmas (N,S), rgbs (N,S,3), z_vals per z_mode (per-object: ray r uses row r / rays_per_obj)
+ * ---------------------------------------------------------------------------------- */
+int snr_composite_fwd(const float* sigmas, const float* rgbs, const float* z_vals, int z_mode, int flags,
+                      int64_t n_rays, int64_t rays_per_obj, int n_samples,
+                      float* rgb, float* depth, float* acc_trans, void* stream);
+/* d_z (layout of z_vals) is produced only for SNR_Z_PER_RAY; pass NULL otherwise */
+int snr_composite_bwd(const float* sigmas, const float* rgbs, const float* z_vals, int z_mode, int flags,
+                      int64_t n_rays, int64_t rays_per_obj, int n_samples,
+                      const float* d_rgb, const float* d_depth, const float* d_acc,
+                      float* d_sigmas, float* d_rgbs, float* d_z, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Sample encoding alone: ray packet -> sample points (+ optional positional encoding).
+ * Replaces sample_from_rays + the in-place frame edits (src/utils.py:154-167,472-495), the
+ * point/metric-depth part of NeRFRenderer.prepare_sampled_rays (src/renderer.py:111-114) and
+ * PE (src/model_supnerf.py:155-161).  Arguments as snr_render_args; outputs
+ *   xyz (N,S,3), viewdir (N,S,3), z_out (N,S) [nullable], pe_xyz (N,S,63) [nullable],
+ *   pe_dir (N,27) [nullable; constant along S]
+ * ---------------------------------------------------------------------------------- */
+int snr_encode_fwd(const snr_render_args* a, float* xyz, float* viewdir, float* z_out,
+                   float* pe_xyz, float* pe_dir, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUPNERF_HIP_H */

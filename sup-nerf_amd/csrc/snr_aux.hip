@@ -1,0 +1,372 @@
+// HBM-bound helper kernels for gfx950: weight packing, standalone alpha composite (forward and
+// analytic backward), standalone sample encoding, and the small reductions used by the backward pass.
+#include "snr_device.hpp"
+#include "snr_host.hpp"
+
+namespace snr {
+
+// ============================================================================ weight packing
+// W is nn.Linear layout (n_out, k_in).  Forward stream: chunk c holds rows n (n_out of them) x 32
+// reduction columns k = 32c..32c+31 (zero beyond k_in).  Backward stream: chunk c holds rows k
+// (rows_pad of them, zero beyond k_in) x 32 reduction columns n = 32c..32c+31.
+__global__ void pack_fwd_kernel(const float* __restrict__ Wt, int n_out, int k_in, int n_chunks, float* __restrict__ dst) {
+    const long long total = (long long)n_chunks * n_out * KC;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % KC);
+        const int row = (int)((i / KC) % n_out);
+        const int c = (int)(i / ((long long)KC * n_out));
+        const int k = c * KC + kk;
+        dst[(long long)c * n_out * KC + chunk_pos(row, kk)] = (k < k_in) ? Wt[(long long)row * k_in + k] : 0.f;
+    }
+}
+
+__global__ void pack_bwd_kernel(const float* __restrict__ Wt, int n_out, int k_in, int rows_pad, float* __restrict__ dst) {
+    const int n_chunks = n_out / KC;
+    const long long total = (long long)n_chunks * rows_pad * KC;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % KC);
+        const int row = (int)((i / KC) % rows_pad);
+        const int c = (int)(i / ((long long)KC * rows_pad));
+        const int n = c * KC + kk;
+        dst[(long long)c * rows_pad * KC + chunk_pos(row, kk)] = (row < k_in) ? Wt[(long long)n * k_in + row] : 0.f;
+    }
+}
+
+__global__ void copy_pad_kernel(const float* __restrict__ src, int n, float* __restrict__ dst, int n_pad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pad) dst[i] = (i < n) ? src[i] : 0.f;
+}
+
+// scatter-add of a packed forward-stream gradient back into nn.Linear layout
+__global__ void unpack_fwd_kernel(const float* __restrict__ src, int n_out, int k_in, int n_chunks, float* __restrict__ dW) {
+    const long long total = (long long)n_out * k_in;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % k_in);
+        const int row = (int)(i / k_in);
+        const int c = k / KC, kk = k % KC;
+        dW[i] = src[(long long)c * n_out * KC + chunk_pos(row, kk)];
+    }
+}
+
+// ============================================================================ composite
+__global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                            const float* __restrict__ zv, int z_mode, int flags, long long n_rays,
+                                                            long long rays_per_obj, int S, float* __restrict__ rgb,
+                                                            float* __restrict__ depth, float* __restrict__ acc) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const bool white = flags & SNR_WHITE_BKGD;
+    for (long long ray = wave0; ray < n_rays; ray += n_waves) {
+        const float* zrow = zv + (z_mode == SNR_Z_SHARED ? 0 : (z_mode == SNR_Z_PER_OBJECT ? (ray / rays_per_obj) * S : ray * S));
+        const float* srow = sigmas + ray * S;
+        const float* crow = rgbs + ray * S * 3;
+        RayOut o = composite_ray_fwd(S, lane, white, [&](int k, float& sg, float& cr, float& cg, float& cb, float& z, float& zn) {
+            sg = srow[k]; cr = crow[3 * k]; cg = crow[3 * k + 1]; cb = crow[3 * k + 2];
+            z = zrow[k]; zn = (k < S - 1) ? zrow[k + 1] : 0.f;
+        });
+        if (lane == 0) {
+            rgb[ray * 3] = o.r; rgb[ray * 3 + 1] = o.g; rgb[ray * 3 + 2] = o.b;
+            depth[ray] = o.depth; acc[ray] = o.acc;
+        }
+    }
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                            const float* __restrict__ zv, int z_mode, int flags, long long n_rays,
+                                                            long long rays_per_obj, int S, const float* __restrict__ d_rgb,
+                                                            const float* __restrict__ d_depth, const float* __restrict__ d_acc,
+                                                            float* __restrict__ d_sigmas, float* __restrict__ d_rgbs,
+                                                            float* __restrict__ d_z) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const bool white = flags & SNR_WHITE_BKGD;
+    for (long long ray = wave0; ray < n_rays; ray += n_waves) {
+        const float* zrow = zv + (z_mode == SNR_Z_SHARED ? 0 : (z_mode == SNR_Z_PER_OBJECT ? (ray / rays_per_obj) * S : ray * S));
+        const float* srow = sigmas + ray * S;
+        const float* crow = rgbs + ray * S * 3;
+        const float gr = d_rgb ? d_rgb[ray * 3] : 0.f, gg = d_rgb ? d_rgb[ray * 3 + 1] : 0.f, gb = d_rgb ? d_rgb[ray * 3 + 2] : 0.f;
+        const float gd = d_depth ? d_depth[ray] : 0.f, ga = d_acc ? d_acc[ray] : 0.f;
+        composite_ray_bwd<NCH>(S, lane, white, gr, gg, gb, gd, ga,
+            [&](int k, float& sg, float& cr, float& cg, float& cb, float& z, float& zn) {
+                sg = srow[k]; cr = crow[3 * k]; cg = crow[3 * k + 1]; cb = crow[3 * k + 2];
+                z = zrow[k]; zn = (k < S - 1) ? zrow[k + 1] : 0.f;
+            },
+            [&](int k, float ds, float dcr, float dcg, float dcb, float dz) {
+                d_sigmas[ray * S + k] = ds;
+                float* o = d_rgbs + (ray * S + k) * 3;
+                o[0] = dcr; o[1] = dcg; o[2] = dcb;
+                if (d_z) d_z[ray * S + k] = dz;
+            });
+    }
+}
+
+// ============================================================================ encode
+// Block of 256 threads = 256 consecutive sample points.  Phase 1: one thread per point computes the
+// sample (coalesced xyz / viewdir / z stores).  Phase 2: the block's 256x63 positional-encoding
+// features are produced in flat output order so every store instruction is fully coalesced.
+__global__ void __launch_bounds__(256) encode_kernel(RayGeom g, float* __restrict__ xyz, float* __restrict__ viewdir,
+                                                     float* __restrict__ z_out, float* __restrict__ pe_xyz) {
+    __shared__ float sx[256][3];
+    const long long P = g.n_rays * g.S;
+    const long long base = blockIdx.x * 256ll;
+    const long long gp = base + threadIdx.x;
+    if (gp < P) {
+        const long long ray = gp / g.S;
+        const int s = (int)(gp - ray * g.S);
+        SamplePoint sp = make_sample(g, ray, s);
+        sx[threadIdx.x][0] = sp.x; sx[threadIdx.x][1] = sp.y; sx[threadIdx.x][2] = sp.z;
+        if (xyz) { xyz[gp * 3] = sp.x; xyz[gp * 3 + 1] = sp.y; xyz[gp * 3 + 2] = sp.z; }
+        if (viewdir) { viewdir[gp * 3] = sp.dx; viewdir[gp * 3 + 1] = sp.dy; viewdir[gp * 3 + 2] = sp.dz; }
+        if (z_out) z_out[gp] = sp.zc;
+    }
+    if (!pe_xyz) return;
+    __syncthreads();
+    const long long n_here = (P - base) < 256 ? (P - base) : 256;
+    const int total = (int)n_here * D_XYZ;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int p = i / D_XYZ, f = i - p * D_XYZ;
+        float v;
+        if (f < 3) v = sx[p][f];
+        else {
+            const int q = (f - 3) % (3 * XYZ_FREQ);
+            const float arg = ldexpf(sx[p][q % 3], q / 3);
+            v = (f < 3 + 3 * XYZ_FREQ) ? sinf(arg) : cosf(arg);
+        }
+        pe_xyz[base * D_XYZ + i] = v;
+    }
+}
+
+__global__ void encode_dir_kernel(RayGeom g, float* __restrict__ pe_dir) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= g.n_rays * D_DIR) return;
+    const long long ray = i / D_DIR;
+    const int f = (int)(i - ray * D_DIR);
+    const float dx = g.rays_d[ray * 3], dy = g.rays_d[ray * 3 + 1], dz = g.rays_d[ray * 3 + 2];
+    const float vx = g.m[0] * dx + g.m[1] * dy + g.m[2] * dz, vy = g.m[3] * dx + g.m[4] * dy + g.m[5] * dz,
+                vz = g.m[6] * dx + g.m[7] * dy + g.m[8] * dz;
+    float v;
+    if (f < 3) v = pick3(vx, vy, vz, f);
+    else {
+        const int q = (f - 3) % (3 * DIR_FREQ);
+        const float arg = ldexpf(pick3(vx, vy, vz, q % 3), q / 3);
+        v = (f < 3 + 3 * DIR_FREQ) ? sinf(arg) : cosf(arg);
+    }
+    pe_dir[i] = v;
+}
+
+// ============================================================================ backward reductions
+// d_latent[obj][j][k] = sum over the object's wave tiles of partial[tile][j][k]
+__global__ void reduce_latent_kernel(const float* __restrict__ partial, long long tiles_per_obj, int n_lat,
+                                     float* __restrict__ d_latent) {
+    const int obj = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over n_lat*256
+    if (idx >= n_lat * 256) return;
+    const float* p = partial + (long long)obj * tiles_per_obj * n_lat * 256 + idx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long long t = 0;
+    const long long stride = (long long)n_lat * 256;
+    for (; t + 3 < tiles_per_obj; t += 4) {
+        s0 += p[t * stride]; s1 += p[(t + 1) * stride]; s2 += p[(t + 2) * stride]; s3 += p[(t + 3) * stride];
+    }
+    for (; t < tiles_per_obj; ++t) s0 += p[t * stride];
+    d_latent[(long long)obj * n_lat * 256 + idx] = (s0 + s1) + (s2 + s3);
+}
+
+}  // namespace snr
+
+using namespace snr;
+
+// ============================================================================ C ABI
+extern "C" {
+
+int snr_abi_version(void) { return SNR_ABI_VERSION; }
+
+static thread_local const char* g_last_err = "";
+const char* snr_last_hip_error(void) { return g_last_err; }
+int snr_check_launch_(void) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_err = hipGetErrorString(e); return SNR_E_LAUNCH; }
+    return SNR_OK;
+}
+
+size_t snr_packed_bytes(int sb, int tb) {
+    if (sb < 0 || tb < 0 || sb > MAX_BLOCKS || tb > MAX_BLOCKS) return 0;
+    return (size_t)make_layout(sb, tb).total * sizeof(float);
+}
+
+size_t snr_mask_bytes(int64_t n_points, int sb, int tb) { return (size_t)mask_bytes(n_points, sb, tb); }
+
+static inline int grid_for(long long total, int block = 256, int cap = 4096) {
+    long long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+int snr_pack_weights(const float* const* t, int n_tensors, int sb, int tb, float* packed, void* stream_) {
+    if (!t || !packed || sb < 0 || tb < 0 || sb > MAX_BLOCKS || tb > MAX_BLOCKS) return SNR_E_ARG;
+    if (n_tensors != 2 * (sb + tb + 6)) return SNR_E_SHAPE;
+    for (int i = 0; i < n_tensors; ++i) if (!t[i]) return SNR_E_ARG;
+    hipStream_t st = (hipStream_t)stream_;
+    const Layout L = make_layout(sb, tb);
+    // tensor index helpers (weight, bias pairs in reference order without the latent layers)
+    int ti = 0;
+    auto Wp = [&](int i) { return t[2 * i]; };
+    auto Bp = [&](int i) { return t[2 * i + 1]; };
+    const int i_xyz = ti++;
+    int i_shape[MAX_BLOCKS]; for (int j = 0; j < sb; ++j) i_shape[j] = ti++;
+    const int i_encshape = ti++;
+    const int i_sigma = ti++;
+    const int i_view = ti++;
+    int i_tex[MAX_BLOCKS]; for (int j = 0; j < tb; ++j) i_tex[j] = ti++;
+    const int i_rgb0 = ti++;
+    const int i_rgb2 = ti++;
+    const long long c256 = 256 * KC;
+
+    // ---- forward stream
+    float* f = packed + L.fwd;
+    auto fwd = [&](const float* Wsrc, int n_out, int k_in, int n_chunks) {
+        pack_fwd_kernel<<<grid_for((long long)n_chunks * n_out * KC), 256, 0, st>>>(Wsrc, n_out, k_in, n_chunks, f);
+        f += (long long)n_chunks * n_out * KC;
+    };
+    fwd(Wp(i_xyz), 256, D_XYZ, 2);
+    for (int j = 0; j < sb; ++j) fwd(Wp(i_shape[j]), 256, 256, 8);
+    fwd(Wp(i_encshape), 256, 256, 8);
+    fwd(Wp(i_view), 256, 256 + D_DIR, 9);
+    for (int j = 0; j < tb; ++j) fwd(Wp(i_tex[j]), 256, 256, 8);
+    fwd(Wp(i_rgb0), 128, 256, 8);
+    if (f - (packed + L.fwd) != L.fwd_floats) return SNR_E_SHAPE;
+
+    // ---- backward stream (reverse consumption order)
+    float* b = packed + L.bwd;
+    auto bwd = [&](const float* Wsrc, int n_out, int k_in, int rows_pad) {
+        const int n_chunks = n_out / KC;
+        pack_bwd_kernel<<<grid_for((long long)n_chunks * rows_pad * KC), 256, 0, st>>>(Wsrc, n_out, k_in, rows_pad, b);
+        b += (long long)n_chunks * rows_pad * KC;
+    };
+    bwd(Wp(i_rgb0), 128, 256, 256);
+    for (int j = tb - 1; j >= 0; --j) bwd(Wp(i_tex[j]), 256, 256, 256);
+    bwd(Wp(i_view), 256, 256 + D_DIR, K_VIEW_PAD);
+    bwd(Wp(i_encshape), 256, 256, 256);
+    for (int j = sb - 1; j >= 0; --j) bwd(Wp(i_shape[j]), 256, 256, 256);
+    bwd(Wp(i_xyz), 256, D_XYZ, K_XYZ_PAD);
+    if (b - (packed + L.bwd) != L.bwd_floats) return SNR_E_SHAPE;
+    (void)c256;
+
+    // ---- vectors
+    auto vec = [&](const float* src, int n, long long off, int n_pad) {
+        copy_pad_kernel<<<(n_pad + 255) / 256, 256, 0, st>>>(src, n, packed + off, n_pad);
+    };
+    vec(Bp(i_xyz), 256, L.bias + 256ll * layer_enc_xyz(), 256);
+    for (int j = 0; j < sb; ++j) vec(Bp(i_shape[j]), 256, L.bias + 256ll * layer_shape(j), 256);
+    vec(Bp(i_encshape), 256, L.bias + 256ll * layer_enc_shape(sb), 256);
+    vec(Bp(i_view), 256, L.bias + 256ll * layer_viewdir(sb), 256);
+    for (int j = 0; j < tb; ++j) vec(Bp(i_tex[j]), 256, L.bias + 256ll * layer_texture(sb, j), 256);
+    vec(Bp(i_rgb0), 128, L.bias + 256ll * layer_rgb0(sb, tb), 256);
+    vec(Wp(i_sigma), 256, L.sigma_w, 256);
+    vec(Bp(i_sigma), 1, L.sigma_b, 4);
+    vec(Wp(i_rgb2), 3 * 128, L.rgb2_w, 3 * 128);
+    vec(Bp(i_rgb2), 3, L.rgb2_b, 4);
+    return snr_check_launch_();
+}
+
+int snr_unpack_weight_grads(const float* pg, float* const* t, int n_tensors, int sb, int tb, void* stream_) {
+    if (!pg || !t || sb < 0 || tb < 0 || sb > MAX_BLOCKS || tb > MAX_BLOCKS) return SNR_E_ARG;
+    if (n_tensors != 2 * (sb + tb + 6)) return SNR_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream_;
+    const Layout L = make_layout(sb, tb);
+    int ti = 0;
+    const float* f = pg + L.fwd;
+    auto un = [&](int idx, int n_out, int k_in, int n_chunks) {
+        if (t[2 * idx]) unpack_fwd_kernel<<<grid_for((long long)n_out * k_in), 256, 0, st>>>(f, n_out, k_in, n_chunks, t[2 * idx]);
+        f += (long long)n_chunks * n_out * KC;
+    };
+    auto vec = [&](float* dst, int n, long long off) {
+        if (dst) copy_pad_kernel<<<(n + 255) / 256, 256, 0, st>>>(pg + off, n, dst, n);
+    };
+    const int i_xyz = ti++;
+    int i_shape[MAX_BLOCKS]; for (int j = 0; j < sb; ++j) i_shape[j] = ti++;
+    const int i_encshape = ti++, i_sigma = ti++, i_view = ti++;
+    int i_tex[MAX_BLOCKS]; for (int j = 0; j < tb; ++j) i_tex[j] = ti++;
+    const int i_rgb0 = ti++, i_rgb2 = ti++;
+    un(i_xyz, 256, D_XYZ, 2);
+    for (int j = 0; j < sb; ++j) un(i_shape[j], 256, 256, 8);
+    un(i_encshape, 256, 256, 8);
+    un(i_view, 256, 256 + D_DIR, 9);
+    for (int j = 0; j < tb; ++j) un(i_tex[j], 256, 256, 8);
+    un(i_rgb0, 128, 256, 8);
+    vec(t[2 * i_xyz + 1], 256, L.bias + 256ll * layer_enc_xyz());
+    for (int j = 0; j < sb; ++j) vec(t[2 * i_shape[j] + 1], 256, L.bias + 256ll * layer_shape(j));
+    vec(t[2 * i_encshape + 1], 256, L.bias + 256ll * layer_enc_shape(sb));
+    vec(t[2 * i_view + 1], 256, L.bias + 256ll * layer_viewdir(sb));
+    for (int j = 0; j < tb; ++j) vec(t[2 * i_tex[j] + 1], 256, L.bias + 256ll * layer_texture(sb, j));
+    vec(t[2 * i_rgb0 + 1], 128, L.bias + 256ll * layer_rgb0(sb, tb));
+    vec(t[2 * i_sigma], 256, L.sigma_w);
+    vec(t[2 * i_sigma + 1], 1, L.sigma_b);
+    vec(t[2 * i_rgb2], 3 * 128, L.rgb2_w);
+    vec(t[2 * i_rgb2 + 1], 3, L.rgb2_b);
+    return snr_check_launch_();
+}
+
+int snr_composite_fwd(const float* sigmas, const float* rgbs, const float* z_vals, int z_mode, int flags, int64_t n_rays,
+                      int64_t rays_per_obj, int S, float* rgb, float* depth, float* acc, void* stream_) {
+    if (n_rays == 0) return SNR_OK;      /* empty ray packet: nothing to do, pointers may be null */
+    if (!sigmas || !rgbs || !z_vals || !rgb || !depth || !acc) return SNR_E_ARG;
+    if (n_rays < 0 || S < 1 || z_mode < 0 || z_mode > 2) return SNR_E_ARG;
+    if (z_mode == SNR_Z_PER_OBJECT && (rays_per_obj < 1)) return SNR_E_SHAPE;
+    if (rays_per_obj < 1) rays_per_obj = n_rays;
+    const int grid = grid_for(n_rays * 64, 256, 8192);
+    composite_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(sigmas, rgbs, z_vals, z_mode, flags, n_rays, rays_per_obj, S, rgb, depth, acc);
+    return snr_check_launch_();
+}
+
+int snr_composite_bwd(const float* sigmas, const float* rgbs, const float* z_vals, int z_mode, int flags, int64_t n_rays,
+                      int64_t rays_per_obj, int S, const float* d_rgb, const float* d_depth, const float* d_acc,
+                      float* d_sigmas, float* d_rgbs, float* d_z, void* stream_) {
+    if (n_rays == 0) return SNR_OK;
+    if (!sigmas || !rgbs || !z_vals || !d_sigmas || !d_rgbs) return SNR_E_ARG;
+    if (n_rays < 0 || S < 1 || z_mode < 0 || z_mode > 2) return SNR_E_ARG;
+    if (d_z && z_mode != SNR_Z_PER_RAY) return SNR_E_UNSUPPORTED;
+    if (S > 256) return SNR_E_UNSUPPORTED;
+    if (rays_per_obj < 1) rays_per_obj = n_rays;
+    const int grid = grid_for(n_rays * 64, 256, 8192);
+    hipStream_t st = (hipStream_t)stream_;
+#define SNR_LAUNCH_CB(N) composite_bwd_kernel<N><<<grid, 256, 0, st>>>(sigmas, rgbs, z_vals, z_mode, flags, n_rays, rays_per_obj, S, \
+                                                                        d_rgb, d_depth, d_acc, d_sigmas, d_rgbs, d_z)
+    if (S <= 64) SNR_LAUNCH_CB(1); else if (S <= 128) SNR_LAUNCH_CB(2); else if (S <= 192) SNR_LAUNCH_CB(3); else SNR_LAUNCH_CB(4);
+#undef SNR_LAUNCH_CB
+    return snr_check_launch_();
+}
+
+int snr_encode_fwd(const snr_render_args* a, float* xyz, float* viewdir, float* z_out, float* pe_xyz, float* pe_dir, void* stream_) {
+    RayGeom g;
+    int rc = snr_fill_geom_(a, &g, /*need_model=*/0);
+    if (rc != SNR_OK) return rc;
+    if (a->n_rays == 0) return SNR_OK;
+    hipStream_t st = (hipStream_t)stream_;
+    const long long P = a->n_rays * a->n_samples;
+    encode_kernel<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(g, xyz, viewdir, z_out, pe_xyz);
+    if (pe_dir) encode_dir_kernel<<<(unsigned)((a->n_rays * D_DIR + 255) / 256), 256, 0, st>>>(g, pe_dir);
+    return snr_check_launch_();
+}
+
+}  // extern "C"
+
+// shared with snr_mlp.hip
+int snr_fill_geom_(const snr_render_args* a, snr::RayGeom* g, int need_model) {
+    if (!a || !a->rays_o || !a->rays_d || !a->t_vals || !a->xyz_div) return SNR_E_ARG;
+    if (a->n_rays < 0 || a->n_samples < 1 || a->z_mode < 0 || a->z_mode > 2) return SNR_E_ARG;
+    if ((a->flags & SNR_METRIC_Z) && !a->z_scale) return SNR_E_ARG;
+    if (a->rays_per_obj < 1 || (a->n_rays % a->rays_per_obj) != 0) return SNR_E_SHAPE;
+    if (need_model) {
+        if (!a->latent || !a->packed) return SNR_E_ARG;
+        if (a->shape_blocks < 0 || a->texture_blocks < 0 || a->shape_blocks > snr::MAX_BLOCKS || a->texture_blocks > snr::MAX_BLOCKS)
+            return SNR_E_ARG;
+    }
+    g->rays_o = a->rays_o; g->rays_d = a->rays_d; g->t_vals = a->t_vals; g->xyz_div = a->xyz_div; g->z_scale = a->z_scale;
+    for (int i = 0; i < 9; ++i) g->m[i] = a->frame[i];
+    g->xyz_mul = a->xyz_mul; g->z_mode = a->z_mode; g->flags = a->flags;
+    g->n_rays = a->n_rays; g->rays_per_obj = a->rays_per_obj; g->S = a->n_samples;
+    return SNR_OK;
+}

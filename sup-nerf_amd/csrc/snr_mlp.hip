@@ -1,0 +1,387 @@
+// Fused decoder kernels for gfx950 (MI355X): positional encoding -> code-conditioned MLP on the
+// fp32 MFMA pipe -> (optionally) wavefront alpha composite, in one launch.
+//
+// Design:
+//   * One workgroup = 4 wavefronts = 128 consecutive sample points; one wave per SIMD so each wave
+//     may use the whole 512-entry unified register file.
+//   * The GEMMs are computed transposed, Y^T = W * X^T, with v_mfma_f32_32x32x2_f32: the weight slice
+//     is the A operand (rows = output features), the 32 points of the wave are the B/C/D columns
+//     (lane & 31 = point).  With that orientation the 32x32 accumulator tile of layer l *is* the B
+//     operand of layer l+1 (register r of lane (p,h) holds feature 32t + 8(r>>2) + 4h + (r&3), exactly
+//     the k a B operand needs when the A fragment is read with one 16-byte LDS load), so activations
+//     never leave the registers: no LDS or HBM traffic between layers.
+//   * Weights stream from L2 through a double-buffered LDS ring in 32-deep k-chunks (ROWS x 32 fp32,
+//     XOR-swizzled 16-byte slots -> conflict-free ds_read_b128) filled by LDS-DMA, shared by the 4 waves.
+//   * Bias / latent adds, ReLU, softplus, the 256->1 density head and the 128->3 colour head run on
+//     the VALU in the accumulator layout; the composite is a 64-lane product scan.
+#include "snr_device.hpp"
+#include "snr_host.hpp"
+
+namespace snr {
+
+constexpr int WBUF = K_VIEW_PAD * KC;               // floats per weight buffer (288 rows x 32, swizzled, no padding)
+constexpr int PE_ROW = 97;                          // per-point scratch row: 64 xyz features + 32 dir features + 1
+constexpr int PE_WAVE = 32 * PE_ROW;
+constexpr int LDS_SCRATCH = 2 * WBUF;               // 4 waves x PE_WAVE
+constexpr int COMP_STRIDE = 8;                      // sigma r g b zc + pad
+constexpr int LDS_COMP = LDS_SCRATCH + 4 * PE_WAVE;
+constexpr int LDS_TOTAL = LDS_COMP + 128 * COMP_STRIDE;   // floats
+static_assert(LDS_TOTAL * 4 <= 160 * 1024, "LDS budget");
+
+// Weight chunks are stored in the packed stream as the exact LDS image (snr_layout.h: 16-byte slot
+// c of row n sits at slot c ^ ((n >> 1) & 7)), so staging is a linear LDS-DMA copy: 1 KiB per
+// wave-instruction, no VGPRs, no ds_write.  `rows` x 128 B, 256 threads x 16 B per step.
+__device__ __forceinline__ void chunk_dma(const float* __restrict__ g, float* lds, int rows, int tid) {
+    const int nvec = rows * 8;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        if (i * 256 < nvec) {    // rows is a multiple of 32: uniform over the workgroup
+            typedef const __attribute__((address_space(1))) void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + (size_t)(i * 256 + tid) * 4), (lptr_t)(lds + (i * 256 + wave * 64) * 4), 16, 0, 0);
+        }
+    }
+}
+
+// one 32-deep k-chunk: acc[t] += W[32t..32t+31][chunk] * b     (NT output tiles).
+// aoff[j] = this lane's float offset of 16-byte slot (2j + h) in row (lane & 31), swizzle applied.
+// The A fragment of the next 4 MFMAs is fetched before the current 4 are issued.
+template <int NT>
+__device__ __forceinline__ void chunk_mma(f32x16 (&acc)[8], const float (&b)[16], const float* wbuf, const int (&aoff)[4]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(wbuf + aoff[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 an = a;
+            if (t + 1 < NT) an = *reinterpret_cast<const f32x4*>(wbuf + aoff[j] + (t + 1) * 32 * KC);
+            else if (j + 1 < 4) an = *reinterpret_cast<const f32x4*>(wbuf + aoff[j + 1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[4 * j + e], acc[t], 0, 0, 0);
+            a = an;
+        }
+    }
+}
+
+struct Pipe {
+    const float* next;   // next chunk to fetch from the packed stream
+    int cur;             // LDS buffer holding the chunk about to be consumed
+    int aoff[4];         // per-lane A-fragment offsets (see chunk_mma)
+};
+
+__device__ __forceinline__ void pipe_init(Pipe& p, const float* stream, int lane) {
+    p.next = stream;
+    p.cur = 0;
+    const int n = lane & 31, h = lane >> 5, sw = (n >> 1) & 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p.aoff[j] = n * KC + (((2 * j + h) ^ sw) << 2);
+}
+
+// consume the current chunk while the following one (rows_next x 32; 0 = none) lands in the other buffer
+template <int NT>
+__device__ __forceinline__ void step(f32x16 (&acc)[8], const float (&b)[16], Pipe& p, float* lds, int rows_next, int tid) {
+    if (rows_next) chunk_dma(p.next, lds + (p.cur ^ 1) * WBUF, rows_next, tid);
+    chunk_mma<NT>(acc, b, lds + p.cur * WBUF, p.aoff);
+    p.next += rows_next * KC;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    p.cur ^= 1;
+}
+
+template <int NT>
+__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[8], const float* __restrict__ bias, int h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * t + 8 * j + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * j + e] = bv[e];
+        }
+}
+
+// accumulators -> next layer's operand registers: optional ReLU (+ mask bits), optional latent add
+template <int NT>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[8], float (&in)[9][16], bool relu, const float* __restrict__ zlat, int h,
+                                         uint32_t (&mask)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mask[i] = 0u;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+            if (zlat) zv = *reinterpret_cast<const f32x4*>(zlat + 32 * t + 8 * j + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[t][4 * j + e];
+                if (relu) {
+                    if (v > 0.f) mask[t >> 1] |= 1u << ((t & 1) * 16 + 4 * j + e);
+                    v = fmaxf(v, 0.f);
+                }
+                in[t][4 * j + e] = v + zv[e];
+            }
+        }
+}
+
+// which latent term (index into the (B,NLAT,256) table) is added after MFMA layer li; -1 = none
+__device__ __forceinline__ int latent_after(int li, int sb, int tb) {
+    if (li < sb) return li;                          // enc_xyz -> z_1, shape_j -> z_{j+1}
+    if (li == sb + 2 && tb > 0) return sb;           // enc_viewdir -> first texture latent
+    if (li > sb + 2 && li < sb + 2 + tb) return li - 2;   // texture_j -> next texture latent
+    return -1;
+}
+// index of MFMA layer li among the ReLU layers (enc_shape has none)
+__device__ __forceinline__ int relu_slot(int li, int sb) { return li <= sb ? li : li - 1; }
+
+struct DecoderIO {
+    const float* packed;
+    const float* latent;      // (B, n_lat, 256)
+    int sb, tb;
+    long long n_points;
+    long long points_per_obj;
+    float* sigmas;            // (P) optional
+    float* rgbs;              // (P,3) optional
+    uint4* masks;             // optional
+};
+
+// -------------------------------------------------------------------------------------------
+// The decoder for the 32 points of this wave.  Inputs: point (x,y,z) and direction (dx,dy,dz) of
+// lane's point p = lane & 31 (both half-waves hold the same point).  Outputs sigma, r, g, b valid in
+// every lane.  All four waves of the workgroup must call it together (block-wide barriers inside).
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const Layout& L, float* lds, long long gp /*clamped point id*/,
+                                                     long long tile32, float x, float y, float z, float dx, float dy, float dz,
+                                                     float& o_sigma, float& o_r, float& o_g, float& o_b) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const int sb = io.sb, tb = io.tb;
+    const int n_relu = n_relu_layers(sb, tb);
+    const float* bias = io.packed + L.bias;
+    const float* lat = io.latent + (gp / io.points_per_obj) * (long long)L.n_lat * 256;
+
+    float in[9][16];
+    f32x16 acc[8];
+    uint32_t mask[4];
+
+    // ---- prologue: first weight chunk in flight while the positional encodings are computed
+    Pipe pipe;
+    pipe_init(pipe, io.packed + L.fwd, lane);
+    {
+        chunk_dma(pipe.next, lds, 256, tid);
+        pipe.next += 256 * KC;
+        float* sc = lds + LDS_SCRATCH + wave * PE_WAVE + p * PE_ROW;
+        // 30 (freq, axis) pairs of the xyz encoding, 15 per half-wave; 12 of the direction encoding, 6 each
+#pragma unroll 1
+        for (int i = 0; i < 15; ++i) {
+            const int q = 15 * h + i;
+            float sn, cs;
+            sincosf(ldexpf(pick3(x, y, z, q % 3), q / 3), &sn, &cs);
+            sc[3 + q] = sn; sc[3 + 3 * XYZ_FREQ + q] = cs;
+        }
+#pragma unroll 1
+        for (int i = 0; i < 6; ++i) {
+            const int q = 6 * h + i;
+            float sn, cs;
+            sincosf(ldexpf(pick3(dx, dy, dz, q % 3), q / 3), &sn, &cs);
+            sc[64 + 3 + q] = sn; sc[64 + 3 + 3 * DIR_FREQ + q] = cs;
+        }
+        if (h == 0) {
+            sc[0] = x; sc[1] = y; sc[2] = z; sc[63] = 0.f;
+            sc[64] = dx; sc[65] = dy; sc[66] = dz;
+#pragma unroll
+            for (int f = D_DIR; f < 32; ++f) sc[64 + f] = 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // operand registers: register 4j+e of tile c <- feature 32c + 8j + 4h + e
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) in[c][r] = sc[32 * c + 8 * (r >> 2) + 4 * h + (r & 3)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) in[8][r] = sc[64 + 8 * (r >> 2) + 4 * h + (r & 3)];
+    }
+
+    // ---- enc_xyz: 64 -> 256
+    acc_init_bias<8>(acc, bias, h);
+    step<8>(acc, in[0], pipe, lds, 256, tid);
+    step<8>(acc, in[1], pipe, lds, 256, tid);
+    {
+        const int la = latent_after(0, sb, tb);
+        epilogue<8>(acc, in, true, la >= 0 ? lat + la * 256 : nullptr, h, mask);
+        if (io.masks) io.masks[(tile32 * n_relu + 0) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
+    }
+
+    // ---- the 256-wide middle layers: shape blocks, enc_shape, enc_viewdir, texture blocks
+    const int li_encshape = sb + 1, li_view = sb + 2, li_last = sb + tb + 2;
+    o_sigma = 0.f;
+#pragma unroll 1
+    for (int li = 1; li <= li_last; ++li) {
+        const bool is_view = (li == li_view);
+        const int rows_after = (li == li_last) ? 128 : 256;
+        acc_init_bias<8>(acc, bias + li * 256, h);
+        step<8>(acc, in[0], pipe, lds, 256, tid);
+        step<8>(acc, in[1], pipe, lds, 256, tid);
+        step<8>(acc, in[2], pipe, lds, 256, tid);
+        step<8>(acc, in[3], pipe, lds, 256, tid);
+        step<8>(acc, in[4], pipe, lds, 256, tid);
+        step<8>(acc, in[5], pipe, lds, 256, tid);
+        step<8>(acc, in[6], pipe, lds, 256, tid);
+        step<8>(acc, in[7], pipe, lds, is_view ? 256 : rows_after, tid);
+        if (is_view) step<8>(acc, in[8], pipe, lds, rows_after, tid);
+        const bool relu = (li != li_encshape);
+        const int la = latent_after(li, sb, tb);
+        epilogue<8>(acc, in, relu, la >= 0 ? lat + la * 256 : nullptr, h, mask);
+        if (relu && io.masks)
+            io.masks[(tile32 * n_relu + relu_slot(li, sb)) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
+        if (li == li_encshape) {
+            // density head: softplus(w_sigma . y + b)   (src/model_supnerf.py:257)
+            const float* ws = io.packed + L.sigma_w;
+            float part = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + 32 * t + 8 * j + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) part = fmaf(wv[e], in[t][4 * j + e], part);
+                }
+            const float pre = part + __shfl_xor(part, 32, 64) + io.packed[L.sigma_b];
+            o_sigma = pre > 20.f ? pre : log1pf(expf(pre));
+        }
+    }
+
+    // ---- rgb.0: 256 -> 128, ReLU;  rgb.2: 128 -> 3 on the VALU
+    acc_init_bias<4>(acc, bias + (li_last + 1) * 256, h);
+    step<4>(acc, in[0], pipe, lds, 128, tid);
+    step<4>(acc, in[1], pipe, lds, 128, tid);
+    step<4>(acc, in[2], pipe, lds, 128, tid);
+    step<4>(acc, in[3], pipe, lds, 128, tid);
+    step<4>(acc, in[4], pipe, lds, 128, tid);
+    step<4>(acc, in[5], pipe, lds, 128, tid);
+    step<4>(acc, in[6], pipe, lds, 128, tid);
+    step<4>(acc, in[7], pipe, lds, 0, tid);
+    epilogue<4>(acc, in, true, nullptr, h, mask);
+    if (io.masks) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mask[0], mask[1], 0u, 0u);
+    {
+        const float* w2 = io.packed + L.rgb2_w;
+        float pr = 0.f, pg = 0.f, pb = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n0 = 32 * t + 8 * j + 4 * h;
+                const f32x4 wr = *reinterpret_cast<const f32x4*>(w2 + n0);
+                const f32x4 wg = *reinterpret_cast<const f32x4*>(w2 + 128 + n0);
+                const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + n0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = in[t][4 * j + e];
+                    pr = fmaf(wr[e], v, pr); pg = fmaf(wg[e], v, pg); pb = fmaf(wb[e], v, pb);
+                }
+            }
+        const float* b2 = io.packed + L.rgb2_b;
+        o_r = pr + __shfl_xor(pr, 32, 64) + b2[0];
+        o_g = pg + __shfl_xor(pg, 32, 64) + b2[1];
+        o_b = pb + __shfl_xor(pb, 32, 64) + b2[2];
+    }
+}
+
+// ===========================================================================================
+// kernels
+// ===========================================================================================
+// MODE 0: explicit points (SUPNeRF.forward drop-in).  MODE 1: fused render (sampling + composite).
+template <int MODE>
+__global__ void __launch_bounds__(256, 1)
+decoder_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom g,
+                   float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_acc) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_TOTAL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31;
+    const long long tile128 = blockIdx.x;
+    const long long gp_raw = tile128 * 128 + wave * 32 + p;
+    const bool live = gp_raw < io.n_points;
+    const long long gp = live ? gp_raw : io.n_points - 1;
+    float x, y, z, dx, dy, dz, zc = 0.f;
+    if (MODE == 0) {
+        x = xyz[gp * 3]; y = xyz[gp * 3 + 1]; z = xyz[gp * 3 + 2];
+        dx = viewdir[gp * 3]; dy = viewdir[gp * 3 + 1]; dz = viewdir[gp * 3 + 2];
+    } else {
+        const long long ray = gp / g.S;
+        const SamplePoint sp = make_sample(g, ray, (int)(gp - ray * g.S));
+        x = sp.x; y = sp.y; z = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc;
+    }
+    float sg, cr, cg, cb;
+    decoder_forward_tile(io, L, lds, gp, tile128 * 4 + wave, x, y, z, dx, dy, dz, sg, cr, cg, cb);
+    if (live && lane < 32) {
+        if (io.sigmas) io.sigmas[gp] = sg;
+        if (io.rgbs) { io.rgbs[gp * 3] = cr; io.rgbs[gp * 3 + 1] = cg; io.rgbs[gp * 3 + 2] = cb; }
+    }
+    if (MODE == 1) {
+        float* comp = lds + LDS_COMP;
+        if (lane < 32) {
+            float* c = comp + (wave * 32 + p) * COMP_STRIDE;
+            c[0] = sg; c[1] = cr; c[2] = cg; c[3] = cb; c[4] = zc;
+        }
+        __syncthreads();
+        const int S = g.S;
+        const int rays_here = 128 / S;           // host guarantees 128 % S == 0
+        const bool white = g.flags & SNR_WHITE_BKGD;
+        for (int r = wave; r < rays_here; r += 4) {
+            const long long ray = tile128 * rays_here + r;
+            if (ray >= g.n_rays) break;
+            const float* c0 = comp + r * S * COMP_STRIDE;
+            RayOut o = composite_ray_fwd(S, lane, white, [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
+                const float* c = c0 + k * COMP_STRIDE;
+                s_ = c[0]; r_ = c[1]; g_ = c[2]; b_ = c[3]; z_ = c[4];
+                zn_ = (k < S - 1) ? c[COMP_STRIDE + 4] : 0.f;
+            });
+            if (lane == 0) {
+                out_rgb[ray * 3] = o.r; out_rgb[ray * 3 + 1] = o.g; out_rgb[ray * 3 + 2] = o.b;
+                out_depth[ray] = o.depth; out_acc[ray] = o.acc;
+            }
+        }
+    }
+}
+
+}  // namespace snr
+
+using namespace snr;
+
+extern "C" {
+
+int snr_decoder_fwd(const float* xyz, const float* viewdir, const float* latent, const float* packed, int64_t n_points,
+                    int64_t points_per_obj, int sb, int tb, float* sigmas, float* rgbs, void* relu_masks, void* stream_) {
+    if (!xyz || !viewdir || !latent || !packed) return SNR_E_ARG;
+    if (sb < 0 || tb < 0 || sb > MAX_BLOCKS || tb > MAX_BLOCKS || n_points < 0) return SNR_E_ARG;
+    if (points_per_obj < 1 || (n_points % points_per_obj) != 0) return SNR_E_SHAPE;
+    if (n_points == 0) return SNR_OK;
+    DecoderIO io{packed, latent, sb, tb, (long long)n_points, (long long)points_per_obj, sigmas, rgbs, (uint4*)relu_masks};
+    RayGeom g{};
+    const Layout L = make_layout(sb, tb);
+    const unsigned grid = (unsigned)((n_points + 127) / 128);
+    decoder_fwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g, nullptr, nullptr, nullptr);
+    return snr_check_launch_();
+}
+
+int snr_render_fwd(const snr_render_args* a, float* rgb, float* depth, float* acc_trans, float* sigmas, float* rgbs,
+                   void* relu_masks, void* stream_) {
+    RayGeom g;
+    int rc = snr_fill_geom_(a, &g, 1);
+    if (rc != SNR_OK) return rc;
+    if (!rgb || !depth || !acc_trans) return SNR_E_ARG;
+    if (a->n_samples > 128 || (128 % a->n_samples) != 0) return SNR_E_UNSUPPORTED;
+    if (a->n_rays == 0) return SNR_OK;
+    const long long P = a->n_rays * a->n_samples;
+    DecoderIO io{a->packed, a->latent, a->shape_blocks, a->texture_blocks, P, a->rays_per_obj * a->n_samples, sigmas, rgbs,
+                 (uint4*)relu_masks};
+    const Layout L = make_layout(a->shape_blocks, a->texture_blocks);
+    const unsigned grid = (unsigned)((P + 127) / 128);
+    decoder_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g, rgb, depth, acc_trans);
+    return snr_check_launch_();
+}
+
+}  // extern "C"

@@ -1,0 +1,305 @@
+"""Tensor-level operators over the C ABI: torch allocates, the HIP library computes.
+
+Everything here requires fp32 tensors on an AMD GPU (``tensor.is_cuda`` under PyTorch-ROCm).
+There is no CPU/eager fallback -- a CPU tensor raises."""
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import METRIC_Z, WHITE_BKGD, Z_PER_OBJECT, Z_PER_RAY, Z_SHARED, RenderArgs, SnrError, check
+
+IDENTITY_FRAME = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise SnrError("supnerf_amd operators need tensors on the GPU (no CPU fallback)")
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+# ------------------------------------------------------------------------------------ weights
+def per_point_tensor_names(shape_blocks: int, texture_blocks: int) -> Sequence[str]:
+    """State-dict keys (reference naming, src/model_supnerf.py:184-199) of the per-point layers in the
+    order snr_pack_weights expects them."""
+    names = ["encoding_xyz.0"] + [f"shape_layer_{j}.0" for j in range(1, shape_blocks + 1)]
+    names += ["encoding_shape", "sigma.0", "encoding_viewdir.0"]
+    names += [f"texture_layer_{j}.0" for j in range(1, texture_blocks + 1)] + ["rgb.0", "rgb.2"]
+    out = []
+    for n in names:
+        out += [n + ".weight", n + ".bias"]
+    return out
+
+
+def check_decoder_shapes(params: Dict[str, torch.Tensor], shape_blocks: int, texture_blocks: int):
+    """The kernels are built for the decoder of every shipped config: W = latent = 256, L_xyz = 10, L_dir = 4."""
+    want = {"encoding_xyz.0.weight": (256, 63), "encoding_shape.weight": (256, 256), "sigma.0.weight": (1, 256),
+            "encoding_viewdir.0.weight": (256, 283), "rgb.0.weight": (128, 256), "rgb.2.weight": (3, 128)}
+    for j in range(1, shape_blocks + 1):
+        want[f"shape_layer_{j}.0.weight"] = (256, 256)
+    for j in range(1, texture_blocks + 1):
+        want[f"texture_layer_{j}.0.weight"] = (256, 256)
+    for k, shp in want.items():
+        if k not in params or tuple(params[k].shape) != shp:
+            got = tuple(params[k].shape) if k in params else None
+            raise SnrError(f"unsupported decoder: {k} is {got}, the gfx950 kernels need {shp} "
+                           "(W=256, latent_dim=256, num_xyz_freq=10, num_dir_freq=4)")
+
+
+def pack_weights(params: Dict[str, torch.Tensor], shape_blocks: int, texture_blocks: int) -> torch.Tensor:
+    """nn.Linear tensors (reference state-dict names) -> the kernels' packed stream buffer."""
+    check_decoder_shapes(params, shape_blocks, texture_blocks)
+    names = per_point_tensor_names(shape_blocks, texture_blocks)
+    ts = [_f32c(params[n].detach()) for n in names]
+    _need_gpu(*ts)
+    dev = ts[0].device
+    nbytes = _lib.lib().snr_packed_bytes(shape_blocks, texture_blocks)
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    arr = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    with torch.cuda.device(dev):
+        check(_lib.lib().snr_pack_weights(arr, len(ts), shape_blocks, texture_blocks, _p(packed), _stream(dev)), "snr_pack_weights")
+    return packed
+
+
+# ------------------------------------------------------------------------------------ composite
+def composite_fwd(sigmas, rgbs, z_vals, z_mode, white_bkgd, rays_per_obj=0):
+    sigmas, rgbs, z_vals = _f32c(sigmas), _f32c(rgbs), _f32c(z_vals)
+    _need_gpu(sigmas, rgbs, z_vals)
+    S = rgbs.shape[-2]
+    n_rays = rgbs.numel() // (3 * S) if rgbs.numel() else 0
+    dev = rgbs.device
+    rgb = torch.empty(n_rays, 3, device=dev)
+    depth = torch.empty(n_rays, device=dev)
+    acc = torch.empty(n_rays, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().snr_composite_fwd(_p(sigmas), _p(rgbs), _p(z_vals), z_mode, WHITE_BKGD if white_bkgd else 0, n_rays,
+                                           rays_per_obj, S, _p(rgb), _p(depth), _p(acc), _stream(dev)), "snr_composite_fwd")
+    return rgb, depth, acc
+
+
+def composite_bwd(sigmas, rgbs, z_vals, z_mode, white_bkgd, rays_per_obj, d_rgb, d_depth, d_acc, need_dz):
+    S = rgbs.shape[-2]
+    n_rays = rgbs.numel() // (3 * S) if rgbs.numel() else 0
+    dev = rgbs.device
+    d_sig = torch.empty(n_rays, S, device=dev)
+    d_rgbs = torch.empty(n_rays, S, 3, device=dev)
+    d_z = torch.empty(n_rays, S, device=dev) if need_dz else None
+    with torch.cuda.device(dev):
+        check(_lib.lib().snr_composite_bwd(_p(sigmas), _p(rgbs), _p(z_vals), z_mode, WHITE_BKGD if white_bkgd else 0, n_rays,
+                                           rays_per_obj, S, _p(_f32c(d_rgb)), _p(_f32c(d_depth)), _p(_f32c(d_acc)),
+                                           _p(d_sig), _p(d_rgbs), _p(d_z), _stream(dev)), "snr_composite_bwd")
+    return d_sig, d_rgbs, d_z
+
+
+class Composite(torch.autograd.Function):
+    """Alpha composite of (N,S) densities / (N,S,3) colours; z per z_mode.  Gradients flow to sigmas and
+    rgbs always and to z_vals when it is per-ray (family B keeps its box bounds differentiable)."""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, z_vals, z_mode, white_bkgd, rays_per_obj):
+        sigmas, rgbs, z_vals = _f32c(sigmas), _f32c(rgbs), _f32c(z_vals)
+        out = composite_fwd(sigmas, rgbs, z_vals, z_mode, white_bkgd, rays_per_obj)
+        ctx.save_for_backward(sigmas, rgbs, z_vals)
+        ctx.cfg = (z_mode, white_bkgd, rays_per_obj)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, d_acc):
+        sigmas, rgbs, z_vals = ctx.saved_tensors
+        z_mode, white, rpo = ctx.cfg
+        need_dz = ctx.needs_input_grad[2]
+        if need_dz and z_mode != Z_PER_RAY:
+            raise SnrError("gradient wrt shared / per-object z_vals is not provided (the reference detaches them, "
+                           "src/utils.py:468-469)")
+        d_sig, d_rgbs, d_z = composite_bwd(sigmas, rgbs, z_vals, z_mode, white, rpo, d_rgb, d_depth, d_acc, need_dz)
+        return d_sig.view(sigmas.shape), d_rgbs.view(rgbs.shape), (d_z.view(z_vals.shape) if need_dz else None), None, None, None
+
+
+# ------------------------------------------------------------------------------------ decoder on points
+def decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=False):
+    """xyz, viewdir (P,3); latent (B,NLAT,256) -> sigmas (P,), rgbs (P,3)[, relu masks]."""
+    xyz, viewdir, latent = _f32c(xyz), _f32c(viewdir), _f32c(latent)
+    _need_gpu(xyz, viewdir, latent, packed)
+    P = xyz.shape[0]
+    B = latent.shape[0]
+    if P % B:
+        raise SnrError("number of points is not divisible by the number of objects")
+    dev = xyz.device
+    sig = torch.empty(P, device=dev)
+    rgb = torch.empty(P, 3, device=dev)
+    masks = None
+    if save_masks:
+        masks = torch.empty(_lib.lib().snr_mask_bytes(P, shape_blocks, texture_blocks), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().snr_decoder_fwd(_p(xyz), _p(viewdir), _p(latent), _p(packed), P, P // B if B else 1, shape_blocks,
+                                         texture_blocks, _p(sig), _p(rgb), _p(masks), _stream(dev)), "snr_decoder_fwd")
+    return sig, rgb, masks
+
+
+def decoder_bwd(xyz, viewdir, latent, packed, masks, sigmas, d_sig, d_rgb, shape_blocks, texture_blocks,
+                need_latent=True, need_xyz=True, need_dir=True):
+    P, B = xyz.shape[0], latent.shape[0]
+    dev = xyz.device
+    d_latent = torch.empty_like(latent) if need_latent else None
+    d_xyz = torch.empty_like(xyz) if need_xyz else None
+    d_dir = torch.empty_like(viewdir) if need_dir else None
+    ws_bytes = _lib.lib().snr_decoder_bwd_ws_bytes(P, shape_blocks, texture_blocks)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().snr_decoder_bwd(_p(xyz), _p(viewdir), _p(latent), _p(packed), _p(masks), _p(sigmas), _p(_f32c(d_sig)),
+                                         _p(_f32c(d_rgb)), P, P // B, shape_blocks, texture_blocks, _p(d_latent), _p(d_xyz),
+                                         _p(d_dir), _p(ws), ws_bytes, _stream(dev)), "snr_decoder_bwd")
+    return d_latent, d_xyz, d_dir
+
+
+class DecoderPoints(torch.autograd.Function):
+    """SUPNeRF.forward on explicit points.  Differentiable wrt latent terms, xyz and viewdir (weights are
+    treated as constants on this path)."""
+
+    @staticmethod
+    def forward(ctx, xyz, viewdir, latent, packed, shape_blocks, texture_blocks):
+        xyz, viewdir, latent = _f32c(xyz), _f32c(viewdir), _f32c(latent)
+        need = any(ctx.needs_input_grad[:3])
+        sig, rgb, masks = decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=need)
+        if need:
+            ctx.save_for_backward(xyz, viewdir, latent, packed, masks, sig)
+            ctx.cfg = (shape_blocks, texture_blocks)
+        return sig, rgb
+
+    @staticmethod
+    def backward(ctx, d_sig, d_rgb):
+        xyz, viewdir, latent, packed, masks, sig = ctx.saved_tensors
+        sb, tb = ctx.cfg
+        d_lat, d_xyz, d_dir = decoder_bwd(xyz, viewdir, latent, packed, masks, sig, d_sig, d_rgb, sb, tb,
+                                          ctx.needs_input_grad[2], ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return d_xyz, d_dir, d_lat, None, None, None
+
+
+# ------------------------------------------------------------------------------------ fused render
+def _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, frame, xyz_mul, z_mode, flags, rays_per_obj,
+                 n_samples, shape_blocks, texture_blocks):
+    a = RenderArgs()
+    a.rays_o, a.rays_d, a.t_vals = rays_o.data_ptr(), rays_d.data_ptr(), t_vals.data_ptr()
+    a.xyz_div = xyz_div.data_ptr()
+    a.z_scale = z_scale.data_ptr() if z_scale is not None else 0
+    a.latent = latent.data_ptr() if latent is not None else 0
+    a.packed = packed.data_ptr() if packed is not None else 0
+    a.frame = (C.c_float * 9)(*[float(v) for v in frame])
+    a.xyz_mul = float(xyz_mul)
+    a.z_mode, a.flags = int(z_mode), int(flags)
+    a.n_rays, a.rays_per_obj = int(rays_o.shape[0]), int(rays_per_obj)
+    a.n_samples, a.shape_blocks, a.texture_blocks = int(n_samples), int(shape_blocks), int(texture_blocks)
+    return a
+
+
+def fused_supported(n_samples: int) -> bool:
+    """The single-launch render needs every ray inside one 128-point workgroup tile."""
+    return 1 <= n_samples <= 128 and 128 % n_samples == 0
+
+
+class RenderCfg:
+    """Per-launch constants of the render operators (not tensors)."""
+
+    def __init__(self, n_samples, z_mode, rays_per_obj, shape_blocks, texture_blocks, frame=IDENTITY_FRAME, xyz_mul=1.0,
+                 white_bkgd=False, metric_z=False):
+        self.n_samples, self.z_mode, self.rays_per_obj = n_samples, z_mode, rays_per_obj
+        self.shape_blocks, self.texture_blocks = shape_blocks, texture_blocks
+        self.frame, self.xyz_mul = tuple(float(v) for v in frame), float(xyz_mul)
+        self.flags = (WHITE_BKGD if white_bkgd else 0) | (METRIC_Z if metric_z else 0)
+
+
+def render_fwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg: RenderCfg, save_for_bwd=False):
+    rays_o, rays_d, t_vals, xyz_div, z_scale, latent = [_f32c(t) for t in (rays_o, rays_d, t_vals, xyz_div, z_scale, latent)]
+    _need_gpu(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed)
+    if not fused_supported(cfg.n_samples):
+        raise SnrError(f"fused render needs n_samples dividing 128 (got {cfg.n_samples}); use the unfused operators")
+    dev = rays_o.device
+    N, S = rays_o.shape[0], cfg.n_samples
+    rgb = torch.empty(N, 3, device=dev)
+    depth = torch.empty(N, device=dev)
+    acc = torch.empty(N, device=dev)
+    sig = rgbs = masks = None
+    if save_for_bwd:
+        sig = torch.empty(N * S, device=dev)
+        rgbs = torch.empty(N * S, 3, device=dev)
+        masks = torch.empty(_lib.lib().snr_mask_bytes(N * S, cfg.shape_blocks, cfg.texture_blocks), dtype=torch.uint8, device=dev)
+    a = _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg.frame, cfg.xyz_mul, cfg.z_mode, cfg.flags,
+                     cfg.rays_per_obj, S, cfg.shape_blocks, cfg.texture_blocks)
+    with torch.cuda.device(dev):
+        check(_lib.lib().snr_render_fwd(C.byref(a), _p(rgb), _p(depth), _p(acc), _p(sig), _p(rgbs), _p(masks), _stream(dev)),
+              "snr_render_fwd")
+    return rgb, depth, acc, sig, rgbs, masks
+
+
+class FusedRender(torch.autograd.Function):
+    """rays -> (rgb, depth, acc_trans) in one launch; backward in one launch (+ a small reduction)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg):
+        rays_o, rays_d, t_vals, xyz_div, z_scale, latent = [_f32c(t) for t in (rays_o, rays_d, t_vals, xyz_div, z_scale, latent)]
+        need = any(ctx.needs_input_grad[:6])
+        rgb, depth, acc, sig, rgbs, masks = render_fwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg, save_for_bwd=need)
+        if need:
+            ctx.save_for_backward(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, sig, rgbs, masks)
+            ctx.cfg = cfg
+        return rgb, depth, acc
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, d_acc):
+        rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, sig, rgbs, masks = ctx.saved_tensors
+        cfg = ctx.cfg
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            raise SnrError("xyz_div / z_scale are per-object constants (object size); no gradient is provided")
+        need_t = ctx.needs_input_grad[2]
+        if need_t and cfg.z_mode != Z_PER_RAY:
+            raise SnrError("gradient wrt shared / per-object depths is not provided (the reference detaches them)")
+        dev = rays_o.device
+        d_lat = torch.empty_like(latent) if ctx.needs_input_grad[5] else None
+        d_o = torch.zeros_like(rays_o) if ctx.needs_input_grad[0] else None
+        d_d = torch.zeros_like(rays_d) if ctx.needs_input_grad[1] else None
+        d_t = torch.empty_like(t_vals) if need_t else None
+        a = _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg.frame, cfg.xyz_mul, cfg.z_mode, cfg.flags,
+                         cfg.rays_per_obj, cfg.n_samples, cfg.shape_blocks, cfg.texture_blocks)
+        ws_bytes = _lib.lib().snr_render_bwd_ws_bytes(C.byref(a))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(_lib.lib().snr_render_bwd(C.byref(a), _p(sig), _p(rgbs), _p(masks), _p(_f32c(d_rgb)), _p(_f32c(d_depth)),
+                                            _p(_f32c(d_acc)), _p(d_lat), _p(d_o), _p(d_d), _p(d_t), _p(ws), ws_bytes, _stream(dev)),
+                  "snr_render_bwd")
+        return d_o, d_d, d_t, None, None, d_lat, None, None
+
+
+# ------------------------------------------------------------------------------------ encode
+def encode(rays_o, rays_d, t_vals, xyz_div, z_scale, cfg: RenderCfg, want_pe=False):
+    """Sample points of a ray packet: xyz (N,S,3), viewdir (N,S,3), z (N,S) [, PE(xyz) (N,S,63), PE(dir) (N,27)]."""
+    rays_o, rays_d, t_vals, xyz_div, z_scale = [_f32c(t) for t in (rays_o, rays_d, t_vals, xyz_div, z_scale)]
+    _need_gpu(rays_o, rays_d, t_vals, xyz_div, z_scale)
+    dev = rays_o.device
+    N, S = rays_o.shape[0], cfg.n_samples
+    xyz = torch.empty(N, S, 3, device=dev)
+    vd = torch.empty(N, S, 3, device=dev)
+    z = torch.empty(N, S, device=dev)
+    pe = torch.empty(N, S, 63, device=dev) if want_pe else None
+    ped = torch.empty(N, 27, device=dev) if want_pe else None
+    a = _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, None, None, cfg.frame, cfg.xyz_mul, cfg.z_mode, cfg.flags,
+                     cfg.rays_per_obj, S, cfg.shape_blocks, cfg.texture_blocks)
+    with torch.cuda.device(dev):
+        check(_lib.lib().snr_encode_fwd(C.byref(a), _p(xyz), _p(vd), _p(z), _p(pe), _p(ped), _stream(dev)), "snr_encode_fwd")
+    return (xyz, vd, z, pe, ped) if want_pe else (xyz, vd, z)
