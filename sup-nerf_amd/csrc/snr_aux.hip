@@ -370,3 +370,10 @@ int snr_fill_geom_(const snr_render_args* a, snr::RayGeom* g, int need_model) {
     g->n_rays = a->n_rays; g->rays_per_obj = a->rays_per_obj; g->S = a->n_samples;
     return SNR_OK;
 }
+
+int snr_launch_reduce_latent_(const float* partial, long long tiles_per_obj, int n_lat, long long n_obj, float* d_latent, void* stream) {
+    if (n_lat <= 0 || n_obj <= 0) return SNR_OK;
+    dim3 grid((unsigned)((n_lat * 256 + 255) / 256), (unsigned)n_obj);
+    snr::reduce_latent_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(partial, tiles_per_obj, n_lat, d_latent);
+    return snr_check_launch_();
+}

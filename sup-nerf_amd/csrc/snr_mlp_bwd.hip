@@ -1,11 +1,441 @@
-// Backward of the fused decoder / render kernels (placeholder until the kernel lands).
-#include "snr_device.hpp"
+// Backward of the fused decoder / render kernels for gfx950.
+//
+// Same structure as the forward (snr_mlp.hip): one workgroup = 4 waves = 128 sample points, gradients
+// stay in registers in the MFMA accumulator layout, and every layer is one transposed product
+// G_in = W^T * G_out on v_mfma_f32_32x32x2_f32 with the transposed weight stream of the packed buffer.
+// Nothing is recomputed: the forward saved one ReLU bit per hidden unit (208 B / point) plus sigma / rgb
+// per point, which is all the chain rule needs when only the latent terms, the sample positions and the
+// view directions are differentiated (optimisation mode; decoder weights are constants here).
+//
+//   composite backward (wave scan) -> colour head -> rgb.0^T -> texture^T .. -> enc_viewdir^T -> (+ density
+//   head) -> enc_shape^T -> shape^T .. -> enc_xyz^T -> positional-encoding backward -> ray origin /
+//   direction / depth gradients.  Gradients of the per-object latent terms are reduced over the 32 points
+//   of a wave with a register reduce-scatter and written as per-tile partials (no atomics, deterministic);
+//   a small second kernel sums the partials per object.
+#include "snr_mlp_core.hpp"
 #include "snr_host.hpp"
-extern "C" {
-size_t snr_decoder_bwd_ws_bytes(int64_t, int, int) { return 16; }
-int snr_decoder_bwd(const float*, const float*, const float*, const float*, const void*, const float*, const float*, const float*,
-                    int64_t, int64_t, int, int, float*, float*, float*, void*, size_t, void*) { return SNR_E_UNSUPPORTED; }
-size_t snr_render_bwd_ws_bytes(const snr_render_args*) { return 16; }
-int snr_render_bwd(const snr_render_args*, const float*, const float*, const void*, const float*, const float*, const float*,
-                   float*, float*, float*, float*, void*, size_t, void*) { return SNR_E_UNSUPPORTED; }
+
+namespace snr {
+
+struct BwdIO {
+    const float* packed;
+    const float* latent;
+    int sb, tb;
+    long long n_points;
+    long long points_per_obj;
+    const uint4* masks;
+    const float* sigmas;     // (P) saved by the forward
+    const float* rgbs;       // (P,3) saved by the forward (render mode)
+    const float* d_sigmas;   // (P)   upstream, points mode
+    const float* d_rgbs;     // (P,3) upstream, points mode
+    const float* d_rgb;      // (N,3) upstream, render mode (nullable)
+    const float* d_depth;    // (N)
+    const float* d_acc;      // (N)
+    float* partial;          // [tiles32][n_lat][256] or null
+    float* d_xyz;            // (P,3) points mode, nullable
+    float* d_dir;            // (P,3) points mode, nullable
+    float* d_rays_o;         // (N,3) render mode, nullable
+    float* d_rays_d;         // (N,3)
+    float* d_t;              // (N,S) per-ray depths only
+};
+
+// accumulators -> operand registers with the saved ReLU bits applied (mask == nullptr: pass through);
+// `add` (nullable) is a per-feature vector scaled by `scale` added first (density-head path).
+template <int NT>
+__device__ __forceinline__ void masked_to_operand(const f32x16 (&acc)[9], float (&in)[9][16], const uint4* mask, const float* __restrict__ add,
+                                                  float scale, int h) {
+    uint32_t m[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    if (mask) { const uint4 v = *mask; m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 av = {0.f, 0.f, 0.f, 0.f};
+            if (add) av = *reinterpret_cast<const f32x4*>(add + 32 * t + 8 * j + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc[t][4 * j + e] + scale * av[e];
+                const bool on = (m[t >> 1] >> ((t & 1) * 16 + 4 * j + e)) & 1u;
+                in[t][4 * j + e] = on ? v : 0.f;
+            }
+        }
 }
+
+template <int NT>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[9]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+}
+
+// Sum the 8 x 16 accumulator registers of tiles 0..7 over the 32 points of the wave (lanes with equal
+// lane>>5) with a butterfly reduce-scatter: 124 shuffles instead of 640.  Afterwards lane (p,h) holds the
+// totals of features 8p + 4h .. +3, i.e. the wave holds all 256 features once: one coalesced 1 KiB store.
+__device__ __forceinline__ void reduce_points_store(const f32x16 (&acc)[9], float* __restrict__ dst, int lane) {
+    const int p = lane & 31, h = lane >> 5;
+    float a64[64], a32[32], a16[16], a8[8], a4[4];
+    {
+        const bool up = p & 16;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const float lo = acc[i >> 4][i & 15], hi = acc[(i + 64) >> 4][(i + 64) & 15];
+            a64[i] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, 16, 64);
+        }
+    }
+    {
+        const bool up = p & 8;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a32[i] = (up ? a64[i + 32] : a64[i]) + __shfl_xor(up ? a64[i] : a64[i + 32], 8, 64);
+    }
+    {
+        const bool up = p & 4;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a16[i] = (up ? a32[i + 16] : a32[i]) + __shfl_xor(up ? a32[i] : a32[i + 16], 4, 64);
+    }
+    {
+        const bool up = p & 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a8[i] = (up ? a16[i + 8] : a16[i]) + __shfl_xor(up ? a16[i] : a16[i + 8], 2, 64);
+    }
+    {
+        const bool up = p & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a4[i] = (up ? a8[i + 4] : a8[i]) + __shfl_xor(up ? a8[i] : a8[i + 4], 1, 64);
+    }
+    f32x4 o = {a4[0], a4[1], a4[2], a4[3]};
+    *reinterpret_cast<f32x4*>(dst + 8 * p + 4 * h) = o;
+}
+
+// MODE 0: explicit points (backward of SUPNeRF.forward).  MODE 1: fused render.
+template <int MODE>
+__global__ void __launch_bounds__(256, 1)
+decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom g) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_TOTAL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
+    const long long tile128 = blockIdx.x;
+    const long long tile32 = tile128 * 4 + wave;
+    const long long gp_raw = tile128 * 128 + wave * 32 + p;
+    const bool live = gp_raw < io.n_points;
+    const long long gp = live ? gp_raw : io.n_points - 1;
+    const int sb = io.sb, tb = io.tb;
+    const int n_relu = n_relu_layers(sb, tb);
+    const int li_encshape = sb + 1, li_view = sb + 2, li_last = sb + tb + 2;
+
+    // ---- start the transposed weight stream
+    Pipe pipe;
+    pipe_init(pipe, io.packed + L.bwd, lane);
+    chunk_dma(pipe.next, lds, 256, tid);
+    pipe.next += 256 * KC;
+
+    // ---- this lane's point and its upstream gradient
+    float x, y, z, dx, dy, dz, tval = 0.f, zc = 0.f;
+    long long ray = 0;
+    if (MODE == 0) {
+        x = xyz[gp * 3]; y = xyz[gp * 3 + 1]; z = xyz[gp * 3 + 2];
+        dx = viewdir[gp * 3]; dy = viewdir[gp * 3 + 1]; dz = viewdir[gp * 3 + 2];
+    } else {
+        ray = gp / g.S;
+        const SamplePoint sp = make_sample(g, ray, (int)(gp - ray * g.S));
+        x = sp.x; y = sp.y; z = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc; tval = sp.t;
+    }
+    float gs = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gzc = 0.f;
+    if (MODE == 0) {
+        if (live) {
+            gs = io.d_sigmas ? io.d_sigmas[gp] : 0.f;
+            if (io.d_rgbs) { gr = io.d_rgbs[gp * 3]; gg = io.d_rgbs[gp * 3 + 1]; gb = io.d_rgbs[gp * 3 + 2]; }
+        }
+    } else {
+        float* comp = lds + LDS_COMP;
+        if (lane < 32) comp[(wave * 32 + p) * COMP_STRIDE + 5] = zc;
+        __syncthreads();
+        const int S = g.S;
+        const int rays_here = 128 / S;
+        const bool white = g.flags & SNR_WHITE_BKGD;
+        for (int r = wave; r < rays_here; r += 4) {
+            const long long rr = tile128 * rays_here + r;
+            if (rr >= g.n_rays) break;
+            float* c0 = comp + r * S * COMP_STRIDE;
+            const float* srow = io.sigmas + rr * S;
+            const float* crow = io.rgbs + rr * S * 3;
+            const float ur = io.d_rgb ? io.d_rgb[rr * 3] : 0.f, ug = io.d_rgb ? io.d_rgb[rr * 3 + 1] : 0.f,
+                        ub = io.d_rgb ? io.d_rgb[rr * 3 + 2] : 0.f;
+            const float ud = io.d_depth ? io.d_depth[rr] : 0.f, ua = io.d_acc ? io.d_acc[rr] : 0.f;
+            composite_ray_bwd<2>(S, lane, white, ur, ug, ub, ud, ua,
+                [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
+                    s_ = srow[k]; r_ = crow[3 * k]; g_ = crow[3 * k + 1]; b_ = crow[3 * k + 2];
+                    z_ = c0[k * COMP_STRIDE + 5];
+                    zn_ = (k < S - 1) ? c0[(k + 1) * COMP_STRIDE + 5] : 0.f;
+                },
+                [&](int k, float ds, float dcr, float dcg, float dcb, float dzz) {
+                    float* c = c0 + k * COMP_STRIDE;
+                    c[0] = ds; c[1] = dcr; c[2] = dcg; c[3] = dcb; c[4] = dzz;
+                });
+        }
+        __syncthreads();
+        if (live) {
+            const float* c = comp + (wave * 32 + p) * COMP_STRIDE;
+            gs = c[0]; gr = c[1]; gg = c[2]; gb = c[3]; gzc = c[4];
+        }
+    }
+    // softplus'(pre) = sigmoid(pre) = 1 - exp(-sigma)   (sigma = softplus(pre); exact 1 in fp32 past the threshold)
+    const float dpre = gs * (1.f - expf(-io.sigmas[gp]));
+
+    float in[9][16];
+    f32x16 acc[9];
+    float gdir[16];
+
+    // ---- colour head backward: g_h = W2^T d_rgb, masked by rgb.0's ReLU
+    {
+        const uint4 mk = io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane];
+        const uint32_t m[2] = {mk.x, mk.y};
+        const float* w2 = io.packed + L.rgb2_w;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n0 = 32 * t + 8 * j + 4 * h;
+                const f32x4 wr = *reinterpret_cast<const f32x4*>(w2 + n0);
+                const f32x4 wg = *reinterpret_cast<const f32x4*>(w2 + 128 + n0);
+                const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + n0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = wr[e] * gr + wg[e] * gg + wb[e] * gb;
+                    const bool on = (m[t >> 1] >> ((t & 1) * 16 + 4 * j + e)) & 1u;
+                    in[t][4 * j + e] = on ? v : 0.f;
+                }
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- rgb.0^T : 128 -> 256
+    auto rows_of = [&](int li) { return li == li_view ? K_VIEW_PAD : (li == 0 ? K_XYZ_PAD : 256); };
+    acc_zero<8>(acc);
+    step<8, 9>(acc, in[0], pipe, lds, 256, tid);
+    step<8, 9>(acc, in[1], pipe, lds, 256, tid);
+    step<8, 9>(acc, in[2], pipe, lds, 256, tid);
+    step<8, 9>(acc, in[3], pipe, lds, rows_of(li_last), tid);
+
+    // ---- 256-wide layers in reverse: texture .., enc_viewdir, enc_shape, shape ..
+#pragma unroll 1
+    for (int li = li_last; li >= 1; --li) {
+        const bool is_view = (li == li_view);
+        const bool relu = (li != li_encshape);
+        // acc = gradient wrt the OUTPUT of layer li; enc_shape's output also feeds the density head
+        masked_to_operand<8>(acc, in, relu ? io.masks + (tile32 * n_relu + relu_slot(li, sb)) * 64 + lane : nullptr,
+                             li == li_encshape ? io.packed + L.sigma_w : nullptr, dpre, h);
+        acc_zero<9>(acc);
+        const int rows = rows_of(li), rows_after = rows_of(li - 1);
+        step<8, 9>(acc, in[0], pipe, lds, rows, tid, is_view);
+        step<8, 9>(acc, in[1], pipe, lds, rows, tid, is_view);
+        step<8, 9>(acc, in[2], pipe, lds, rows, tid, is_view);
+        step<8, 9>(acc, in[3], pipe, lds, rows, tid, is_view);
+        step<8, 9>(acc, in[4], pipe, lds, rows, tid, is_view);
+        step<8, 9>(acc, in[5], pipe, lds, rows, tid, is_view);
+        step<8, 9>(acc, in[6], pipe, lds, rows, tid, is_view);
+        step<8, 9>(acc, in[7], pipe, lds, rows_after, tid, is_view);
+        // acc = gradient wrt the INPUT of layer li = previous output + latent term
+        const int la = latent_after(li - 1, sb, tb);
+        if (la >= 0 && io.partial) reduce_points_store(acc, io.partial + (tile32 * L.n_lat + la) * 256, lane);
+        if (is_view) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gdir[r] = acc[8][r];
+        }
+    }
+
+    // ---- enc_xyz^T : 256 -> 64 positional-encoding features
+    masked_to_operand<8>(acc, in, io.masks + (tile32 * n_relu + 0) * 64 + lane, nullptr, 0.f, h);
+    acc_zero<2>(acc);
+    step<2, 9>(acc, in[0], pipe, lds, 64, tid);
+    step<2, 9>(acc, in[1], pipe, lds, 64, tid);
+    step<2, 9>(acc, in[2], pipe, lds, 64, tid);
+    step<2, 9>(acc, in[3], pipe, lds, 64, tid);
+    step<2, 9>(acc, in[4], pipe, lds, 64, tid);
+    step<2, 9>(acc, in[5], pipe, lds, 64, tid);
+    step<2, 9>(acc, in[6], pipe, lds, 64, tid);
+    step<2, 9>(acc, in[7], pipe, lds, 0, tid);
+
+    // ---- positional-encoding backward through the per-wave scratch rows
+    float* sc = lds + LDS_SCRATCH + wave * PE_WAVE + p * PE_ROW;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[32 * c + 8 * (r >> 2) + 4 * h + (r & 3)] = acc[c][r];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[64 + 8 * (r >> 2) + 4 * h + (r & 3)] = gdir[r];
+    __syncthreads();
+    float gx = 0.f, gy = 0.f, gz = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < 15; ++i) {
+        const int q = 15 * h + i, a = q % 3, f = q / 3;
+        float sn, cs;
+        sincosf(ldexpf(pick3(x, y, z, a), f), &sn, &cs);
+        const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * XYZ_FREQ + q] * sn, f);
+        gx += a == 0 ? v : 0.f; gy += a == 1 ? v : 0.f; gz += a == 2 ? v : 0.f;
+    }
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) {
+        const int q = 6 * h + i, a = q % 3, f = q / 3;
+        float sn, cs;
+        sincosf(ldexpf(pick3(dx, dy, dz, a), f), &sn, &cs);
+        const float v = ldexpf(sc[64 + 3 + q] * cs - sc[64 + 3 + 3 * DIR_FREQ + q] * sn, f);
+        hx += a == 0 ? v : 0.f; hy += a == 1 ? v : 0.f; hz += a == 2 ? v : 0.f;
+    }
+    if (h == 0) { gx += sc[0]; gy += sc[1]; gz += sc[2]; hx += sc[64]; hy += sc[65]; hz += sc[66]; }
+    gx += __shfl_xor(gx, 32, 64); gy += __shfl_xor(gy, 32, 64); gz += __shfl_xor(gz, 32, 64);
+    hx += __shfl_xor(hx, 32, 64); hy += __shfl_xor(hy, 32, 64); hz += __shfl_xor(hz, 32, 64);
+
+    if (MODE == 0) {
+        if (live && h == 0) {
+            if (io.d_xyz) { io.d_xyz[gp * 3] = gx; io.d_xyz[gp * 3 + 1] = gy; io.d_xyz[gp * 3 + 2] = gz; }
+            if (io.d_dir) { io.d_dir[gp * 3] = hx; io.d_dir[gp * 3 + 1] = hy; io.d_dir[gp * 3 + 2] = hz; }
+        }
+        return;
+    }
+
+    // ---- sample point -> ray: p' = M (((o + t d) / div) mul), dir' = M d
+    {
+        const long long obj = ray / g.rays_per_obj;
+        const float sc_ = g.xyz_mul / g.xyz_div[obj];
+        // M^T g
+        const float px = (g.m[0] * gx + g.m[3] * gy + g.m[6] * gz) * sc_;
+        const float py = (g.m[1] * gx + g.m[4] * gy + g.m[7] * gz) * sc_;
+        const float pz = (g.m[2] * gx + g.m[5] * gy + g.m[8] * gz) * sc_;
+        const float qx = g.m[0] * hx + g.m[3] * hy + g.m[6] * hz;
+        const float qy = g.m[1] * hx + g.m[4] * hy + g.m[7] * hz;
+        const float qz = g.m[2] * hx + g.m[5] * hy + g.m[8] * hz;
+        const float rdx = g.rays_d[ray * 3], rdy = g.rays_d[ray * 3 + 1], rdz = g.rays_d[ray * 3 + 2];
+        float c[6] = {px, py, pz, tval * px + qx, tval * py + qy, tval * pz + qz};
+        float dt = rdx * px + rdy * py + rdz * pz;
+        if (g.flags & SNR_METRIC_Z) {
+            // zc = | t d | zs  ->  d zc/d t = zs^2 t |d|^2 / zc ,  d zc/d d = zs^2 t^2 d / zc
+            const float zs = g.z_scale[obj];
+            const float k = zc > 0.f ? gzc * zs * zs * tval / zc : 0.f;
+            dt += k * (rdx * rdx + rdy * rdy + rdz * rdz);
+            c[3] += k * tval * rdx; c[4] += k * tval * rdy; c[5] += k * tval * rdz;
+        } else {
+            dt += gzc;
+        }
+        if (!(live && h == 0)) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) c[i] = 0.f;
+        }
+        if (io.d_t && live && h == 0) io.d_t[gp] = dt;
+        if (io.d_rays_o || io.d_rays_d) {
+            const int S = g.S;
+            const int G = S < 32 ? S : 32;      // lanes of this wave that share a ray (S divides 128)
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                for (int off = 1; off < G; off <<= 1) c[i] += __shfl_xor(c[i], off, 64);
+            if (S <= 32) {
+                if (live && h == 0 && (p % S) == 0) {
+                    if (io.d_rays_o) { io.d_rays_o[ray * 3] = c[0]; io.d_rays_o[ray * 3 + 1] = c[1]; io.d_rays_o[ray * 3 + 2] = c[2]; }
+                    if (io.d_rays_d) { io.d_rays_d[ray * 3] = c[3]; io.d_rays_d[ray * 3 + 1] = c[4]; io.d_rays_d[ray * 3 + 2] = c[5]; }
+                }
+            } else {
+                float* part = lds + LDS_COMP;      // composite scratch is free by now
+                __syncthreads();
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) part[wave * 8 + i] = c[i];
+                }
+                __syncthreads();
+                const int waves_per_ray = S / 32;              // 2 or 4
+                const int rays_here = 128 / S;
+                if (tid < rays_here * 6) {
+                    const int r = tid / 6, i = tid % 6;
+                    const long long rr = tile128 * rays_here + r;
+                    if (rr < g.n_rays) {
+                        float s = 0.f;
+                        for (int w = 0; w < waves_per_ray; ++w) s += part[(r * waves_per_ray + w) * 8 + i];
+                        float* dst = i < 3 ? io.d_rays_o : io.d_rays_d;
+                        if (dst) dst[rr * 3 + (i % 3)] = s;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace snr
+
+using namespace snr;
+
+int snr_launch_reduce_latent_(const float* partial, long long tiles_per_obj, int n_lat, long long n_obj, float* d_latent, void* stream);
+
+static size_t bwd_ws_bytes(int64_t n_points, int sb, int tb) {
+    const int64_t tiles = (n_points + 31) / 32;
+    return (size_t)(tiles * (int64_t)(sb + tb) * 256 * sizeof(float) + 256);
+}
+
+extern "C" {
+
+size_t snr_decoder_bwd_ws_bytes(int64_t n_points, int sb, int tb) { return bwd_ws_bytes(n_points, sb, tb); }
+
+int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent, const float* packed, const void* relu_masks,
+                    const float* sigmas, const float* d_sigmas, const float* d_rgbs, int64_t n_points, int64_t points_per_obj, int sb,
+                    int tb, float* d_latent, float* d_xyz, float* d_viewdir, void* workspace, size_t ws_bytes, void* stream_) {
+    if (n_points == 0) return SNR_OK;
+    if (!xyz || !viewdir || !latent || !packed || !relu_masks || !sigmas) return SNR_E_ARG;
+    if (sb < 0 || tb < 0 || sb > MAX_BLOCKS || tb > MAX_BLOCKS || n_points < 0) return SNR_E_ARG;
+    if (points_per_obj < 1 || (n_points % points_per_obj) != 0) return SNR_E_SHAPE;
+    const bool want_lat = d_latent && (sb + tb) > 0;
+    if (want_lat) {
+        if (points_per_obj % 32) return SNR_E_UNSUPPORTED;   // a wave tile must not straddle two objects
+        if (!workspace || ws_bytes < bwd_ws_bytes(n_points, sb, tb)) return SNR_E_WORKSPACE;
+    }
+    BwdIO io{};
+    io.packed = packed; io.latent = latent; io.sb = sb; io.tb = tb; io.n_points = n_points; io.points_per_obj = points_per_obj;
+    io.masks = (const uint4*)relu_masks; io.sigmas = sigmas; io.d_sigmas = d_sigmas; io.d_rgbs = d_rgbs;
+    io.partial = want_lat ? (float*)workspace : nullptr;
+    io.d_xyz = d_xyz; io.d_dir = d_viewdir;
+    RayGeom g{};
+    const Layout L = make_layout(sb, tb);
+    const unsigned grid = (unsigned)((n_points + 127) / 128);
+    decoder_bwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
+    int rc = snr_check_launch_();
+    if (rc != SNR_OK) return rc;
+    if (want_lat) return snr_launch_reduce_latent_(io.partial, points_per_obj / 32, sb + tb, n_points / points_per_obj, d_latent, stream_);
+    return SNR_OK;
+}
+
+size_t snr_render_bwd_ws_bytes(const snr_render_args* a) {
+    if (!a) return 0;
+    return bwd_ws_bytes(a->n_rays * (int64_t)a->n_samples, a->shape_blocks, a->texture_blocks);
+}
+
+int snr_render_bwd(const snr_render_args* a, const float* sigmas, const float* rgbs, const void* relu_masks, const float* d_rgb,
+                   const float* d_depth, const float* d_acc, float* d_latent, float* d_rays_o, float* d_rays_d, float* d_t,
+                   void* workspace, size_t ws_bytes, void* stream_) {
+    RayGeom g;
+    int rc = snr_fill_geom_(a, &g, 1);
+    if (rc != SNR_OK) return rc;
+    if (a->n_rays == 0) return SNR_OK;
+    if (!sigmas || !rgbs || !relu_masks) return SNR_E_ARG;
+    if (a->n_samples > 128 || (128 % a->n_samples) != 0) return SNR_E_UNSUPPORTED;
+    if (d_t && a->z_mode != SNR_Z_PER_RAY) return SNR_E_UNSUPPORTED;
+    const int sb = a->shape_blocks, tb = a->texture_blocks;
+    const long long P = a->n_rays * a->n_samples;
+    const long long ppo = a->rays_per_obj * a->n_samples;
+    const bool want_lat = d_latent && (sb + tb) > 0;
+    if (want_lat) {
+        if (ppo % 32) return SNR_E_UNSUPPORTED;
+        if (!workspace || ws_bytes < bwd_ws_bytes(P, sb, tb)) return SNR_E_WORKSPACE;
+    }
+    BwdIO io{};
+    io.packed = a->packed; io.latent = a->latent; io.sb = sb; io.tb = tb; io.n_points = P; io.points_per_obj = ppo;
+    io.masks = (const uint4*)relu_masks; io.sigmas = sigmas; io.rgbs = rgbs;
+    io.d_rgb = d_rgb; io.d_depth = d_depth; io.d_acc = d_acc;
+    io.partial = want_lat ? (float*)workspace : nullptr;
+    io.d_rays_o = d_rays_o; io.d_rays_d = d_rays_d; io.d_t = d_t;
+    const Layout L = make_layout(sb, tb);
+    const unsigned grid = (unsigned)((P + 127) / 128);
+    decoder_bwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g);
+    rc = snr_check_launch_();
+    if (rc != SNR_OK) return rc;
+    if (want_lat) return snr_launch_reduce_latent_(io.partial, ppo / 32, sb + tb, a->n_rays / a->rays_per_obj, d_latent, stream_);
+    return SNR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// Shared pieces of the fused decoder kernels (forward: snr_mlp.hip, backward: snr_mlp_bwd.hip):
+// LDS map, weight-chunk LDS-DMA pipeline, the fp32-MFMA chunk product and layer bookkeeping.
+#pragma once
+#include "snr_device.hpp"
+
+namespace snr {
+
+constexpr int WBUF = K_VIEW_PAD * KC;               // floats per weight buffer (288 rows x 32, swizzled, no padding)
+constexpr int PE_ROW = 97;                          // per-point scratch row: 64 xyz features + 32 dir features + 1
+constexpr int PE_WAVE = 32 * PE_ROW;
+constexpr int LDS_SCRATCH = 2 * WBUF;               // 4 waves x PE_WAVE
+constexpr int COMP_STRIDE = 8;                      // sigma r g b zc + pad
+constexpr int LDS_COMP = LDS_SCRATCH + 4 * PE_WAVE;
+constexpr int LDS_TOTAL = LDS_COMP + 128 * COMP_STRIDE;   // floats
+static_assert(LDS_TOTAL * 4 <= 160 * 1024, "LDS budget");
+
+// Weight chunks are stored in the packed stream as the exact LDS image (snr_layout.h: 16-byte slot
+// c of row n sits at slot c ^ ((n >> 1) & 7)), so staging is a linear LDS-DMA copy: 1 KiB per
+// wave-instruction, no VGPRs, no ds_write.  `rows` x 128 B, 256 threads x 16 B per step.
+__device__ __forceinline__ void chunk_dma(const float* __restrict__ g, float* lds, int rows, int tid) {
+    const int nvec = rows * 8;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        if (i * 256 < nvec) {    // rows is a multiple of 32: uniform over the workgroup
+            typedef const __attribute__((address_space(1))) void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + (size_t)(i * 256 + tid) * 4), (lptr_t)(lds + (i * 256 + wave * 64) * 4), 16, 0, 0);
+        }
+    }
+}
+
+// one 32-deep k-chunk: acc[t] += W[32t..32t+31][chunk] * b     (NT output tiles).
+// aoff[j] = this lane's float offset of 16-byte slot (2j + h) in row (lane & 31), swizzle applied.
+// The A fragment of the next 4 MFMAs is fetched before the current 4 are issued.
+template <int NT, int NA, int T0 = 0>
+__device__ __forceinline__ void chunk_mma(f32x16 (&acc)[NA], const float (&b)[16], const float* wbuf, const int (&aoff)[4]) {
+    // output tiles T0 .. T0+NT-1
+    f32x4 a = *reinterpret_cast<const f32x4*>(wbuf + aoff[0] + T0 * 32 * KC);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = T0; t < T0 + NT; ++t) {
+            f32x4 an = a;
+            if (t + 1 < T0 + NT) an = *reinterpret_cast<const f32x4*>(wbuf + aoff[j] + (t + 1) * 32 * KC);
+            else if (j + 1 < 4) an = *reinterpret_cast<const f32x4*>(wbuf + aoff[j + 1] + T0 * 32 * KC);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[4 * j + e], acc[t], 0, 0, 0);
+            a = an;
+        }
+    }
+}
+
+struct Pipe {
+    const float* next;   // next chunk to fetch from the packed stream
+    int cur;             // LDS buffer holding the chunk about to be consumed
+    int aoff[4];         // per-lane A-fragment offsets (see chunk_mma)
+};
+
+__device__ __forceinline__ void pipe_init(Pipe& p, const float* stream, int lane) {
+    p.next = stream;
+    p.cur = 0;
+    const int n = lane & 31, h = lane >> 5, sw = (n >> 1) & 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p.aoff[j] = n * KC + (((2 * j + h) ^ sw) << 2);
+}
+
+// consume the current chunk while the following one (rows_next x 32; 0 = none) lands in the other buffer
+template <int NT, int NA>
+__device__ __forceinline__ void step(f32x16 (&acc)[NA], const float (&b)[16], Pipe& p, float* lds, int rows_next, int tid,
+                                     bool extra_tile = false) {
+    if (rows_next) chunk_dma(p.next, lds + (p.cur ^ 1) * WBUF, rows_next, tid);
+    chunk_mma<NT, NA>(acc, b, lds + p.cur * WBUF, p.aoff);
+    if (NA > NT && extra_tile) chunk_mma<1, NA, (NA > NT ? NT : 0)>(acc, b, lds + p.cur * WBUF, p.aoff);   // tile NT (backward of enc_viewdir)
+    p.next += rows_next * KC;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    p.cur ^= 1;
+}
+
+template <int NT, int NA>
+__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NA], const float* __restrict__ bias, int h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * t + 8 * j + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * j + e] = bv[e];
+        }
+}
+
+// accumulators -> next layer's operand registers: optional ReLU (+ mask bits), optional latent add
+template <int NT, int NA>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[NA], float (&in)[9][16], bool relu, const float* __restrict__ zlat, int h,
+                                         uint32_t (&mask)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mask[i] = 0u;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+            if (zlat) zv = *reinterpret_cast<const f32x4*>(zlat + 32 * t + 8 * j + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[t][4 * j + e];
+                if (relu) {
+                    if (v > 0.f) mask[t >> 1] |= 1u << ((t & 1) * 16 + 4 * j + e);
+                    v = fmaxf(v, 0.f);
+                }
+                in[t][4 * j + e] = v + zv[e];
+            }
+        }
+}
+
+// which latent term (index into the (B,NLAT,256) table) is added after MFMA layer li; -1 = none
+__device__ __forceinline__ int latent_after(int li, int sb, int tb) {
+    if (li < sb) return li;                          // enc_xyz -> z_1, shape_j -> z_{j+1}
+    if (li == sb + 2 && tb > 0) return sb;           // enc_viewdir -> first texture latent
+    if (li > sb + 2 && li < sb + 2 + tb) return li - 2;   // texture_j -> next texture latent
+    return -1;
+}
+// index of MFMA layer li among the ReLU layers (enc_shape has none)
+__device__ __forceinline__ int relu_slot(int li, int sb) { return li <= sb ? li : li - 1; }
+
+struct DecoderIO {
+    const float* packed;
+    const float* latent;      // (B, n_lat, 256)
+    int sb, tb;
+    long long n_points;
+    long long points_per_obj;
+    float* sigmas;            // (P) optional
+    float* rgbs;              // (P,3) optional
+    uint4* masks;             // optional
+};
+
+}  // namespace snr

@@ -1,0 +1,143 @@
+"""Decoder modules with the reference's constructor / forward signatures, running on the HIP kernels.
+
+``CodeNeRF`` mirrors src/model_codenerf.py:13-63 and ``SUPNeRF`` the decoder + pose-update half of
+src/model_supnerf.py:164-269.  Parameter names and shapes are identical to the reference so its
+checkpoints (``saved['model_params']``) load with ``load_state_dict``.  The ResNet image encoder of
+SUPNeRF is out of scope (it stays a stock PyTorch module supplied by the caller).
+
+What runs where:
+  * per-object latent layers ``*_latent_layer_*`` -- stock PyTorch (B x 256 GEMMs, autograd gives the code
+    and latent-weight gradients);
+  * the per-point decoder (8 GEMMs per sample point) -- ``libsupnerf_hip.so``;
+  * ``fused_render`` additionally fuses sampling, frame transforms, positional encoding and the
+    alpha composite into the same launch (used by ``supnerf_amd.utils`` / ``supnerf_amd.renderer``).
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import SnrError
+
+
+class _DecoderBase(nn.Module):
+    """Layer set of src/model_supnerf.py:184-199 and the HIP forward."""
+
+    def _build_decoder(self, shape_blocks, texture_blocks, W, num_xyz_freq, num_dir_freq, latent_dim):
+        if W != 256 or latent_dim != 256 or num_xyz_freq != 10 or num_dir_freq != 4:
+            raise SnrError("the gfx950 kernels are built for W=256, latent_dim=256, num_xyz_freq=10, num_dir_freq=4 "
+                           "(every shipped SUP-NeRF config); got "
+                           f"W={W}, latent_dim={latent_dim}, num_xyz_freq={num_xyz_freq}, num_dir_freq={num_dir_freq}")
+        if not (0 <= shape_blocks <= 8 and 0 <= texture_blocks <= 8):
+            raise SnrError("shape_blocks / texture_blocks must be in 0..8")
+        self.shape_blocks, self.texture_blocks = shape_blocks, texture_blocks
+        self.num_xyz_freq, self.num_dir_freq = num_xyz_freq, num_dir_freq
+        d_xyz, d_viewdir = 3 + 6 * num_xyz_freq, 3 + 6 * num_dir_freq
+        self.encoding_xyz = nn.Sequential(nn.Linear(d_xyz, W), nn.ReLU())
+        for j in range(shape_blocks):
+            setattr(self, f"shape_latent_layer_{j + 1}", nn.Sequential(nn.Linear(latent_dim, W), nn.ReLU()))
+            setattr(self, f"shape_layer_{j + 1}", nn.Sequential(nn.Linear(W, W), nn.ReLU()))
+        self.encoding_shape = nn.Linear(W, W)
+        self.sigma = nn.Sequential(nn.Linear(W, 1), nn.Softplus())
+        self.encoding_viewdir = nn.Sequential(nn.Linear(W + d_viewdir, W), nn.ReLU())
+        for j in range(texture_blocks):
+            setattr(self, f"texture_latent_layer_{j + 1}", nn.Sequential(nn.Linear(latent_dim, W), nn.ReLU()))
+            setattr(self, f"texture_layer_{j + 1}", nn.Sequential(nn.Linear(W, W), nn.ReLU()))
+        self.rgb = nn.Sequential(nn.Linear(W, W // 2), nn.ReLU(), nn.Linear(W // 2, 3))
+        self._packed = None
+        self._packed_key = None
+
+    # ---- packed per-point weights, re-packed only when a tensor changed
+    def _per_point_params(self):
+        sd = dict(self.named_parameters())
+        return {n: sd[n] for n in ops.per_point_tensor_names(self.shape_blocks, self.texture_blocks)}
+
+    def packed_weights(self) -> torch.Tensor:
+        pp = self._per_point_params()
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in pp.values())
+        if self._packed is None or key != self._packed_key:
+            if torch.is_grad_enabled() and getattr(self, "train_decoder_weights", False):
+                raise NotImplementedError("gradients wrt the per-point decoder weights (training mode) are not built yet; "
+                                          "this path differentiates codes and poses only")
+            self._packed = ops.pack_weights(pp, self.shape_blocks, self.texture_blocks)
+            self._packed_key = key
+        return self._packed
+
+    def latent_terms(self, shape_latent: torch.Tensor, texture_latent: torch.Tensor) -> torch.Tensor:
+        """(B, shape_blocks+texture_blocks, 256): z_j = ReLU(Lin_j(code)) (src/model_supnerf.py:253,261), hoisted out
+        of the per-ray loop.  With no blocks at all a dummy (B,1,256) of zeros is returned."""
+        outs = [getattr(self, f"shape_latent_layer_{j + 1}")(shape_latent) for j in range(self.shape_blocks)]
+        outs += [getattr(self, f"texture_latent_layer_{j + 1}")(texture_latent) for j in range(self.texture_blocks)]
+        if not outs:
+            return shape_latent.new_zeros(shape_latent.shape[0], 1, 256)
+        return torch.stack(outs, dim=1)
+
+    def forward(self, xyz, viewdir, shape_latent, texture_latent):
+        """sigmas (N,S,1), rgbs (N,S,3) -- same contract as the reference forward
+        (src/model_supnerf.py:241-269); rays are object-major over the B codes."""
+        if xyz.shape[0] % shape_latent.shape[0]:
+            raise SnrError("the number of rays must be divisible by the number of codes (object-major batching)")
+        lead = xyz.shape[:-1]
+        lat = self.latent_terms(shape_latent, texture_latent)
+        sig, rgb = ops.DecoderPoints.apply(xyz.reshape(-1, 3), viewdir.reshape(-1, 3), lat, self.packed_weights(),
+                                           self.shape_blocks, self.texture_blocks)
+        return sig.view(*lead, 1), rgb.view(*lead, 3)
+
+    def fused_render(self, rays_o, rays_d, t_vals, xyz_div, z_scale, shape_latent, texture_latent, cfg: "ops.RenderCfg"):
+        """rays -> (rgb (N,3), depth (N,), acc_trans (N,)) in one launch (see ops.FusedRender)."""
+        lat = self.latent_terms(shape_latent, texture_latent)
+        return ops.FusedRender.apply(rays_o, rays_d, t_vals, xyz_div, z_scale, lat, self.packed_weights(), cfg)
+
+
+class CodeNeRF(_DecoderBase):
+    """Drop-in for src/model_codenerf.py:13 (same constructor defaults)."""
+
+    def __init__(self, shape_blocks=2, texture_blocks=1, W=256, num_xyz_freq=10, num_dir_freq=4, latent_dim=256):
+        super().__init__()
+        self._build_decoder(shape_blocks, texture_blocks, W, num_xyz_freq, num_dir_freq, latent_dim)
+
+
+class SUPNeRF(_DecoderBase):
+    """Decoder + pose-update head of src/model_supnerf.py:164-269 (same constructor keywords).
+
+    ``img_encoder`` is the caller's stock-PyTorch image encoder (the reference's ResNet ``ImgEncoder``,
+    src/model_supnerf.py:17-152, is outside this package); ``encode_img`` forwards to it."""
+
+    def __init__(self, shape_blocks=5, texture_blocks=5, pose_blocks=3, regress_blocks=3, latent_dim=256, pose_dim=16,
+                 num_xyz_freq=10, num_dir_freq=4, norm_layer_type="BatchNorm2d", pose_shortcut=False, pred_wlh=False,
+                 img_encoder: Optional[nn.Module] = None):
+        super().__init__()
+        if img_encoder is not None:
+            self.img_encoder = img_encoder
+        W = latent_dim
+        self.pose_shortcut, self.pred_wlh = pose_shortcut, pred_wlh
+        self._build_decoder(shape_blocks, texture_blocks, W, num_xyz_freq, num_dir_freq, latent_dim)
+        self.pose_blocks, self.regress_blocks = pose_blocks, regress_blocks
+        self.pose_layer_0 = nn.Sequential(nn.Linear(pose_dim, W), nn.ReLU(inplace=True))
+        for j in range(1, pose_blocks):
+            setattr(self, f"pose_layer_{j}", nn.Sequential(nn.Linear(W, W), nn.ReLU(inplace=True)))
+        self.regress_layer_0 = nn.Sequential(nn.Linear(latent_dim + W, W), nn.ReLU(inplace=True))
+        for j in range(1, regress_blocks):
+            setattr(self, f"regress_layer_{j}", nn.Sequential(nn.Linear(W, W), nn.ReLU(inplace=True)))
+        self.out_delta_layer = nn.Linear(W, 6)
+
+    def encode_img(self, img):
+        """src/model_supnerf.py:218-224 (stock PyTorch)."""
+        if not hasattr(self, "img_encoder"):
+            raise SnrError("SUPNeRF was built without an img_encoder (the ResNet encoder stays a stock PyTorch module)")
+        out = self.img_encoder(img, self.pose_shortcut)
+        if self.pred_wlh:
+            return out
+        return (*out, None)
+
+    def pose_update(self, im_feat, box_uv_src):
+        """src/model_supnerf.py:226-239 (stock PyTorch)."""
+        f = self.pose_layer_0(box_uv_src)
+        for j in range(1, self.pose_blocks):
+            f = getattr(self, f"pose_layer_{j}")(f)
+        d = self.regress_layer_0(torch.cat([im_feat, f], -1))
+        for j in range(1, self.regress_blocks):
+            d = getattr(self, f"regress_layer_{j}")(d)
+        return self.out_delta_layer(d)

@@ -1,0 +1,348 @@
+"""Family-A renderer API (the one the reference's optimisers and trainer import from ``utils``):
+same function names, argument order and return values as src/utils.py:94-672 of the reference, with
+the work done by the HIP kernels.
+
+Differences in mechanism, not in results:
+  * everything after ray generation (sampling, /obj_diag, symmetry flip, kitti2nusc, shapenet frame,
+    positional encoding, decoder, composite) is ONE kernel launch when ``model`` is a
+    ``supnerf_amd.model`` decoder and n_samples divides 128; otherwise three HIP launches
+    (encode -> model(...) -> composite);
+  * near/far are computed on the device when the pose lives there, so no ``.tolist()`` host sync
+    (src/utils.py:468-469) stalls the stream; like the reference they are detached from the pose;
+  * random draws come from the same generators in the same order as the reference (CPU ``torch.rand(S)``
+    jitter, ``np.random.permutation`` ray subset, ``random.uniform`` symmetry coin), so a seeded run
+    consumes identical random numbers.
+"""
+import random
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import SnrError
+from .ops import Z_PER_OBJECT, Z_PER_RAY, Z_SHARED
+
+
+# ------------------------------------------------------------------------------------ rays
+def _pixel_dirs(K, c2w, px, py):
+    cx, cy, fx, fy = K[0, 2], K[1, 2], K[0, 0], K[1, 1]
+    cam = torch.stack([(px - cx) / fx, (py - cy) / fy, torch.ones_like(px)], -1).type_as(c2w)
+    world = (cam[..., None, :] * c2w[..., :3, :3]).sum(-1)
+    unit = world / torch.norm(world, dim=-1, keepdim=True)
+    origin = c2w[..., :3, -1].expand(world.shape)
+    return origin.reshape(-1, 3), unit.reshape(-1, 3)
+
+
+def get_rays(K, c2w, roi, uv_steps=None):
+    """src/utils.py:107-135: rays through a pixel grid over roi=[xmin,ymin,xmax,ymax], row-major (y,x);
+    returns (rays_o (N,3), viewdirs (N,3)) on c2w's device, differentiable wrt c2w."""
+    x0, y0, x1, y1 = [int(v) for v in roi]
+    nx, ny = (int(uv_steps[0]), int(uv_steps[1])) if uv_steps is not None else (x1 - x0, y1 - y0)
+    xs = torch.linspace(x0, x1 - 1, nx)
+    ys = torch.linspace(y0, y1 - 1, ny)
+    return _pixel_dirs(K, c2w, xs[None, :].expand(ny, nx), ys[:, None].expand(ny, nx))
+
+
+def get_rays_specified(K, c2w, x_vec, y_vec):
+    """src/utils.py:138-151: rays through listed pixel coordinates (numpy integer arrays)."""
+    return _pixel_dirs(K, c2w, torch.from_numpy(np.asarray(x_vec)), torch.from_numpy(np.asarray(y_vec)))
+
+
+def get_rays_srn(H, W, focal, c2w):
+    """src/utils.py:94-104 (ShapeNet-SRN camera convention; unused by the shipped drivers)."""
+    xs, ys = torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H)
+    px, py = xs[None, :].expand(H, W), ys[:, None].expand(H, W)
+    cam = torch.stack([(px - W * .5) / focal, -(py - H * .5) / focal, -torch.ones_like(px)], -1).type_as(c2w)
+    world = (cam[..., None, :] * c2w[..., :3, :3]).sum(-1)
+    unit = world / torch.norm(world, dim=-1, keepdim=True)
+    return c2w[..., :3, -1].expand(world.shape).reshape(-1, 3), unit.reshape(-1, 3)
+
+
+# ------------------------------------------------------------------------------------ sampling
+def _sphere_bounds(cam_pose, obj_diag):
+    """near/far = |camera centre| -/+ diag/2, detached (src/utils.py:468-469).  CPU pose: python floats exactly
+    as the reference; GPU pose: 0-dim device tensors, no host sync."""
+    if cam_pose.is_cuda:
+        dist = cam_pose[:, -1].detach().float().norm()
+        half = float(obj_diag) / 2
+        return dist - half, dist + half
+    dist = np.linalg.norm(cam_pose[:, -1].tolist())
+    return dist - obj_diag / 2, dist + obj_diag / 2
+
+
+def _linspace(start, end, steps, device):
+    """torch.linspace for python-float or 0-dim-tensor endpoints (same two-sided fp32 formula)."""
+    if not torch.is_tensor(start):
+        return torch.linspace(start, end, steps).to(device)
+    start, end = start.float(), end.float()
+    i = torch.arange(steps, device=start.device, dtype=torch.float32)
+    step = (end - start) / max(steps - 1, 1)
+    lo = start + step * i
+    hi = end - step * (steps - 1 - i)
+    return torch.where(i < steps // 2, lo, hi)
+
+
+# test hook: a tensor here replaces the next jitter draws (parity tests inject the reference's numbers)
+JITTER_OVERRIDE = None
+
+
+def _shared_depths(near, far, n_samples, device, z_fixed=False, jitter=None):
+    """The (S,) depth vector of ``sample_from_rays`` (src/utils.py:159-164).  ``jitter`` overrides the
+    ``torch.rand(S)`` draw (tests)."""
+    if z_fixed:
+        return _linspace(near, far, n_samples, device)
+    half = (far - near) / (2 * n_samples)
+    z = _linspace(near + half, far - half, n_samples, device)
+    if jitter is None:
+        jitter = JITTER_OVERRIDE if JITTER_OVERRIDE is not None else torch.rand(n_samples)
+    return z + jitter.to(device) * (far - near) / (2 * n_samples)
+
+
+def sample_from_rays(ro, vd, near, far, N_samples, z_fixed=False):
+    """src/utils.py:154-167: xyz (N,S,3), viewdir repeated (N,S,3), z_vals (S,).  HIP encode kernel."""
+    z = _shared_depths(near, far, N_samples, ro.device, z_fixed)
+    cfg = ops.RenderCfg(N_samples, Z_SHARED, max(ro.shape[0], 1), 0, 0)
+    if ro.requires_grad or vd.requires_grad:
+        zz = z.type_as(ro)
+        return ro.unsqueeze(-2) + vd.unsqueeze(-2) * zz.unsqueeze(-1), vd.unsqueeze(-2).repeat(1, N_samples, 1), z
+    xyz, vdir, _ = ops.encode(ro, vd, z, torch.ones(1, device=ro.device), None, cfg)
+    return xyz, vdir, z
+
+
+def _frame(sym_flip, kitti2nusc, shapenet_obj_cood):
+    """Row-major 3x3 combining, in the reference's order (src/utils.py:475-495): y mirror, KITTI->nuScenes
+    (x,y,z)->(x,z,-y), nuScenes->ShapeNet (x,y,z)->(-y,x,z)."""
+    m = np.eye(3, dtype=np.float32)
+    if sym_flip:
+        m = np.diag([1.0, -1.0, 1.0]).astype(np.float32) @ m
+    if kitti2nusc:
+        m = np.array([[1, 0, 0], [0, 0, 1], [0, -1, 0]], dtype=np.float32) @ m
+    if shapenet_obj_cood:
+        m = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], dtype=np.float32) @ m
+    return tuple(m.reshape(-1).tolist())
+
+
+def _sym_coin(sym_aug):
+    return bool(sym_aug) and random.uniform(0, 1) > 0.5
+
+
+# ------------------------------------------------------------------------------------ composite
+def _composite(sigmas, rgbs, z_vals, z_mode, white_bkgd, rays_per_obj=0):
+    sig = sigmas.squeeze(-1) if sigmas.dim() == rgbs.dim() else sigmas
+    return ops.Composite.apply(sig, rgbs, z_vals, z_mode, white_bkgd, rays_per_obj)
+
+
+def volume_rendering2(sigmas, rgbs, z_vals):
+    """src/utils.py:202-217: sigmas (N,S,1), rgbs (N,S,3), z_vals (S,) -> rgb (N,3), depth (N,), acc_trans (N,)."""
+    return _composite(sigmas, rgbs, z_vals, Z_SHARED, False)
+
+
+def volume_rendering(sigmas, rgbs, z_vals):
+    """src/utils.py:187-199 (legacy, two outputs; the reference omits the relu here, which only matters for
+    negative densities -- the decoder's softplus never produces them)."""
+    rgb, depth, _ = _composite(sigmas, rgbs, z_vals, Z_SHARED, False)
+    return rgb, depth
+
+
+def volume_rendering_batch(sigmas, rgbs, z_vals):
+    """src/utils.py:220-233: sigmas (B,n,S,1), rgbs (B,n,S,3), z_vals (B,S) -> (B,n,3), (B,n), (B,n)."""
+    B, n, S = rgbs.shape[:3]
+    rgb, depth, acc = _composite(sigmas.reshape(B * n, S), rgbs.reshape(B * n, S, 3), z_vals, Z_PER_OBJECT, False, rays_per_obj=n)
+    return rgb.view(B, n, 3), depth.view(B, n), acc.view(B, n)
+
+
+# ------------------------------------------------------------------------------------ targets
+def _resize(img, mask_occ, im_sz):
+    """Bilinear, no antialias (torchvision 0.13 tensor ``Resize``); mask truncated through int32
+    (src/utils.py:447-456)."""
+    im = F.interpolate(img.permute(2, 0, 1)[None], size=(im_sz, im_sz), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+    mk = F.interpolate(mask_occ.permute(2, 0, 1)[None], size=(im_sz, im_sz), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+    return im, mk.type(torch.int32).type(torch.float32)
+
+
+# ------------------------------------------------------------------------------------ render core
+def _is_native(model):
+    return hasattr(model, "fused_render") and hasattr(model, "packed_weights")
+
+
+def _render_shared_z(model, device, rays_o, viewdir, z, obj_diag, frame, shapecode, texturecode):
+    """Family-A tail: points = frame * ((o + z d) / obj_diag), black background, z shared by all rays."""
+    S = z.shape[0]
+    dev = torch.device(device)
+    rays_o, viewdir, z = rays_o.to(dev), viewdir.to(dev), z.to(dev)
+    B = shapecode.shape[0]
+    div = torch.full((B,), float(obj_diag), device=dev)
+    cfg = ops.RenderCfg(S, Z_SHARED, rays_o.shape[0] // B, getattr(model, "shape_blocks", 0), getattr(model, "texture_blocks", 0),
+                        frame=frame)
+    if rays_o.shape[0] == 0:
+        e = torch.empty(0, device=dev)
+        return e.view(0, 3), e, e
+    if _is_native(model) and ops.fused_supported(S):
+        return model.fused_render(rays_o, viewdir, z, div, None, shapecode, texturecode, cfg)
+    # unfused: HIP encode -> caller's decoder -> HIP composite
+    if rays_o.requires_grad or viewdir.requires_grad:
+        m = torch.tensor(frame, device=dev).view(3, 3)
+        xyz = ((rays_o[:, None, :] + viewdir[:, None, :] * z[None, :, None]) / float(obj_diag)) @ m.T
+        vdir = (viewdir @ m.T)[:, None, :].repeat(1, S, 1)
+    else:
+        xyz, vdir, _ = ops.encode(rays_o, viewdir, z, div, None, cfg)
+    sigmas, rgbs = model(xyz, vdir, shapecode, texturecode)
+    return volume_rendering2(sigmas, rgbs, z)
+
+
+def render_rays(model, device, img, mask_occ, cam_pose, obj_diag, K, roi, n_samples, shapecode, texturecode, shapenet_obj_cood,
+                sym_aug, kitti2nusc=False, n_rays=2500):
+    """src/utils.py:380-432: a random subset of n_rays pixels of the full roi."""
+    rays_o, viewdir = get_rays(K, cam_pose, roi)
+    n_rays = int(np.minimum(rays_o.shape[0], n_rays))
+    ids = np.random.permutation(rays_o.shape[0])[:n_rays]
+    rays_o, viewdir = rays_o[ids], viewdir[ids]
+    rgb_tgt = img.reshape(-1, 3)[ids].to(device)
+    occ_pixels = mask_occ.reshape(-1, 1)[ids].to(device)
+    near, far = _sphere_bounds(cam_pose, obj_diag)
+    z = _shared_depths(near, far, n_samples, rays_o.device)
+    frame = _frame(_sym_coin(sym_aug), kitti2nusc, shapenet_obj_cood)
+    rgb, depth, acc = _render_shared_z(model, device, rays_o, viewdir, z, obj_diag, frame, shapecode, texturecode)
+    return rgb, depth, acc, rgb_tgt, occ_pixels
+
+
+def render_rays_v2(model, device, img, mask_occ, cam_pose, obj_diag, K, roi, n_samples, shapecode, texturecode, shapenet_obj_cood,
+                   sym_aug, kitti2nusc=False, im_sz=64, n_rays=None):
+    """src/utils.py:435-502: im_sz x im_sz grid over the roi (the optimisers' render call)."""
+    rays_o, viewdir = get_rays(K, cam_pose, roi, uv_steps=[im_sz, im_sz])
+    img, mask_occ = _resize(img, mask_occ, im_sz)
+    rgb_tgt = img.reshape(-1, 3).to(device)
+    occ_pixels = mask_occ.reshape(-1, 1).to(device)
+    if n_rays is not None:
+        n_rays = int(np.minimum(rays_o.shape[0], n_rays))
+        ids = np.random.permutation(rays_o.shape[0])[:n_rays]
+        rays_o, viewdir, rgb_tgt, occ_pixels = rays_o[ids], viewdir[ids], rgb_tgt[ids], occ_pixels[ids]
+    near, far = _sphere_bounds(cam_pose, obj_diag)
+    z = _shared_depths(near, far, n_samples, rays_o.device)
+    frame = _frame(_sym_coin(sym_aug), kitti2nusc, shapenet_obj_cood)
+    rgb, depth, acc = _render_shared_z(model, device, rays_o, viewdir, z, obj_diag, frame, shapecode, texturecode)
+    return rgb, depth, acc, rgb_tgt, occ_pixels
+
+
+def render_rays_specified(model, device, img, mask_occ, cam_pose, obj_diag, K, roi, x_vec, y_vec, n_samples, shapecode, texturecode,
+                          shapenet_obj_cood, sym_aug, kitti2nusc=False):
+    """src/utils.py:504-551: rays at listed pixels of the crop (lidar pixels in the optimisers)."""
+    rays_o, viewdir = get_rays_specified(K, cam_pose, x_vec + int(roi[0]), y_vec + int(roi[1]))
+    rgb_tgt = img[y_vec, x_vec, :].to(device)
+    occ_pixels = mask_occ[y_vec, x_vec, :].to(device)
+    near, far = _sphere_bounds(cam_pose, obj_diag)
+    z = _shared_depths(near, far, n_samples, rays_o.device)
+    frame = _frame(_sym_coin(sym_aug), kitti2nusc, shapenet_obj_cood)
+    rgb, depth, acc = _render_shared_z(model, device, rays_o, viewdir, z, obj_diag, frame, shapecode, texturecode)
+    return rgb, depth, acc, rgb_tgt, occ_pixels
+
+
+def prepare_pixel_samples(img, mask_occ, cam_pose, obj_diag, K, roi, n_rays, n_samples, shapenet_obj_cood, sym_aug, im_sz=None):
+    """src/utils.py:330-377: pre-sampled ray batch for the trainer: xyz (n,S,3), viewdir (n,S,3), z_vals (S,),
+    rgb_tgt (n,3), occ_pixels (n,1).  Stays on the inputs' device (the datasets call it on CPU workers; there the
+    arithmetic is plain torch, on the GPU it is the encode kernel)."""
+    near, far = _sphere_bounds(cam_pose, obj_diag)
+    if im_sz is None:
+        rays_o, viewdir = get_rays(K, cam_pose, roi)
+    else:
+        rays_o, viewdir = get_rays(K, cam_pose, roi, uv_steps=[im_sz, im_sz])
+        img, mask_occ = _resize(img, mask_occ, im_sz)
+    n_rays = int(np.minimum(rays_o.shape[0], n_rays))
+    ids = np.random.permutation(rays_o.shape[0])[:n_rays]
+    rays_o, viewdir = rays_o[ids], viewdir[ids]
+    rgb_tgt = img.reshape(-1, 3)[ids]
+    occ_pixels = mask_occ.reshape(-1, 1)[ids]
+    z = _shared_depths(near, far, n_samples, rays_o.device)
+    frame = _frame(_sym_coin(sym_aug), False, shapenet_obj_cood)
+    if rays_o.is_cuda:
+        cfg = ops.RenderCfg(n_samples, Z_SHARED, max(rays_o.shape[0], 1), 0, 0, frame=frame)
+        xyz, vdir, _ = ops.encode(rays_o, viewdir, z, torch.full((1,), float(obj_diag), device=rays_o.device), None, cfg)
+    else:
+        m = torch.tensor(frame).view(3, 3)
+        xyz = ((rays_o[:, None, :] + viewdir[:, None, :] * z[None, :, None]) / obj_diag) @ m.T
+        vdir = (viewdir @ m.T)[:, None, :].repeat(1, n_samples, 1)
+    return xyz, vdir, z, rgb_tgt, occ_pixels
+
+
+def render_full_img(model, device, cam_pose, obj_sz, K, roi, n_samples, shapecode, texturecode, shapenet_obj_cood, out_depth=False,
+                    debug_occ=False, kitti2nusc=False):
+    """src/utils.py:554-616: every pixel of the roi; returns (H,W,3) [and (H,W) depth].  The reference renders in
+    slabs of max(roi_w, roi_h) rays to bound activation memory; the fused kernel keeps activations in registers, so
+    the whole roi is one launch."""
+    obj_diag = np.linalg.norm(obj_sz).astype(np.float32)
+    rays_o, viewdir = get_rays(K, cam_pose, roi)
+    near, far = _sphere_bounds(cam_pose, obj_diag)
+    z = _shared_depths(near, far, n_samples, rays_o.device)
+    frame = _frame(False, kitti2nusc, shapenet_obj_cood)
+    with torch.no_grad():
+        rgb, depth, acc = _render_shared_z(model, device, rays_o, viewdir, z, obj_diag, frame, shapecode, texturecode)
+    h, w = int(roi[3] - roi[1]), int(roi[2] - roi[0])
+    if debug_occ:
+        raise SnrError("debug_occ opens a cv2 window in the reference; not available in this package")
+    if out_depth:
+        return rgb.reshape(h, w, 3), depth.reshape(h, w)
+    return rgb.reshape(h, w, 3)
+
+
+def render_virtual_imgs(model, device, obj_sz, K, n_samples, shapecode, texturecode, shapenet_obj_cood, radius=40., tilt=np.pi / 6,
+                        pan_num=8, img_sz=128, kitti2nusc=False):
+    """src/utils.py:619-672: pan_num turntable views at fixed radius / tilt.  Returns the list of (img_sz,img_sz,3)
+    CPU tensors; the reference additionally draws the object axes with cv2 arrows (visualisation only, omitted)."""
+    cx, cy = float(K[0, 2]), float(K[1, 2])
+    roi = np.asarray([cx - img_sz / 2, cy - img_sz / 2, cx + img_sz / 2, cy + img_sz / 2]).astype(np.int64)
+    cam_init = np.asarray([[0, 0, 1, -radius], [-1, 0, 0, 0], [0, -1, 0, 0], [0, 0, 0, 1]]).astype(np.float32)
+    ct, st = np.cos(tilt), np.sin(tilt)
+    cam_tilt = np.asarray([[ct, 0, st, 0], [0, 1, 0, 0], [-st, 0, ct, 0], [0, 0, 0, 1]]).astype(np.float32) @ cam_init
+    views = []
+    for pan in np.linspace(0, 2 * np.pi, pan_num, endpoint=False):
+        cp, sp = np.cos(pan), np.sin(pan)
+        pose = np.asarray([[cp, -sp, 0, 0], [sp, cp, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]).astype(np.float32) @ cam_tilt
+        img = render_full_img(model, device, torch.from_numpy(pose[:3, :]), obj_sz, K, roi, n_samples, shapecode, texturecode,
+                              shapenet_obj_cood, kitti2nusc=kitti2nusc)
+        views.append(img.cpu())
+    return views
+
+
+# ------------------------------------------------------------------------------------ box test (used by renderer.py)
+def ray_box_intersection_tensor(ray_o, ray_d, aabb_min=None, aabb_max=None):
+    """src/utils.py:283-327: slab test; returns (z_in, z_out) of the HIT rays and the boolean hit map, or
+    (None, None, None) for an empty ray set.  NaN-propagating min/max like the reference."""
+    if aabb_min is None:
+        aabb_min = torch.full_like(ray_o, -1.)
+    if aabb_max is None:
+        aabb_max = torch.full_like(ray_o, 1.)
+    t_near, t_far, hit = _slab(ray_o, ray_d, aabb_min, aabb_max)
+    if hit.shape[0] == 0:
+        return None, None, None
+    return t_near[hit], t_far[hit], hit
+
+
+def _slab(ray_o, ray_d, aabb_min, aabb_max):
+    inv = torch.reciprocal(ray_d)
+    ta, tb = (aabb_min - ray_o) * inv, (aabb_max - ray_o) * inv
+    lo, hi = torch.minimum(ta, tb), torch.maximum(ta, tb)
+    t_near = torch.maximum(torch.maximum(lo[..., 0], lo[..., 1]), lo[..., 2])
+    t_far = torch.minimum(torch.minimum(hi[..., 0], hi[..., 1]), hi[..., 2])
+    hit = t_far > t_near
+    hit = torch.logical_and(hit, (t_far * hit) > 0)
+    return t_near, t_far, hit
+
+
+def ray_box_intersection(ray_o, ray_d, aabb_min=None, aabb_max=None):
+    """src/utils.py:236-280: numpy twin of the slab test."""
+    if aabb_min is None:
+        aabb_min = np.ones_like(ray_o) * -1.
+    if aabb_max is None:
+        aabb_max = np.ones_like(ray_o)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = np.reciprocal(ray_d)
+        ta, tb = (aabb_min - ray_o) * inv, (aabb_max - ray_o) * inv
+    lo, hi = np.minimum(ta, tb), np.maximum(ta, tb)
+    t_near = np.maximum(np.maximum(lo[..., 0], lo[..., 1]), lo[..., 2])
+    t_far = np.minimum(np.minimum(hi[..., 0], hi[..., 1]), hi[..., 2])
+    hit = t_far > t_near
+    hit = np.logical_and(hit, (t_far * hit) > 0)
+    if hit.shape[0] == 0:
+        return None, None, None
+    return t_near[hit], t_far[hit], hit

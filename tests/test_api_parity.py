@@ -1,0 +1,313 @@
+"""The reference-signature API (supnerf_amd.utils / .renderer / .model) on the GPU against the golden vectors
+the reference produced, forward and backward.  These read like calls into the reference's own modules."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import supnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_RGB, TOL_ACC = 2e-5, 2e-5
+TOL_DEPTH_MEAN, TOL_DEPTH_MAX = 1e-5, 1e-4       # metres; north_star bound on the mean is 1e-4
+TOL_PSNR_DB = 0.01                               # north_star: PSNR delta <= 0.01 dB
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import supnerf_amd
+    return supnerf_amd
+
+
+@pytest.fixture(scope="module")
+def model(amd, dev, oracle_params):
+    m = amd.CodeNeRF(shape_blocks=3, texture_blocks=1)
+    m.load_state_dict(oracle_params, strict=True)
+    return m.to(dev)
+
+
+@pytest.fixture()
+def jitter(amd):
+    def set_(t):
+        amd.utils.JITTER_OVERRIDE = t
+    yield set_
+    amd.utils.JITTER_OVERRIDE = None
+
+
+def md(a, b):
+    return float((a.detach().double().cpu() - torch.as_tensor(b).double().cpu()).abs().max())
+
+
+def close_grad(a, b, rel=2e-4):
+    b = torch.as_tensor(b).double().cpu()
+    return md(a, b) <= rel * float(b.abs().max()) + 1e-7
+
+
+def check_render(out, g, keys=("rgb", "depth", "acc", "rgb_tgt", "occ")):
+    rgb, depth, acc = out[0], out[1], out[2]
+    assert md(rgb, g[keys[0]]) < TOL_RGB
+    assert float((depth.cpu() - g[keys[1]]).abs().mean()) < TOL_DEPTH_MEAN and md(depth, g[keys[1]]) < TOL_DEPTH_MAX
+    assert md(acc, g[keys[2]]) < TOL_ACC
+    if len(keys) > 3:
+        assert md(out[3], g[keys[3]]) == 0.0 and md(out[4], g[keys[4]]) == 0.0
+
+
+def psnr(rgb, tgt, occ):
+    fg = occ.clone(); fg[occ < 0] = 0
+    return float(-10 * torch.log10(((rgb - tgt) ** 2 * fg).sum() / (fg.sum() + 1e-9)))
+
+
+# ------------------------------------------------------------------ family A (src/utils.py)
+@pytest.mark.parametrize("tag", ["a_nusc", "a_demo", "a_kitti"])
+def test_render_rays_v2(amd, dev, model, golden, jitter, tag):
+    g = golden("render_" + tag)
+    jitter(g["jitter"])
+    with torch.no_grad():
+        out = amd.utils.render_rays_v2(model, dev, g["img"], g["mask_occ"], g["cam_pose"], np.float32(g["obj_diag"]), g["K"], g["roi"],
+                                       int(g["n_samples"]), g["shapecode"].to(dev), g["texturecode"].to(dev),
+                                       int(g["shapenet_obj_cood"]), 0, kitti2nusc=bool(g["kitti2nusc"]), im_sz=int(g["im_sz"]))
+    check_render(out, g)
+    # the metric BASELINE.json names: PSNR against the same target, ours vs reference
+    p_ref = psnr(g["rgb"], g["rgb_tgt"], g["occ"]); p_our = psnr(out[0].cpu(), g["rgb_tgt"], g["occ"])
+    assert abs(p_ref - p_our) < TOL_PSNR_DB
+
+
+def test_render_rays_v2_pose_on_gpu_no_host_sync(amd, dev, model, golden, jitter):
+    """Pose on the device (optimiser mode): near/far are computed there; results agree to fp32 round-off."""
+    g = golden("render_a_nusc")
+    jitter(g["jitter"])
+    with torch.no_grad():
+        out = amd.utils.render_rays_v2(model, dev, g["img"], g["mask_occ"], g["cam_pose"].to(dev), np.float32(g["obj_diag"]), g["K"],
+                                       g["roi"], 64, g["shapecode"].to(dev), g["texturecode"].to(dev), 1, 0, im_sz=8)
+    assert md(out[0], g["rgb"]) < 5e-5 and md(out[1], g["depth"]) < 2e-4 and md(out[2], g["acc"]) < 5e-5
+
+
+def test_render_rays_v2_flip_and_subset_same_rng_stream(amd, dev, model, golden, jitter):
+    """sym_aug coin, ray permutation and jitter come from the same generators in the same order as the reference."""
+    g = golden("render_a_flip_subset")
+    jitter(g["jitter"])
+    seed_flip = next(s for s in range(100) if random.Random(s).uniform(0, 1) > 0.5)
+    random.seed(seed_flip); np.random.seed(7)
+    with torch.no_grad():
+        out = amd.utils.render_rays_v2(model, dev, g["img"], g["mask_occ"], g["cam_pose"], np.float32(g["obj_diag"]), g["K"], g["roi"],
+                                       64, g["shapecode"].to(dev), g["texturecode"].to(dev), 1, 1, im_sz=8, n_rays=40)
+    check_render(out, g)
+
+
+def test_jitter_uses_cpu_generator_like_reference(amd, dev, model, golden):
+    g = golden("render_a_nusc")
+    torch.manual_seed(41)                      # the seed gen_golden.py used for this fixture
+    with torch.no_grad():
+        out = amd.utils.render_rays_v2(model, dev, g["img"], g["mask_occ"], g["cam_pose"], np.float32(g["obj_diag"]), g["K"], g["roi"],
+                                       64, g["shapecode"].to(dev), g["texturecode"].to(dev), 1, 0, im_sz=8)
+    check_render(out, g)
+
+
+def test_render_rays_specified(amd, dev, model, golden, jitter):
+    g = golden("render_a_specified")
+    jitter(g["jitter"])
+    with torch.no_grad():
+        out = amd.utils.render_rays_specified(model, dev, g["img"], g["mask_occ"], g["cam_pose"], np.float32(g["obj_diag"]), g["K"],
+                                              g["roi"], g["x_vec"].numpy(), g["y_vec"].numpy(), 64, g["shapecode"].to(dev),
+                                              g["texturecode"].to(dev), 1, 0)
+    # 7 rays x 64 samples: a partially filled 128-point tile
+    check_render(out, g)
+
+
+def test_resize_targets(amd, golden):
+    g = golden("resize_targets")
+    im, mk = amd.utils._resize(g["img"], g["mask_occ"], 8)
+    assert md(im.reshape(-1, 3), g["rgb_tgt"]) == 0 and md(mk.reshape(-1, 1), g["occ"]) == 0
+
+
+def test_prepare_pixel_samples(amd, dev, golden, jitter):
+    g = golden("prepare_pixel_samples")
+    for device in ("cpu", dev):
+        jitter(g["jitter"])
+        np.random.seed(9)
+        out = amd.utils.prepare_pixel_samples(g["img"].to(device), g["mask_occ"].to(device), g["cam_pose"].to(device),
+                                              np.float32(g["obj_diag"]), g["K"], g["roi"], 20, 64, 1, 0, im_sz=8)
+        for a, k in zip(out, ("xyz", "viewdir", "z_vals", "rgb_tgt", "occ")):
+            assert md(a, g[k]) < 2e-6, (k, str(device))
+
+
+def test_render_full_img(amd, dev, model, golden, jitter):
+    g = golden("render_full_img")
+    jitter(g["jitter"])
+    img, depth = amd.utils.render_full_img(model, dev, g["cam_pose"], g["wlh"].numpy(), g["K"], g["roi"], 64, g["shapecode"].to(dev),
+                                           g["texturecode"].to(dev), 1, out_depth=True)
+    assert md(img, g["img"]) < TOL_RGB and md(depth, g["depth"]) < TOL_DEPTH_MAX
+
+
+def test_unfused_path_odd_sample_count(amd, dev, model, oracle_params, jitter):
+    """n_samples that does not divide 128: encode -> decoder -> composite, three HIP launches, same results."""
+    ob = O.synthetic_object(3)
+    img, mask = O.synthetic_targets(3, 8)
+    S = 48
+    jit = torch.rand(S, generator=torch.Generator().manual_seed(3))
+    gen = torch.Generator().manual_seed(33)
+    sc, tc = torch.randn(1, 256, generator=gen) * 0.3, torch.randn(1, 256, generator=gen) * 0.3
+    with torch.no_grad():
+        ref = O.render_rays_v2(oracle_params, img, mask, ob["cam_pose"], ob["obj_diag"], ob["K"], ob["roi"], S, sc, tc, True, im_sz=8,
+                               jitter=jit)
+    jitter(jit)
+    with torch.no_grad():
+        out = amd.utils.render_rays_v2(model, dev, img, mask, ob["cam_pose"], ob["obj_diag"], ob["K"], ob["roi"], S, sc.to(dev),
+                                       tc.to(dev), 1, 0, im_sz=8)
+    for a, b, tol in zip(out[:3], ref[:3], (TOL_RGB, TOL_DEPTH_MAX, TOL_ACC)):
+        assert md(a, b) < tol
+
+
+# ------------------------------------------------------------------ family B (src/renderer.py)
+@pytest.mark.parametrize("tag", ["b_hit", "b_s32"])
+def test_nerf_renderer_render_rays(amd, dev, model, golden, jitter, tag):
+    g = golden("render_" + tag)
+    jitter(g["jitter"])
+    rend = amd.NeRFRenderer(n_samples=int(g["n_samples"]), white_bkgd=True)
+    with torch.no_grad():
+        out = rend.render_rays(model, dev, g["img"], g["mask_occ"], g["cam_pose"], g["wlh"].numpy(), g["K"], g["roi"],
+                               g["shapecode"].to(dev), g["texturecode"].to(dev), im_sz=int(g["im_sz"]))
+    check_render(out, g)
+    miss = ~g["hit"].bool()
+    # rays that miss the box see only the white background and report depth diag/2 * |d| at the collapsed sample
+    assert miss.any()
+
+
+def test_render_rays_v3(amd, dev, model, golden, jitter):
+    g, g3 = golden("render_b_hit"), golden("render_v3_b_hit")
+    jitter(g3["jitter"])
+    with torch.no_grad():
+        out = amd.render_rays_v3(model, dev, g["img"], g["mask_occ"], g["cam_pose"], g["wlh"].numpy(), g["K"], g["roi"], 64,
+                                 g["shapecode"].to(dev), g["texturecode"].to(dev), 1, 0, im_sz=8, adjust_scale=float(g3["adjust_scale"]))
+    assert md(out[0], g3["rgb"]) < 5e-5 and md(out[1], g3["depth"]) < 2e-4 and md(out[2], g3["acc"]) < 5e-5
+    with pytest.raises(amd.SnrError):
+        amd.render_rays_v3(model, dev, g["img"], g["mask_occ"], g["cam_pose"], g["wlh"].numpy(), g["K"], g["roi"], 32,
+                           g["shapecode"].to(dev), g["texturecode"].to(dev), 1, 0, im_sz=8)
+
+
+# ------------------------------------------------------------------ decoder drop-in (src/model_supnerf.py)
+@pytest.mark.parametrize("tag", ["b1_s32", "b3_s64", "b2_s7"])
+def test_model_forward(amd, dev, model, golden, tag):
+    g = golden("decoder_" + tag)
+    with torch.no_grad():
+        sig, rgb = model(g["xyz"].to(dev), g["viewdir"].to(dev), g["shapecode"].to(dev), g["texturecode"].to(dev))
+    assert sig.shape == g["sigmas"].shape and rgb.shape == g["rgbs"].shape
+    assert md(sig, g["sigmas"]) < 2e-5 and md(rgb, g["rgbs"]) < 2e-5
+
+
+def test_model_forward_backward_vs_oracle_autograd(amd, dev, model, oracle_params):
+    gen = torch.Generator().manual_seed(77)
+    N, S, B = 8, 16, 2            # 64 points per object: whole wave tiles per object
+    xyz = (torch.rand(N, S, 3, generator=gen) - 0.5).requires_grad_()
+    vd = torch.randn(N, S, 3, generator=gen); vd = (vd / vd.norm(dim=-1, keepdim=True)).requires_grad_()
+    sc = (torch.randn(B, 256, generator=gen) * 0.3).requires_grad_()
+    tc = (torch.randn(B, 256, generator=gen) * 0.3).requires_grad_()
+    ws, wr = torch.randn(N, S, 1, generator=gen), torch.randn(N, S, 3, generator=gen)
+    sig_o, rgb_o = O.decoder_forward(oracle_params, xyz, vd, sc, tc)
+    ((sig_o * ws).sum() + (rgb_o * wr).sum()).backward()
+    leaves = [t.detach().to(dev).requires_grad_() for t in (xyz, vd, sc, tc)]
+    sig, rgb = model(*leaves)
+    ((sig * ws.to(dev)).sum() + (rgb * wr.to(dev)).sum()).backward()
+    for a, b, name in zip(leaves, (xyz, vd, sc, tc), ("xyz", "viewdir", "shapecode", "texturecode")):
+        assert close_grad(a.grad, b.grad), name
+
+
+# ------------------------------------------------------------------ gradients of the render path
+def test_gradients_family_a(amd, dev, model, golden, jitter):
+    g = golden("grads_family_a")
+    jitter(g["jitter"])
+    sc = g["shapecode"].to(dev).requires_grad_()
+    tc = g["texturecode"].to(dev).requires_grad_()
+    pose = g["cam_pose"].to(dev).requires_grad_()
+    out = amd.utils.render_rays_v2(model, dev, g["img"], g["mask_occ"], pose, np.float32(g["obj_diag"]), g["K"], g["roi"], 64, sc, tc, 1, 0,
+                                   im_sz=8)
+    loss, l_rgb, l_occ, ps = O.optimise_losses(out[0], out[2], out[3], out[4], 0.1)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 2e-5 and abs(float(ps) - float(g["psnr"])) < TOL_PSNR_DB
+    assert close_grad(sc.grad, g["d_shapecode"]) and close_grad(tc.grad, g["d_texturecode"])
+    assert close_grad(pose.grad, g["d_cam_pose"], rel=5e-4)
+
+
+def test_gradients_family_b(amd, dev, model, golden, jitter):
+    g = golden("grads_family_b")
+    jitter(g["jitter"])
+    sc = g["shapecode"].to(dev).requires_grad_()
+    tc = g["texturecode"].to(dev).requires_grad_()
+    pose = g["cam_pose"].to(dev).requires_grad_()
+    rend = amd.NeRFRenderer(n_samples=32, white_bkgd=True)
+    out = rend.render_rays(model, dev, g["img"], g["mask_occ"], pose, g["wlh"].numpy(), g["K"], g["roi"], sc, tc, im_sz=8)
+    loss = O.optimise_losses(out[0], out[2], out[3], out[4], 0.1)[0] + 0.01 * out[1].sum()
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 5e-5
+    assert close_grad(sc.grad, g["d_shapecode"]) and close_grad(tc.grad, g["d_texturecode"])
+    assert close_grad(pose.grad, g["d_cam_pose"], rel=5e-4)
+
+
+def test_training_shapes_volume_rendering_batch(amd, dev, model, golden):
+    """Decoder half of ParallelModel.forward (src/trainer_unified_nuscenes.py:120-129): batched codes, per-object z."""
+    g = golden("train_step")
+    B, n, S = g["xyz"].shape[:3]
+    sc = g["shapecode"].to(dev).requires_grad_()
+    tc = g["texturecode"].to(dev).requires_grad_()
+    sig, rgb = model(g["xyz"].flatten(0, 1).to(dev), g["viewdir"].flatten(0, 1).to(dev), sc, tc)
+    out = amd.utils.volume_rendering_batch(sig.view(B, n, S, 1), rgb.view(B, n, S, 3), g["z_vals"].to(dev))
+    loss = ((out[0] - g["tgt"].to(dev)) ** 2).mean() + 0.1 * out[2].mean()
+    loss.backward()
+    assert md(out[0], g["rgb"]) < TOL_RGB and md(out[1], g["depth"]) < TOL_DEPTH_MAX and md(out[2], g["acc"]) < TOL_ACC
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    assert close_grad(sc.grad, g["d_shapecode"]) and close_grad(tc.grad, g["d_texturecode"])
+
+
+# ------------------------------------------------------------------ batched objects, full size properties
+def test_batched_objects_equal_single_objects(amd, dev, model):
+    """C3 shape in miniature: B objects in one launch == B single-object launches (object-major codes, per-object z)."""
+    ops = amd.ops
+    B, N, S = 3, 64, 64
+    gen = torch.Generator().manual_seed(5)
+    ro = (torch.randn(B * N, 3, generator=gen) * 0.2 + torch.tensor([0., -11., 1.])).to(dev)
+    vd = torch.randn(B * N, 3, generator=gen) * 0.1 + torch.tensor([0., 1., 0.]); vd = (vd / vd.norm(dim=-1, keepdim=True)).to(dev)
+    z = torch.sort(torch.rand(B, S, generator=gen) * 5 + 8.5, dim=-1)[0].to(dev)
+    sc, tc = (torch.randn(B, 256, generator=gen) * 0.3).to(dev), (torch.randn(B, 256, generator=gen) * 0.3).to(dev)
+    div = torch.tensor([5.1, 5.6, 4.9], device=dev)
+    with torch.no_grad():
+        cfg = ops.RenderCfg(S, ops.Z_PER_OBJECT, N, 3, 1)
+        full = model.fused_render(ro, vd, z, div, None, sc, tc, cfg)
+        for b in range(B):
+            cfg1 = ops.RenderCfg(S, ops.Z_SHARED, N, 3, 1)
+            one = model.fused_render(ro[b * N:(b + 1) * N], vd[b * N:(b + 1) * N], z[b], div[b:b + 1], None, sc[b:b + 1], tc[b:b + 1], cfg1)
+            for a, c in zip(full, one):
+                assert torch.equal(a[b * N:(b + 1) * N], c)
+
+
+def test_full_size_properties(amd, dev, model):
+    """BASELINE config 2 size (4096 rays x 64 samples): size-independent properties instead of an oracle run --
+    determinism, independence of rays (any subset renders to the same values), opacity bounds."""
+    ops = amd.ops
+    N, S = 4096, 64
+    gen = torch.Generator().manual_seed(9)
+    ro = (torch.randn(N, 3, generator=gen) * 0.3 + torch.tensor([0., -12., 1.])).to(dev)
+    vd = torch.randn(N, 3, generator=gen) * 0.15 + torch.tensor([0., 1., 0.]); vd = (vd / vd.norm(dim=-1, keepdim=True)).to(dev)
+    z = torch.linspace(9.3, 14.7, S).to(dev)
+    sc, tc = (torch.randn(1, 256, generator=gen) * 0.3).to(dev), (torch.randn(1, 256, generator=gen) * 0.3).to(dev)
+    div = torch.tensor([5.4], device=dev)
+    cfg = ops.RenderCfg(S, ops.Z_SHARED, N, 3, 1)
+    with torch.no_grad():
+        a = model.fused_render(ro, vd, z, div, None, sc, tc, cfg)
+        b = model.fused_render(ro, vd, z, div, None, sc, tc, cfg)
+        idx = torch.randperm(N, generator=gen)[:1000].to(dev)
+        cfg_s = ops.RenderCfg(S, ops.Z_SHARED, 1000, 3, 1)
+        sub = model.fused_render(ro[idx], vd[idx], z, div, None, sc, tc, cfg_s)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    for x, y in zip(a, sub):
+        assert torch.equal(x[idx], y)
+    assert bool((a[2] >= 0).all()) and bool((a[2] <= 1 + 1e-6).all())
+    assert bool((a[1] >= 0).all()) and bool((a[1] <= float(z[-1]) + 1e-3).all())
