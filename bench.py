@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/s of the fused render hot path at BASELINE.json's configuration.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One *step* = one fused forward pass (sample -> frame transform -> positional encoding -> decoder -> composite) over
+one object's ray batch: 4096 rays x 64 samples (BASELINE configs[1]: supnerf.nusc.vehicle.car.json hyper-parameters,
+im_sz 64, synthetic nuScenes-like car, random-init decoder with the sigma bias of SURVEY 8d), inputs resident in
+HBM.  Every rank renders its own object (objects are independent: weak scaling, no data-path collective); the only
+collective is the max-reduce of the elapsed time.  Rank 0 prints ONE JSON line.
+
+Extra legs that are reported but are NOT `value`:
+  * forward+backward (codes + pose gradients) rays/s, the optimiser's inner iteration;
+  * `roofline`: algorithmic FLOPs (57.56 MFLOP/ray) / kernel time from device events on the
+    launch stream, against the fp32-matrix peak of MI355X_MICROARCH.md (157.3 TFLOP/s);
+  * `cpu_baseline`: the CPU oracle (pure PyTorch restatement of the reference, oracle/) timed on this host's cores
+    over a bounded sample, plus the parity numbers (PSNR delta, depth L1) of the GPU output against it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_RAY = 57.56e6          # forward, S = 64
+PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+N_RAYS, N_SAMPLES, IM_SZ = 4096, 64, 64
+
+
+def make_workload(dev, seed):
+    """One synthetic object: rays of a 64x64 grid over its roi, shared stratified depths, codes, decoder weights."""
+    import supnerf_amd as A
+    from supnerf_amd import synthetic as O
+    params = O.init_decoder_params(seed=0)
+    model = A.CodeNeRF(shape_blocks=3, texture_blocks=1)
+    model.load_state_dict(params)
+    model = model.to(dev)
+    ob = O.synthetic_object(seed)
+    img, mask = O.synthetic_targets(seed, IM_SZ)
+    gen = torch.Generator().manual_seed(seed)
+    sc = (torch.randn(1, 256, generator=gen) * 0.3).to(dev)
+    tc = (torch.randn(1, 256, generator=gen) * 0.3).to(dev)
+    jit = torch.rand(N_SAMPLES, generator=gen)
+    return dict(model=model, params=params, ob=ob, img=img, mask=mask, sc=sc, tc=tc, jit=jit)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+
+    import supnerf_amd as A
+    from supnerf_amd import ops, utils as U
+    w = make_workload(dev, seed=100 + rank)
+    model, ob = w["model"], w["ob"]
+
+    # ---- device-resident inputs of the hot path (ray generation is outside the path's timed region: it is part of the
+    # caller-side glue and costs microseconds)
+    with torch.no_grad():
+        rays_o, viewdir = U.get_rays(ob["K"], ob["cam_pose"].to(dev), ob["roi"], uv_steps=[IM_SZ, IM_SZ])
+        near, far = U._sphere_bounds(ob["cam_pose"], ob["obj_diag"])
+        z = U._shared_depths(near, far, N_SAMPLES, dev, jitter=w["jit"])
+        lat = model.latent_terms(w["sc"], w["tc"])
+    packed = model.packed_weights()
+    div = torch.full((1,), float(ob["obj_diag"]), device=dev)
+    cfg = ops.RenderCfg(N_SAMPLES, ops.Z_SHARED, N_RAYS, 3, 1, frame=U._frame(False, False, True))
+    assert rays_o.shape[0] == N_RAYS
+
+    def step():
+        return ops.render_fwd(rays_o, viewdir, z, div, None, lat, packed, cfg)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * N_RAYS * args.steps / elapsed
+
+    # ---- kernel time from device events on the launch stream (torch's current stream IS the launch stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(args.steps):
+        out = step()
+    e1.record()
+    torch.cuda.synchronize()
+    kern_ms = e0.elapsed_time(e1) / args.steps
+    achieved = N_RAYS * FLOP_PER_RAY / (kern_ms * 1e-3) / 1e12
+
+    # ---- forward + backward leg (the optimiser's inner iteration: gradients wrt codes and pose)
+    sc_g, tc_g = w["sc"].clone().requires_grad_(), w["tc"].clone().requires_grad_()
+    pose_g = ob["cam_pose"].to(dev).requires_grad_()
+    tgt = w["img"].reshape(-1, 3).to(dev)
+
+    def step_fb():
+        ro, vd = U.get_rays(ob["K"], pose_g, ob["roi"], uv_steps=[IM_SZ, IM_SZ])
+        rgb, depth, acc = model.fused_render(ro, vd, z, div, None, sc_g, tc_g, cfg)
+        loss = ((rgb - tgt) ** 2).mean() + 0.1 * acc.mean()
+        sc_g.grad = tc_g.grad = pose_g.grad = None
+        loss.backward()
+
+    for _ in range(3):
+        step_fb()
+    barrier()
+    n_fb = max(10, args.steps // 4)
+    t0 = time.perf_counter()
+    for _ in range(n_fb):
+        step_fb()
+    barrier()
+    fb_elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([fb_elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        fb_elapsed = float(t.item())
+    fwd_bwd_rays = world * N_RAYS * n_fb / fb_elapsed
+
+    result = {
+        "metric": "rays/sec at 4096 rays x 64 samples (fused render forward)",
+        "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "supnerf.nusc.vehicle.car.json decoder (shape_blocks 3, texture_blocks 1, W 256), 1 object per GPU, "
+                               "4096 rays x 64 samples, family-A render (render_rays_v2 tail), fp32 MFMA",
+                   "rays": N_RAYS, "samples": N_SAMPLES, "objects_per_gpu": 1, "sharding": "objects across ranks, no data-path collective"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                     "kernel": "decoder_fwd_kernel<1>", "kernel_ms": kern_ms, "flop_per_launch": N_RAYS * FLOP_PER_RAY},
+        "extra": {"fwd_bwd_rays_per_s": fwd_bwd_rays, "fwd_bwd_ms_per_iter": fb_elapsed / n_fb * 1e3,
+                  "fwd_bwd_note": "forward + backward to shape/texture codes and camera pose, incl. ray generation and loss in torch"},
+    }
+
+    # ---- CPU baseline + parity (rank 0, N = 1 only): the oracle is the checker and the baseline, never the product
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import supnerf_oracle as O
+        # the box's CPU share for one GPU is 16 cores whatever os.cpu_count() says; more threads only thrash
+        cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+        torch.set_num_threads(cores)
+        n_cpu = 1024                       # a quarter of the workload: same rays, same codes, same weights
+        ro_c, vd_c, z_c = rays_o[:n_cpu].cpu(), viewdir[:n_cpu].cpu(), z.cpu()
+        sc_c, tc_c = w["sc"].cpu(), w["tc"].cpu()
+
+        def cpu_pass():
+            with torch.no_grad():
+                xyz, vd = O.points_on_rays(ro_c, vd_c, z_c)
+                xyz = xyz / ob["obj_diag"]
+                xyz, vd = O.object_frame_transforms(xyz, vd, False, False, True)
+                sig, rgb = O.decoder_forward(w["params"], xyz, vd, sc_c, tc_c)
+                return O.volume_rendering2(sig, rgb, z_c)
+        ref = cpu_pass()
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 3 or (time.perf_counter() - t_start < 10 and len(times) < 30):
+            t0 = time.perf_counter(); ref = cpu_pass(); times.append(time.perf_counter() - t0)
+        cpu_rays = n_cpu / float(np.median(times))
+        rgb_g, depth_g, acc_g = [t[:n_cpu].cpu() for t in out[:3]]
+        tgt_c, occ_c = w["img"].reshape(-1, 3)[:n_cpu], w["mask"].reshape(-1, 1)[:n_cpu]
+        fg = occ_c.clone(); fg[occ_c < 0] = 0
+        ps = lambda rgb: float(-10 * torch.log10(((rgb - tgt_c) ** 2 * fg).sum() / (fg.sum() + 1e-9)))
+        result["cpu_baseline"] = {"value": cpu_rays, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": f"{n_cpu} of the 4096 rays x 64 samples, forward, oracle/supnerf_oracle.py "
+                                            f"(PyTorch {torch.__version__} CPU), median of {len(times)} passes"}
+        result["parity"] = {"psnr_delta_db": abs(ps(rgb_g) - ps(ref[0])), "depth_l1_mean_m": float((depth_g - ref[1]).abs().mean()),
+                            "rgb_max_abs": float((rgb_g - ref[0]).abs().max()), "acc_max_abs": float((acc_g - ref[2]).abs().max()),
+                            "bound": "north_star: PSNR delta <= 0.01 dB, depth L1 <= 1e-4"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -89,7 +89,7 @@ int snr_decoder_fwd(const float* xyz, const float* viewdir, const float* latent,
                     float* sigmas, float* rgbs, void* relu_masks, void* stream);
 /* gradients wrt latent (B,NLAT,256), xyz (P,3), viewdir (P,3) [each nullable] given d_sigmas (P)
  * and d_rgbs (P,3).  workspace: snr_decoder_bwd_ws_bytes(). */
-size_t snr_decoder_bwd_ws_bytes(int64_t n_points, int shape_blocks, int texture_blocks);
+size_t snr_decoder_bwd_ws_bytes(int64_t n_points, int64_t points_per_obj, int shape_blocks, int texture_blocks);
 int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent, const float* packed,
                     const void* relu_masks, const float* sigmas, const float* d_sigmas, const float* d_rgbs,
                     int64_t n_points, int64_t points_per_obj, int shape_blocks, int texture_blocks,

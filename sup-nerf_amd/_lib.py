@@ -36,7 +36,7 @@ _SIGS = {
     "snr_unpack_weight_grads": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.c_int, _P]),
     "snr_mask_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "snr_decoder_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P]),
-    "snr_decoder_bwd_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "snr_decoder_bwd_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "snr_decoder_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P,
                                   C.c_size_t, _P]),
     "snr_render_fwd": (C.c_int, [C.POINTER(RenderArgs), _P, _P, _P, _P, _P, _P, _P]),

@@ -158,21 +158,27 @@ __global__ void encode_dir_kernel(RayGeom g, float* __restrict__ pe_dir) {
 }
 
 // ============================================================================ backward reductions
-// d_latent[obj][j][k] = sum over the object's wave tiles of partial[tile][j][k]
-__global__ void reduce_latent_kernel(const float* __restrict__ partial, long long tiles_per_obj, int n_lat,
-                                     float* __restrict__ d_latent) {
-    const int obj = blockIdx.y;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over n_lat*256
-    if (idx >= n_lat * 256) return;
-    const float* p = partial + (long long)obj * tiles_per_obj * n_lat * 256 + idx;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    long long t = 0;
-    const long long stride = (long long)n_lat * 256;
-    for (; t + 3 < tiles_per_obj; t += 4) {
-        s0 += p[t * stride]; s1 += p[(t + 1) * stride]; s2 += p[(t + 2) * stride]; s3 += p[(t + 3) * stride];
+// Sum per-tile partial latent gradients, deterministic tree: every block adds up to RED_CHUNK consecutive
+// tiles of one object for all n_lat*256 columns (float4 per thread, coalesced 1 KiB rows).
+//   in : [obj][tiles][cols]      out : [obj][ceil(tiles/RED_CHUNK)][cols]
+constexpr int RED_CHUNK = 32;
+__global__ void __launch_bounds__(256) reduce_tiles_kernel(const float* __restrict__ in, long long tiles, int cols, float* __restrict__ out) {
+    const long long n_chunks = (tiles + RED_CHUNK - 1) / RED_CHUNK;
+    const long long chunk = blockIdx.x, obj = blockIdx.y;
+    const long long t0 = chunk * RED_CHUNK;
+    const long long t1 = (t0 + RED_CHUNK < tiles) ? t0 + RED_CHUNK : tiles;
+    for (int c4 = threadIdx.x; c4 * 4 < cols; c4 += blockDim.x) {
+        const float* p = in + (obj * tiles + t0) * cols + c4 * 4;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        long long t = t0;
+        for (; t + 1 < t1; t += 2) {
+            s0 += *reinterpret_cast<const f32x4*>(p);
+            s1 += *reinterpret_cast<const f32x4*>(p + cols);
+            p += 2 * (long long)cols;
+        }
+        if (t < t1) s0 += *reinterpret_cast<const f32x4*>(p);
+        *reinterpret_cast<f32x4*>(out + (obj * n_chunks + chunk) * cols + c4 * 4) = s0 + s1;
     }
-    for (; t < tiles_per_obj; ++t) s0 += p[t * stride];
-    d_latent[(long long)obj * n_lat * 256 + idx] = (s0 + s1) + (s2 + s3);
 }
 
 }  // namespace snr
@@ -371,9 +377,29 @@ int snr_fill_geom_(const snr_render_args* a, snr::RayGeom* g, int need_model) {
     return SNR_OK;
 }
 
-int snr_launch_reduce_latent_(const float* partial, long long tiles_per_obj, int n_lat, long long n_obj, float* d_latent, void* stream) {
+// scratch needed behind the [obj][tiles][cols] partials for the reduction tree (floats)
+long long snr_reduce_scratch_floats_(long long tiles_per_obj, int n_lat, long long n_obj) {
+    const long long lvl1 = (tiles_per_obj + snr::RED_CHUNK - 1) / snr::RED_CHUNK;
+    const long long lvl2 = (lvl1 + snr::RED_CHUNK - 1) / snr::RED_CHUNK;
+    return (lvl1 + lvl2) * n_obj * n_lat * 256;
+}
+
+int snr_launch_reduce_latent_(const float* partial, float* scratch, long long tiles_per_obj, int n_lat, long long n_obj, float* d_latent,
+                              void* stream) {
     if (n_lat <= 0 || n_obj <= 0) return SNR_OK;
-    dim3 grid((unsigned)((n_lat * 256 + 255) / 256), (unsigned)n_obj);
-    snr::reduce_latent_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(partial, tiles_per_obj, n_lat, d_latent);
+    const int cols = n_lat * 256;
+    const long long lvl1 = (tiles_per_obj + snr::RED_CHUNK - 1) / snr::RED_CHUNK;
+    float* bufs[2] = {scratch, scratch + lvl1 * n_obj * cols};
+    const float* in = partial;
+    long long tiles = tiles_per_obj;
+    int which = 0;
+    while (true) {
+        const long long n_chunks = (tiles + snr::RED_CHUNK - 1) / snr::RED_CHUNK;
+        float* out = (n_chunks == 1) ? d_latent : bufs[which];
+        dim3 grid((unsigned)n_chunks, (unsigned)n_obj);
+        snr::reduce_tiles_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, tiles, cols, out);
+        if (n_chunks == 1) break;
+        in = out; tiles = n_chunks; which ^= 1;
+    }
     return snr_check_launch_();
 }

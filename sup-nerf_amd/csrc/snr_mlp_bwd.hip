@@ -362,16 +362,22 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
 
 using namespace snr;
 
-int snr_launch_reduce_latent_(const float* partial, long long tiles_per_obj, int n_lat, long long n_obj, float* d_latent, void* stream);
+int snr_launch_reduce_latent_(const float* partial, float* scratch, long long tiles_per_obj, int n_lat, long long n_obj, float* d_latent,
+                              void* stream);
+long long snr_reduce_scratch_floats_(long long tiles_per_obj, int n_lat, long long n_obj);
 
-static size_t bwd_ws_bytes(int64_t n_points, int sb, int tb) {
+// workspace = per-wave-tile partial latent gradients [tiles32][n_lat][256] + the reduction tree's scratch
+static size_t bwd_ws_bytes(int64_t n_points, int64_t points_per_obj, int sb, int tb) {
     const int64_t tiles = (n_points + 31) / 32;
-    return (size_t)(tiles * (int64_t)(sb + tb) * 256 * sizeof(float) + 256);
+    const int64_t ppo = points_per_obj > 0 ? points_per_obj : n_points;
+    const int64_t n_obj = ppo > 0 ? (n_points + ppo - 1) / ppo : 1;
+    const int64_t tree = snr_reduce_scratch_floats_((ppo + 31) / 32, sb + tb, n_obj);
+    return (size_t)((tiles * (int64_t)(sb + tb) * 256 + tree) * sizeof(float) + 256);
 }
 
 extern "C" {
 
-size_t snr_decoder_bwd_ws_bytes(int64_t n_points, int sb, int tb) { return bwd_ws_bytes(n_points, sb, tb); }
+size_t snr_decoder_bwd_ws_bytes(int64_t n_points, int64_t points_per_obj, int sb, int tb) { return bwd_ws_bytes(n_points, points_per_obj, sb, tb); }
 
 int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent, const float* packed, const void* relu_masks,
                     const float* sigmas, const float* d_sigmas, const float* d_rgbs, int64_t n_points, int64_t points_per_obj, int sb,
@@ -383,7 +389,7 @@ int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent,
     const bool want_lat = d_latent && (sb + tb) > 0;
     if (want_lat) {
         if (points_per_obj % 32) return SNR_E_UNSUPPORTED;   // a wave tile must not straddle two objects
-        if (!workspace || ws_bytes < bwd_ws_bytes(n_points, sb, tb)) return SNR_E_WORKSPACE;
+        if (!workspace || ws_bytes < bwd_ws_bytes(n_points, points_per_obj, sb, tb)) return SNR_E_WORKSPACE;
     }
     BwdIO io{};
     io.packed = packed; io.latent = latent; io.sb = sb; io.tb = tb; io.n_points = n_points; io.points_per_obj = points_per_obj;
@@ -396,13 +402,15 @@ int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent,
     decoder_bwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
     int rc = snr_check_launch_();
     if (rc != SNR_OK) return rc;
-    if (want_lat) return snr_launch_reduce_latent_(io.partial, points_per_obj / 32, sb + tb, n_points / points_per_obj, d_latent, stream_);
+    if (want_lat)
+        return snr_launch_reduce_latent_(io.partial, io.partial + ((n_points + 31) / 32) * (int64_t)(sb + tb) * 256, points_per_obj / 32, sb + tb,
+                                         n_points / points_per_obj, d_latent, stream_);
     return SNR_OK;
 }
 
 size_t snr_render_bwd_ws_bytes(const snr_render_args* a) {
     if (!a) return 0;
-    return bwd_ws_bytes(a->n_rays * (int64_t)a->n_samples, a->shape_blocks, a->texture_blocks);
+    return bwd_ws_bytes(a->n_rays * (int64_t)a->n_samples, a->rays_per_obj * (int64_t)a->n_samples, a->shape_blocks, a->texture_blocks);
 }
 
 int snr_render_bwd(const snr_render_args* a, const float* sigmas, const float* rgbs, const void* relu_masks, const float* d_rgb,
@@ -421,7 +429,7 @@ int snr_render_bwd(const snr_render_args* a, const float* sigmas, const float* r
     const bool want_lat = d_latent && (sb + tb) > 0;
     if (want_lat) {
         if (ppo % 32) return SNR_E_UNSUPPORTED;
-        if (!workspace || ws_bytes < bwd_ws_bytes(P, sb, tb)) return SNR_E_WORKSPACE;
+        if (!workspace || ws_bytes < bwd_ws_bytes(P, ppo, sb, tb)) return SNR_E_WORKSPACE;
     }
     BwdIO io{};
     io.packed = a->packed; io.latent = a->latent; io.sb = sb; io.tb = tb; io.n_points = P; io.points_per_obj = ppo;
@@ -434,7 +442,9 @@ int snr_render_bwd(const snr_render_args* a, const float* sigmas, const float* r
     decoder_bwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g);
     rc = snr_check_launch_();
     if (rc != SNR_OK) return rc;
-    if (want_lat) return snr_launch_reduce_latent_(io.partial, ppo / 32, sb + tb, a->n_rays / a->rays_per_obj, d_latent, stream_);
+    if (want_lat)
+        return snr_launch_reduce_latent_(io.partial, io.partial + ((P + 31) / 32) * (long long)(sb + tb) * 256, ppo / 32, sb + tb,
+                                         a->n_rays / a->rays_per_obj, d_latent, stream_);
     return SNR_OK;
 }
 

@@ -160,7 +160,7 @@ def decoder_bwd(xyz, viewdir, latent, packed, masks, sigmas, d_sig, d_rgb, shape
     d_latent = torch.empty_like(latent) if need_latent else None
     d_xyz = torch.empty_like(xyz) if need_xyz else None
     d_dir = torch.empty_like(viewdir) if need_dir else None
-    ws_bytes = _lib.lib().snr_decoder_bwd_ws_bytes(P, shape_blocks, texture_blocks)
+    ws_bytes = _lib.lib().snr_decoder_bwd_ws_bytes(P, P // B, shape_blocks, texture_blocks)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         check(_lib.lib().snr_decoder_bwd(_p(xyz), _p(viewdir), _p(latent), _p(packed), _p(masks), _p(sigmas), _p(_f32c(d_sig)),

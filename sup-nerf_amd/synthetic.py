@@ -1,0 +1,73 @@
+"""Synthetic "nuScenes car" workloads: seeded decoder weights, car-sized boxes at 8-35 m with
+a plausible camera, square rois, random targets with an elliptical occupancy mask.  No dataset or checkpoint is
+available offline, so bench.py, the driver and the tests all draw from here.  (The CPU oracle keeps an identical,
+independent copy so that it does not depend on the product package; tests/test_host_logic.py checks they agree.)"""
+import math
+
+import numpy as np
+import torch
+
+WLH_MEAN = np.array([1.94, 4.64, 1.71], dtype=np.float32)      # src/optimizer_nuscenes.py:27 of the reference
+WLH_STD = np.array([0.19, 0.46, 0.25], dtype=np.float32)
+NUSC_K = np.array([[1266.4, 0.0, 816.3], [0.0, 1266.4, 491.5], [0.0, 0.0, 1.0]], dtype=np.float32)
+KITTI_K = np.array([[721.5, 0.0, 609.6], [0.0, 721.5, 172.9], [0.0, 0.0, 1.0]], dtype=np.float32)
+
+
+def decoder_layer_shapes(shape_blocks=3, texture_blocks=1, W=256, latent_dim=256, d_xyz=63, d_dir=27):
+    """(name, n_out, n_in) in the reference's registration order (src/model_supnerf.py:184-199)."""
+    out = [("encoding_xyz.0", W, d_xyz)]
+    for j in range(1, shape_blocks + 1):
+        out += [(f"shape_latent_layer_{j}.0", W, latent_dim), (f"shape_layer_{j}.0", W, W)]
+    out += [("encoding_shape", W, W), ("sigma.0", 1, W), ("encoding_viewdir.0", W, W + d_dir)]
+    for j in range(1, texture_blocks + 1):
+        out += [(f"texture_latent_layer_{j}.0", W, latent_dim), (f"texture_layer_{j}.0", W, W)]
+    out += [("rgb.0", W // 2, W), ("rgb.2", 3, W // 2)]
+    return out
+
+
+def init_decoder_params(shape_blocks=3, texture_blocks=1, seed=0, sigma_bias=-2.0):
+    """nn.Linear default init, U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias, from one seeded generator;
+    the density-head bias is then set to ``sigma_bias`` so that alpha spans (0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+    for name, n_out, n_in in decoder_layer_shapes(shape_blocks, texture_blocks):
+        bound = 1.0 / math.sqrt(n_in)
+        p[name + ".weight"] = (torch.rand(n_out, n_in, generator=g) * 2 - 1) * bound
+        p[name + ".bias"] = (torch.rand(n_out, generator=g) * 2 - 1) * bound
+    if sigma_bias is not None:
+        p["sigma.0.bias"] = torch.full((1,), float(sigma_bias))
+    return p
+
+
+def synthetic_object(index, im_w=1600, im_h=900, K=NUSC_K):
+    """Deterministic in ``index``: dict(wlh, obj_diag, cam_pose (3,4) camera-in-object, K, roi int32[4])."""
+    rs = np.random.RandomState(1000 + index)
+    wlh = (WLH_MEAN + WLH_STD * rs.randn(3)).astype(np.float32)
+    diag = np.linalg.norm(wlh).astype(np.float32)
+    yaw = rs.uniform(-np.pi, np.pi)
+    depth = rs.uniform(8.0, 35.0)
+    lateral = rs.uniform(-0.25, 0.25) * depth
+    c, s = np.cos(yaw), np.sin(yaw)
+    R_obj = np.array([[c, -s, 0], [0, 0, -1], [s, c, 0]], dtype=np.float32)      # object axes in the camera frame
+    t_obj = np.array([lateral, 1.2, depth], dtype=np.float32)
+    R_c2o = R_obj.T
+    t_c2o = -R_c2o @ t_obj
+    cam_pose = torch.from_numpy(np.concatenate([R_c2o, t_c2o[:, None]], axis=1).astype(np.float32))
+    u = K[0, 0] * t_obj[0] / t_obj[2] + K[0, 2]
+    v = K[1, 1] * t_obj[1] / t_obj[2] + K[1, 2]
+    half = int(max(16, 0.36 * K[0, 0] * diag / depth))
+    x0 = int(np.clip(u - half, 0, im_w - 2 * half - 1))
+    y0 = int(np.clip(v - half, 0, im_h - 2 * half - 1))
+    roi = torch.tensor([x0, y0, x0 + 2 * half, y0 + 2 * half], dtype=torch.int32)
+    return dict(wlh=wlh, obj_diag=diag, cam_pose=cam_pose, K=torch.from_numpy(K.copy()), roi=roi)
+
+
+def synthetic_targets(index, im_sz):
+    """Target crop (im_sz,im_sz,3) in [0,1) and occupancy mask (im_sz,im_sz,1) in {-1,0,1} (ellipse, thin unknown rim)."""
+    g = torch.Generator().manual_seed(2000 + index)
+    img = torch.rand(im_sz, im_sz, 3, generator=g)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, im_sz), torch.linspace(-1, 1, im_sz), indexing="ij")
+    r = (xx / 0.8) ** 2 + (yy / 0.55) ** 2
+    mask = torch.where(r < 1.0, torch.ones_like(r), -torch.ones_like(r))
+    mask = torch.where((r >= 1.0) & (r < 1.3), torch.zeros_like(r), mask)
+    return img, mask[..., None]

@@ -1,0 +1,194 @@
+"""CPU tests of the host side: the C-ABI library loads and exports what the header declares, the host geometry
+matches the oracle, the product path refuses CPU tensors (no fallback), sharding / metric gather logic incl. a
+world_size-2 gloo run."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import supnerf_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import supnerf_amd
+    return supnerf_amd
+
+
+def test_library_exports_every_declared_symbol(amd):
+    hdr = open(os.path.join(ROOT, "include", "supnerf_hip.h")).read()
+    declared = set(re.findall(r"\b(snr_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(amd._lib.exported_symbols()), declared ^ set(amd._lib.exported_symbols())
+    lib = amd._lib.lib()                      # loads without a GPU; no compute call is made here
+    for s in declared:
+        assert hasattr(lib, s)
+    assert lib.snr_abi_version() == 1
+    assert lib.snr_packed_bytes(3, 1) == 3615264 and lib.snr_packed_bytes(9, 1) == 0
+    assert lib.snr_mask_bytes(262144, 3, 1) == 262144 // 32 * 7 * 1024
+
+
+def test_product_path_has_no_cpu_fallback(amd):
+    p = O.init_decoder_params()
+    with pytest.raises(amd.SnrError):
+        amd.ops.pack_weights(p, 3, 1)                      # CPU tensors
+    with pytest.raises(amd.SnrError):
+        amd.ops.composite_fwd(torch.rand(4, 8), torch.rand(4, 8, 3), torch.rand(8), amd.ops.Z_SHARED, False)
+    m = amd.CodeNeRF(3, 1)
+    with pytest.raises(amd.SnrError):
+        m(torch.rand(2, 4, 3), torch.rand(2, 4, 3), torch.rand(1, 256), torch.rand(1, 256))
+    with pytest.raises(amd.SnrError):
+        amd.CodeNeRF(3, 1, W=128)                          # unsupported width fails loudly
+
+
+def test_state_dict_names_match_reference(amd):
+    m = amd.CodeNeRF(shape_blocks=3, texture_blocks=1)
+    assert list(m.state_dict().keys()) == list(O.decoder_param_names(3, 1))
+    m.load_state_dict(O.init_decoder_params(), strict=True)
+    s = amd.SUPNeRF(shape_blocks=3, texture_blocks=1, pose_blocks=3, regress_blocks=3)
+    keys = list(s.state_dict().keys())
+    assert keys[:28] == list(O.decoder_param_names(3, 1)) and "out_delta_layer.weight" in keys and "pose_layer_0.0.weight" in keys
+    # pose head is stock torch
+    assert s.pose_update(torch.rand(2, 256), torch.rand(2, 16)).shape == (2, 6)
+
+
+def test_synthetic_matches_oracle_copy(amd):
+    a, b = amd.synthetic.init_decoder_params(), O.init_decoder_params()
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    for i in (0, 3, 17):
+        x, y = amd.synthetic.synthetic_object(i), O.synthetic_object(i)
+        assert torch.equal(x["cam_pose"], y["cam_pose"]) and torch.equal(x["roi"], y["roi"]) and x["obj_diag"] == y["obj_diag"]
+        assert all(torch.equal(p, q) for p, q in zip(amd.synthetic.synthetic_targets(i, 16), O.synthetic_targets(i, 16)))
+
+
+def test_rays_and_depths_match_oracle(amd, golden):
+    g = golden("rays")
+    U = amd.utils
+    o, d = U.get_rays(g["K"], g["cam_pose"], g["roi"], uv_steps=[8, 8])
+    assert torch.equal(o, g["rays_o"]) and torch.equal(d, g["viewdir"])
+    o, d = U.get_rays(g["K"], g["cam_pose"], g["roi_small"])
+    assert torch.equal(d, g["viewdir_small"])
+    o, d = U.get_rays_specified(g["K"], g["cam_pose"], g["x_vec"].numpy() + int(g["roi"][0]), g["y_vec"].numpy() + int(g["roi"][1]))
+    assert torch.equal(d, g["viewdir_spec"])
+    jit = torch.rand(64, generator=torch.Generator().manual_seed(1))
+    near, far = U._sphere_bounds(g["cam_pose"], np.float32(5.3))
+    assert torch.equal(U._shared_depths(near, far, 64, "cpu", jitter=jit), O.shared_depth_samples(*O.sphere_bounds(g["cam_pose"], np.float32(5.3)), 64, jit))
+    # tensor end points (device-side bounds, no host sync) agree with torch.linspace to fp32 round-off
+    a = U._linspace(torch.tensor(9.25), torch.tensor(14.5), 64, "cpu")
+    assert float((a - torch.linspace(9.25, 14.5, 64)).abs().max()) < 2e-6
+
+
+def test_frame_matrices(amd):
+    U = amd.utils
+    g = torch.Generator().manual_seed(0)
+    xyz, vd = torch.randn(5, 7, 3, generator=g), torch.randn(5, 7, 3, generator=g)
+    for flip in (False, True):
+        for kitti in (False, True):
+            for shapenet in (False, True):
+                m = torch.tensor(U._frame(flip, kitti, shapenet)).view(3, 3)
+                xo, vo = O.object_frame_transforms(xyz, vd, flip, kitti, shapenet)
+                assert torch.equal(xyz @ m.T, xo) and torch.equal(vd @ m.T, vo)
+
+
+def test_prepare_pixel_samples_cpu_and_resize(amd, golden):
+    g = golden("prepare_pixel_samples")
+    amd.utils.JITTER_OVERRIDE = g["jitter"]
+    try:
+        np.random.seed(9)
+        out = amd.utils.prepare_pixel_samples(g["img"], g["mask_occ"], g["cam_pose"], np.float32(g["obj_diag"]), g["K"], g["roi"], 20, 64,
+                                              1, 0, im_sz=8)
+    finally:
+        amd.utils.JITTER_OVERRIDE = None
+    for a, k in zip(out, ("xyz", "viewdir", "z_vals", "rgb_tgt", "occ")):
+        assert float((a - g[k]).abs().max()) < 2e-6, k
+    r = golden("resize_targets")
+    im, mk = amd.utils._resize(r["img"], r["mask_occ"], 8)
+    assert torch.equal(im.reshape(-1, 3), r["rgb_tgt"]) and torch.equal(mk.reshape(-1, 1), r["occ"])
+
+
+def test_box_bounds_match_oracle(amd, golden):
+    g = golden("render_b_hit")
+    ro, vd = O.pixel_rays(g["K"], g["cam_pose"], g["roi"], uv_steps=[8, 8])
+    wlh = g["wlh"].numpy()
+    diag = np.linalg.norm(wlh).astype(np.float32)
+    near, far, hit = amd.renderer._box_bounds(ro / (diag / 2), vd, wlh, diag)
+    assert torch.equal(hit, g["hit"].bool())
+    rend = amd.NeRFRenderer(n_samples=64)
+    amd.utils.JITTER_OVERRIDE = g["jitter"]
+    try:
+        xyz, vdir, z_vals, hit2 = rend.prepare_sampled_rays(ro, vd, wlh)        # CPU tensors: plain torch arithmetic
+    finally:
+        amd.utils.JITTER_OVERRIDE = None
+    assert float((z_vals - g["z_vals"]).abs().max()) < 1e-6
+    zi, zo, hm = amd.utils.ray_box_intersection_tensor(ro / (diag / 2), vd, -torch.tensor([wlh[1], wlh[0], wlh[2]]) / diag,
+                                                       torch.tensor([wlh[1], wlh[0], wlh[2]]) / diag)
+    assert torch.equal(hm, hit) and zi.shape[0] == int(hit.sum())
+    assert amd.utils.ray_box_intersection_tensor(torch.empty(0, 3), torch.empty(0, 3)) == (None, None, None)
+
+
+def test_rotation_helpers(amd):
+    D = amd.driver
+    g = torch.Generator().manual_seed(0)
+    v = torch.randn(64, 3, generator=g)
+    v = v / v.norm(dim=-1, keepdim=True) * (torch.rand(64, 1, generator=g) * 3.1)
+    R = D.axis_angle_to_matrix(v)
+    eye = torch.eye(3).expand(64, 3, 3)
+    assert float((R @ R.transpose(-1, -2) - eye).abs().max()) < 1e-5 and float((torch.linalg.det(R) - 1).abs().max()) < 1e-5
+    assert float((D.matrix_to_axis_angle(R) - v).abs().max()) < 2e-4
+    assert float(D.axis_angle_to_matrix(torch.zeros(3)).sub(torch.eye(3)).abs().max()) == 0
+    # against scipy (independent implementation)
+    from scipy.spatial.transform import Rotation
+    assert float((R - torch.from_numpy(Rotation.from_rotvec(v.numpy()).as_matrix()).float()).abs().max()) < 1e-5
+    assert float((D.rot_dist(R, R)).abs().max()) < 1e-3
+
+
+def test_shard_slices_cover_everything(amd):
+    D = amd.driver
+    for n in (0, 1, 7, 64, 65):
+        for w in (1, 2, 3, 8):
+            got = [i for r in range(w) for i in D.shard_slice(n, w, r)]
+            assert got == list(range(n))
+            sizes = [len(D.shard_slice(n, w, r)) for r in range(w)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_hpams_reader(amd, tmp_path):
+    h = amd.driver.load_hpams()
+    assert h["n_samples"] == 64 and h["optimize"]["num_opts"] == 100 and h["net_hyperparams"]["shape_blocks"] == 3
+    p = tmp_path / "c.json"
+    p.write_text('{"n_samples": 32, "optimize": {"num_opts": 5}}')
+    assert amd.driver.load_hpams(str(p))["n_samples"] == 32
+
+
+_GLOO_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+import supnerf_amd
+from supnerf_amd import driver as D
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+n = 5
+mine = list(D.shard_slice(n, 2, rank))
+rows = torch.tensor([[float(i), 10.0 * i + 1, 10.0 * i + 2] for i in mine]).reshape(len(mine), 3)
+out = D.gather_metric_rows(rows, torch.tensor(mine, dtype=torch.float32), n)
+exp = torch.tensor([[float(i), 10.0 * i + 1, 10.0 * i + 2] for i in range(n)])
+assert torch.equal(out, exp), (rank, out)
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_metric_gather_two_ranks_gloo(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
