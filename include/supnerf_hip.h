@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SNR_ABI_VERSION 1
+#define SNR_ABI_VERSION 2
 
 enum {
     SNR_OK = 0,
@@ -44,6 +44,13 @@ enum {
 
 /* how per-sample depths are laid out */
 enum { SNR_Z_SHARED = 0 /* (S,) */, SNR_Z_PER_OBJECT = 1 /* (B,S) */, SNR_Z_PER_RAY = 2 /* (N,S) */ };
+
+/* arithmetic of the decoder GEMMs.  SNR_FP32: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain.
+ * SNR_BF16X3: every operand split into bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate (relative operand
+ * error ~2^-17; 5x less matrix time).  SNR_BF16X3 needs shape_blocks + texture_blocks <= 4 and whole 32-point tiles per
+ * object; snr_precision_supported() tells. */
+enum { SNR_FP32 = 0, SNR_BF16X3 = 1 };
+int snr_precision_supported(int precision, int shape_blocks, int texture_blocks, int64_t points_per_obj);
 
 /* flags for the render / composite entry points */
 enum {
@@ -86,7 +93,7 @@ int snr_unpack_weight_grads(const float* packed_grad, float* const* tensors, int
 size_t snr_mask_bytes(int64_t n_points, int shape_blocks, int texture_blocks);
 int snr_decoder_fwd(const float* xyz, const float* viewdir, const float* latent, const float* packed,
                     int64_t n_points, int64_t points_per_obj, int shape_blocks, int texture_blocks,
-                    float* sigmas, float* rgbs, void* relu_masks, void* stream);
+                    float* sigmas, float* rgbs, void* relu_masks, int precision, void* stream);
 /* gradients wrt latent (B,NLAT,256), xyz (P,3), viewdir (P,3) [each nullable] given d_sigmas (P)
  * and d_rgbs (P,3).  workspace: snr_decoder_bwd_ws_bytes(). */
 size_t snr_decoder_bwd_ws_bytes(int64_t n_points, int64_t points_per_obj, int shape_blocks, int texture_blocks);
@@ -94,7 +101,7 @@ int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent,
                     const void* relu_masks, const float* sigmas, const float* d_sigmas, const float* d_rgbs,
                     int64_t n_points, int64_t points_per_obj, int shape_blocks, int texture_blocks,
                     float* d_latent, float* d_xyz, float* d_viewdir,
-                    void* workspace, size_t ws_bytes, void* stream);
+                    void* workspace, size_t ws_bytes, int precision, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused render: sample points on rays -> frame transform -> PE -> decoder -> composite.
@@ -128,7 +135,7 @@ typedef struct snr_render_args {
     int32_t n_samples;
     int32_t shape_blocks;
     int32_t texture_blocks;
-    int32_t reserved;
+    int32_t precision;      /* SNR_FP32 / SNR_BF16X3 */
 } snr_render_args;
 
 int snr_render_fwd(const snr_render_args* a, float* rgb, float* depth, float* acc_trans,

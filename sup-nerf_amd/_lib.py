@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libsupnerf_hip.so")
 
 Z_SHARED, Z_PER_OBJECT, Z_PER_RAY = 0, 1, 2
 WHITE_BKGD, METRIC_Z = 1, 2
+FP32, BF16X3 = 0, 1
 ERRORS = {-1: "SNR_E_ARG", -2: "SNR_E_SHAPE", -3: "SNR_E_WORKSPACE", -4: "SNR_E_LAUNCH", -5: "SNR_E_UNSUPPORTED"}
 
 
@@ -22,7 +23,7 @@ class RenderArgs(C.Structure):
                 ("z_scale", C.c_void_p), ("latent", C.c_void_p), ("packed", C.c_void_p),
                 ("frame", C.c_float * 9), ("xyz_mul", C.c_float), ("z_mode", C.c_int32), ("flags", C.c_int32),
                 ("n_rays", C.c_int64), ("rays_per_obj", C.c_int64), ("n_samples", C.c_int32),
-                ("shape_blocks", C.c_int32), ("texture_blocks", C.c_int32), ("reserved", C.c_int32)]
+                ("shape_blocks", C.c_int32), ("texture_blocks", C.c_int32), ("precision", C.c_int32)]
 
 
 _lib = None
@@ -35,10 +36,11 @@ _SIGS = {
     "snr_pack_weights": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, _P, _P]),
     "snr_unpack_weight_grads": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.c_int, _P]),
     "snr_mask_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
-    "snr_decoder_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "snr_precision_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64]),
+    "snr_decoder_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
     "snr_decoder_bwd_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "snr_decoder_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P,
-                                  C.c_size_t, _P]),
+                                  C.c_size_t, C.c_int, _P]),
     "snr_render_fwd": (C.c_int, [C.POINTER(RenderArgs), _P, _P, _P, _P, _P, _P, _P]),
     "snr_render_bwd_ws_bytes": (C.c_size_t, [C.POINTER(RenderArgs)]),
     "snr_render_bwd": (C.c_int, [C.POINTER(RenderArgs), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
@@ -65,7 +67,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)       # AttributeError if the header and the library disagree
             fn.restype, fn.argtypes = res, args
-        if l.snr_abi_version() != 1:
+        if l.snr_abi_version() != 2:
             raise SnrError("libsupnerf_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -186,6 +186,8 @@ __global__ void __launch_bounds__(256) reduce_tiles_kernel(const float* __restri
 using namespace snr;
 
 // ============================================================================ C ABI
+int snr_bf16_pack_(const float* const* W, int sb, int tb, float* packed, void* stream_);   // snr_bf16.hip
+
 extern "C" {
 
 int snr_abi_version(void) { return SNR_ABI_VERSION; }
@@ -274,6 +276,19 @@ int snr_pack_weights(const float* const* t, int n_tensors, int sb, int tb, float
     vec(Bp(i_sigma), 1, L.sigma_b, 4);
     vec(Wp(i_rgb2), 3 * 128, L.rgb2_w, 3 * 128);
     vec(Bp(i_rgb2), 3, L.rgb2_b, 4);
+    // ---- split-bf16 streams (same weights as hi/lo bf16 pairs, output-tile-major chunks)
+    {
+        const float* Wl[MAX_BLOCKS * 2 + 4];
+        int n = 0;
+        Wl[n++] = Wp(i_xyz);
+        for (int j = 0; j < sb; ++j) Wl[n++] = Wp(i_shape[j]);
+        Wl[n++] = Wp(i_encshape);
+        Wl[n++] = Wp(i_view);
+        for (int j = 0; j < tb; ++j) Wl[n++] = Wp(i_tex[j]);
+        Wl[n++] = Wp(i_rgb0);
+        int rc = snr_bf16_pack_(Wl, sb, tb, packed, stream_);
+        if (rc != SNR_OK) return rc;
+    }
     return snr_check_launch_();
 }
 

@@ -1,0 +1,845 @@
+// Split-bf16 ("bf16x3") variant of the fused decoder kernels for gfx950.
+//
+// Same mathematics and the same register-resident layer chain as the fp32 kernels (snr_mlp.hip), but every
+// fp32 operand is carried as hi = bf16(x), lo = bf16(x - hi) and every product as
+//      w*x  ~=  w_hi*x_hi + w_hi*x_lo + w_lo*x_hi            (fp32 accumulate, dropped term <= 2^-18 |w x|)
+// on v_mfma_f32_32x32x16_bf16: 3 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64 cycles (5.3x less matrix-pipe time)
+// at ~2^-17 relative operand error, two orders of magnitude inside the path's tolerance (PSNR 0.01 dB, depth 1e-4 m).
+//
+// Restructured around the 5x shorter matrix time:
+//   * weights are stored as the lane-linear LDS image [k16-step][tile][hi/lo][lane][8 bf16] -> A fragments are plain
+//     conflict-free ds_read_b128 at immediate offsets; staging is LDS-DMA into a 3-deep ring with counted vmcnt
+//     (two 32 KiB chunks in flight across raw s_barriers);
+//   * TWO accumulator sets (2 x 128 AGPRs) and ONE operand set (128 VGPRs): layer l+1 consumes operand step s =
+//     (tile s/2, half s%2) of layer l's finished accumulators, so layer l's epilogue (ReLU / mask / latent add /
+//     hi-lo split) is spread over layer l+1's steps and issued in the shadow of its MFMAs; an operand step is dead
+//     as soon as the layer has used it (k-outer order), so the next layer's operands overwrite it in place;
+//   * biases, latent terms and the two small heads are staged in LDS once, so no compiler-tracked global load
+//     drains the DMA queue inside the layer chain.
+// Limits of this variant (the fp32 kernels have none of them): shape_blocks + texture_blocks <= 4 and
+// whole 32-point wave tiles per object.
+#include "snr_mlp_core.hpp"
+#include "snr_host.hpp"
+
+namespace snr {
+namespace bf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct XOp { bf16x8 hi, lo; };       // one k16-step of a B operand: 8 VGPRs
+
+constexpr int NBUF = 3;
+constexpr int WB_BYTES = BF_CHUNK_VIEW;                    // 36864
+constexpr int MAX_LAYERS = 8;                              // sb + tb + 4
+constexpr int MAX_LAT = 4;
+// LDS map (bytes)
+constexpr int OFF_VEC = NBUF * WB_BYTES;                   // bias[8][256] | sigma_w[256] | rgb2_w[384] | sigma_b, rgb2_b[3], pad
+constexpr int VEC_BIAS = 0, VEC_SIGW = MAX_LAYERS * 256, VEC_RGBW = VEC_SIGW + 256, VEC_MISC = VEC_RGBW + 384;
+constexpr int VEC_ZERO = VEC_MISC + 8;                     // 256 zeros: "no latent term" / "no density head" without a branch
+constexpr int VEC_FLOATS = VEC_ZERO + 256;
+constexpr int OFF_LAT = OFF_VEC + VEC_FLOATS * 4;          // [4 waves][MAX_LAT][256] f32
+constexpr int OFF_COMP = OFF_LAT + 4 * MAX_LAT * 256 * 4;  // 128 points x 8 floats
+constexpr int OFF_XDIR = OFF_COMP + 128 * COMP_STRIDE * 4; // direction operand steps: [wave][step 2][plane 2][lane 64] x 16 B
+constexpr int LDS_BYTES = OFF_XDIR + 4 * 4 * 1024;
+constexpr int PE_ROWF = 65;                                // floats per point row of the PE scratch (aliases ring buffer 2)
+constexpr int OFF_PE = 2 * WB_BYTES;
+static_assert(4 * 32 * PE_ROWF * 4 <= WB_BYTES, "PE scratch must fit in one ring buffer");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(OFF_LAT % 16 == 0 && OFF_COMP % 16 == 0, "alignment");
+
+// ------------------------------------------------------------------------------------------ weight ring
+struct Ring {
+    const char* next;     // global address of the next chunk to fetch
+    int ci;               // index of the next chunk to consume
+    int total;            // chunks in the stream
+    int view0;            // first of the 8 backward enc_viewdir^T chunks (36 KiB each); negative = none
+    int use, fill;        // ring buffer holding chunk ci / receiving the next fetched chunk
+    unsigned wave_lds;    // wave id * 1024 (SGPR): this wave's 1 KiB slice inside every 4 KiB DMA row
+};
+__device__ __forceinline__ int ring_bytes(const Ring& r, int i) { return (i >= r.view0 && i < r.view0 + 8) ? BF_CHUNK_VIEW : BF_CHUNK; }
+
+// LDS-DMA of one chunk, 4 KiB per workgroup-instruction.  Issued through inline asm on purpose: hipcc then does not
+// track these loads, so it cannot put a vmcnt(0) in front of the next ds_read "that might alias" (which would drain the
+// two-chunk prefetch every step); completion is counted by hand in ring_acquire (vmcnt(N) + s_barrier before the reads).
+// M0 (LDS destination base, wave-uniform) is written and restored inside the statement that uses it.
+__device__ __forceinline__ void ring_dma(const Ring& r, const char* g, char* lds, int bytes, int tid) {
+    const int n = bytes >> 12;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + r.wave_lds;
+    const unsigned voff = threadIdx.x * 16u;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        if (i < n) {
+            unsigned keep;
+            const char* gi = g + i * 4096;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + i * 4096u);
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(gi), "s"(dst) : "memory");
+        }
+}
+
+// prologue: chunks 0 and 1 in flight
+__device__ __forceinline__ void ring_start(Ring& r, const char* stream, int total, int view0, char* lds, int tid) {
+    r.next = stream; r.ci = 0; r.total = total; r.view0 = view0; r.use = 0; r.fill = 2 % NBUF;
+    r.wave_lds = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 1024u);
+    for (int i = 0; i < 2 && i < total; ++i) {
+        const int b = ring_bytes(r, i);
+        ring_dma(r, r.next, lds + i * WB_BYTES, b, tid);
+        r.next += b;
+    }
+}
+
+// Wait for chunk ci (leaving chunk ci+1 in flight), rendezvous, start fetching chunk ci+2 into the buffer chunk
+// ci-1 just vacated.  Returns the LDS address of chunk ci.
+__device__ __forceinline__ const char* ring_acquire(Ring& r, char* lds, int tid) {
+    // every chunk is issued as 8 (32 KiB) or 9 (36 KiB) DMA instructions per wave; leaving the 8 youngest in flight
+    // retires chunk ci completely (and at most one instruction of a 36 KiB chunk ci+1)
+    if (r.ci + 1 < r.total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (r.ci + 2 < r.total) {
+        const int b = ring_bytes(r, r.ci + 2);
+        ring_dma(r, r.next, lds + r.fill * WB_BYTES, b, tid);
+        r.next += b;
+        r.fill = (r.fill == NBUF - 1) ? 0 : r.fill + 1;
+    }
+    const char* p = lds + r.use * WB_BYTES;
+    r.use = (r.use == NBUF - 1) ? 0 : r.use + 1;
+    r.ci += 1;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------ matrix core
+// Layer image in the stream: [k16-step s][output tile t][plane hi/lo][lane][8 bf16]; a chunk = a few whole steps.
+// One step: acc[t] += W_t[:, 16s..16s+15] * x   for t < NT, three split products each.
+template <int NT, int NA>
+__device__ __forceinline__ void step_mma(f32x16 (&acc)[NA], const XOp& x, const char* ws /* chunk + step offset + lane*16 */) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + (2 * t) * 1024);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ws + (2 * t + 1) * 1024);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x.hi, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x.lo, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, x.hi, acc[t], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void split_store(float v, XOp& o, int j) {
+    const __bf16 hi = (__bf16)v;
+    o.hi[j] = hi;
+    o.lo[j] = (__bf16)(v - (float)hi);
+}
+
+template <int NT, int NA>
+__device__ __forceinline__ void acc_bias(f32x16 (&acc)[NA], const float* __restrict__ bias /*LDS*/, int h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 32 * t + 8 * j + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * j + e] = b[e];
+        }
+}
+template <int NT, int NA>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[NA]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+}
+
+// What happens to a finished accumulator tile of the PREVIOUS layer on its way to becoming operand step s of the
+// current layer (s = 2*tile + half: registers 8*half .. 8*half+7 of the tile).
+struct FwdEpi {
+    float floor;          // 0 for a ReLU layer, -inf for none:  v = max(v, floor)
+    const float* bias;    // LDS: bias of the layer that produced the accumulators
+    const float* zl;      // LDS: latent term added after the activation (a block of zeros if none)
+};
+// pin an operand step where it is produced: without this LLVM sinks the whole epilogue down to its use in the next
+// step (behind the barrier), which serialises it with that step's MFMAs instead of hiding it under this step's
+__device__ __forceinline__ void pin(XOp& o) { asm volatile("" : "+v"(o.hi), "+v"(o.lo)); }
+
+template <int T, int HALF>
+__device__ __forceinline__ void fwd_half_tile(const f32x16& acc, XOp& out, const FwdEpi& c, int h, uint32_t (&mask)[4]) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * HALF + jj;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(c.bias + 32 * T + 8 * j + 4 * h);
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(c.zl + 32 * T + 8 * j + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * j + e;
+            const float a = acc[r] + bv[e];
+            mask[T >> 1] |= (a > 0.f ? 1u : 0u) << ((T & 1) * 16 + r);      // only stored for ReLU layers
+            split_store(fmaxf(a, c.floor) + zv[e], out, r & 7);
+        }
+    }
+    pin(out);
+}
+
+// density head on finished enc_shape accumulators (+ its bias): this lane's share of w_sigma . y
+__device__ __forceinline__ float sigma_partial(const f32x16 (&acc)[8], const float* __restrict__ bias, const float* __restrict__ wsig, int h) {
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wsig + 32 * t + 8 * j + 4 * h);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * t + 8 * j + 4 * h);
+            d0 = fmaf(wv[0], acc[t][4 * j + 0] + bv[0], d0); d1 = fmaf(wv[1], acc[t][4 * j + 1] + bv[1], d1);
+            d2 = fmaf(wv[2], acc[t][4 * j + 2] + bv[2], d2); d3 = fmaf(wv[3], acc[t][4 * j + 3] + bv[3], d3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return (d0 + d1) + (d2 + d3);
+}
+
+// Step s of a layer whose operands come from the previous layer's accumulators: produce x[S+1] (if any) from accP
+// while the MFMAs of step S (operand x[S]) run.  Written as one straight block so the scheduler can interleave.
+template <int S, int NT>
+__device__ __forceinline__ void fwd_step(f32x16 (&accP)[8], f32x16 (&accC)[8], XOp (&x)[16], const char* ws, const FwdEpi& c, int h,
+                                         uint32_t (&mask)[4]) {
+    step_mma<NT, 8>(accC, x[S], ws);
+    if constexpr (S + 1 < 16) fwd_half_tile<((S + 1) >> 1), ((S + 1) & 1)>(accP[(S + 1) >> 1], x[S + 1], c, h, mask);
+    __builtin_amdgcn_sched_barrier(0);      // keep live ranges inside one step: nothing is hoisted across steps
+}
+
+// One layer with 16 operand steps taken from accP (+ 2 direction steps for enc_viewdir), NT output tiles into accC.
+template <int NT>
+__device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], XOp (&x)[16], const char* xdir_lds, Ring& ring, char* lds,
+                                          const FwdEpi& c, bool extra, uint32_t (&mask)[4], int tid, int lane) {
+    const int h = lane >> 5;
+    constexpr int SPC = (NT == 8) ? 2 : 4;            // steps per 32 KiB chunk
+    constexpr int STEP_BYTES = NT * 2 * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mask[i] = 0u;
+    acc_zero<NT, 8>(accC);
+    fwd_half_tile<0, 0>(accP[0], x[0], c, h, mask);
+    const char* w = nullptr;
+#define SNR_FSTEP(S)                                                                         \
+    if ((S) % SPC == 0) w = ring_acquire(ring, lds, tid) + lane * 16;                        \
+    fwd_step<S, NT>(accP, accC, x, w + ((S) % SPC) * STEP_BYTES, c, h, mask);
+    SNR_FSTEP(0) SNR_FSTEP(1) SNR_FSTEP(2) SNR_FSTEP(3) SNR_FSTEP(4) SNR_FSTEP(5) SNR_FSTEP(6) SNR_FSTEP(7)
+    SNR_FSTEP(8) SNR_FSTEP(9) SNR_FSTEP(10) SNR_FSTEP(11) SNR_FSTEP(12) SNR_FSTEP(13) SNR_FSTEP(14) SNR_FSTEP(15)
+#undef SNR_FSTEP
+    if (extra) {      // enc_viewdir: k = 256..287 are the direction features
+        w = ring_acquire(ring, lds, tid) + lane * 16;
+        XOp d0, d1;
+        d0.hi = *reinterpret_cast<const bf16x8*>(xdir_lds);        d0.lo = *reinterpret_cast<const bf16x8*>(xdir_lds + 1024);
+        d1.hi = *reinterpret_cast<const bf16x8*>(xdir_lds + 2048); d1.lo = *reinterpret_cast<const bf16x8*>(xdir_lds + 3072);
+        step_mma<NT, 8>(accC, d0, w);
+        step_mma<NT, 8>(accC, d1, w + STEP_BYTES);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward kernel
+template <int MODE>
+__global__ void __launch_bounds__(256, 1)
+bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom g,
+                float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_acc) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
+    const long long tile128 = blockIdx.x;
+    const long long tile32 = tile128 * 4 + wave;
+    const long long gp_raw = tile128 * 128 + wave * 32 + p;
+    const bool live = gp_raw < io.n_points;
+    const long long gp = live ? gp_raw : io.n_points - 1;
+    const int sb = io.sb, tb = io.tb;
+    const int n_relu = n_relu_layers(sb, tb);
+    const int li_encshape = sb + 1, li_view = sb + 2, li_last = sb + tb + 2;
+    float* vec = reinterpret_cast<float*>(lds + OFF_VEC);
+    float* latw = reinterpret_cast<float*>(lds + OFF_LAT) + wave * MAX_LAT * 256;
+
+    // ---- stage the small vectors and this wave's latent terms in LDS (plain loads, before any DMA is queued)
+    {
+        const float* src = io.packed + L.bias;
+        for (int i = tid; i < L.n_mfma_layers * 256; i += 256) vec[VEC_BIAS + i] = src[i];
+        vec[VEC_SIGW + tid] = io.packed[L.sigma_w + tid];
+        for (int i = tid; i < 384; i += 256) vec[VEC_RGBW + i] = io.packed[L.rgb2_w + i];
+        if (tid < 4) vec[VEC_MISC + tid] = io.packed[L.sigma_b + tid];
+        if (tid >= 4 && tid < 8) vec[VEC_MISC + tid] = io.packed[L.rgb2_b + tid - 4];
+        vec[VEC_ZERO + tid] = 0.f;
+        const long long first = tile32 * 32 < io.n_points ? tile32 * 32 : io.n_points - 1;
+        const float* ls = io.latent + (first / io.points_per_obj) * L.n_lat * 256;
+        for (int i = lane; i < L.n_lat * 256; i += 64) latw[i] = ls[i];
+    }
+    float px, py, pz, dx, dy, dz, zc = 0.f;
+    if (MODE == 0) {
+        px = xyz[gp * 3]; py = xyz[gp * 3 + 1]; pz = xyz[gp * 3 + 2];
+        dx = viewdir[gp * 3]; dy = viewdir[gp * 3 + 1]; dz = viewdir[gp * 3 + 2];
+    } else {
+        const long long ray = gp / g.S;
+        const SamplePoint sp = make_sample(g, ray, (int)(gp - ray * g.S));
+        px = sp.x; py = sp.y; pz = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc;
+        if (lane < 32) reinterpret_cast<float*>(lds + OFF_COMP)[(wave * 32 + p) * COMP_STRIDE + 4] = zc;
+    }
+    __syncthreads();
+
+    // ---- weight ring: chunks 0,1 in flight while the positional encodings are computed (scratch = ring buffer 2)
+    Ring ring;
+    const int total_chunks = 2 + 8 * (sb + 1) + 9 + 8 * tb + 4;
+    ring_start(ring, reinterpret_cast<const char*>(io.packed + L.bf_fwd), total_chunks, -100, lds, tid);
+
+    XOp x[16];
+    char* xdir = lds + OFF_XDIR + wave * 4096 + lane * 16;
+    {
+        float* sc = reinterpret_cast<float*>(lds + OFF_PE) + (wave * 32 + p) * PE_ROWF;      // rows are private to a wave
+#pragma unroll 1
+        for (int i = 0; i < 15; ++i) {
+            const int q = 15 * h + i;
+            float sn, cs;
+            sincosf(ldexpf(pick3(px, py, pz, q % 3), q / 3), &sn, &cs);
+            sc[3 + q] = sn; sc[3 + 3 * XYZ_FREQ + q] = cs;
+        }
+        if (h == 0) { sc[0] = px; sc[1] = py; sc[2] = pz; sc[63] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) split_store(sc[16 * s + 8 * (j >> 2) + 4 * h + (j & 3)], x[s], j);
+#pragma unroll 1
+        for (int i = 0; i < 6; ++i) {
+            const int q = 6 * h + i;
+            float sn, cs;
+            sincosf(ldexpf(pick3(dx, dy, dz, q % 3), q / 3), &sn, &cs);
+            sc[3 + q] = sn; sc[3 + 3 * DIR_FREQ + q] = cs;
+        }
+        if (h == 0) {
+            sc[0] = dx; sc[1] = dy; sc[2] = dz;
+#pragma unroll
+            for (int f = D_DIR; f < 32; ++f) sc[f] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            XOp d;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) split_store(sc[16 * s + 8 * (j >> 2) + 4 * h + (j & 3)], d, j);
+            *reinterpret_cast<bf16x8*>(xdir + s * 2048) = d.hi;
+            *reinterpret_cast<bf16x8*>(xdir + s * 2048 + 1024) = d.lo;
+        }
+    }
+
+    f32x16 accA[8], accB[8];
+    uint32_t mask[4];
+    float sig_dot = 0.f;
+
+    // ---- enc_xyz: 4 operand steps straight from the encoding -> accA
+    acc_zero<8, 8>(accA);
+    {
+        const char* w = ring_acquire(ring, lds, tid) + lane * 16;      // (its barrier also retires the scratch rows)
+        step_mma<8, 8>(accA, x[0], w);
+        step_mma<8, 8>(accA, x[1], w + 16 * 1024);
+        w = ring_acquire(ring, lds, tid) + lane * 16;
+        step_mma<8, 8>(accA, x[2], w);
+        step_mma<8, 8>(accA, x[3], w + 16 * 1024);
+    }
+
+    // ---- 256-wide layers: layer li consumes the accumulators of layer li-1 (epilogue fused into its steps)
+    auto epi_of = [&](int l) {     // epilogue configuration of MFMA layer l's output
+        FwdEpi c;
+        c.floor = (l != li_encshape) ? 0.f : -__builtin_inff();
+        c.bias = vec + VEC_BIAS + l * 256;
+        const int la = latent_after(l, sb, tb);
+        c.zl = la >= 0 ? latw + la * 256 : vec + VEC_ZERO;
+        return c;
+    };
+    auto store_mask = [&](int l) {   // ReLU bits of layer l (complete once the next layer has consumed all its tiles)
+        if (l != li_encshape && io.masks)
+            io.masks[(tile32 * n_relu + relu_slot(l, sb)) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
+    };
+    int li = 1;
+#pragma unroll 1
+    for (; li + 1 <= li_last; li += 2) {
+        layer_fwd<8>(accA, accB, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
+        store_mask(li - 1);
+        if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_BIAS + li * 256, vec + VEC_SIGW, h);
+        layer_fwd<8>(accB, accA, x, xdir, ring, lds, epi_of(li), li + 1 == li_view, mask, tid, lane);
+        store_mask(li);
+        if (li + 1 == li_encshape) sig_dot = sigma_partial(accA, vec + VEC_BIAS + (li + 1) * 256, vec + VEC_SIGW, h);
+    }
+    const bool odd_tail = (li == li_last);
+    if (odd_tail) {
+        layer_fwd<8>(accA, accB, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
+        store_mask(li - 1);
+        if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_BIAS + li * 256, vec + VEC_SIGW, h);
+    }
+    // ---- rgb.0: 256 -> 128 (4 tiles) from the last 256-wide layer's accumulators
+    if (odd_tail) layer_fwd<4>(accB, accA, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
+    else          layer_fwd<4>(accA, accB, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
+    store_mask(li_last);
+
+    // density head (enc_shape's output dotted with w_sigma inside the epilogues)
+    const float pre = sig_dot + __shfl_xor(sig_dot, 32, 64) + vec[VEC_MISC + 0];
+    const float o_sigma = pre > 20.f ? pre : log1pf(expf(pre));
+
+    // ---- colour head: ReLU(rgb.0) . W2 on the VALU
+    float pr = 0.f, pg = 0.f, pb = 0.f;
+    {
+        uint32_t mk[2] = {0u, 0u};
+        const float* w2 = vec + VEC_RGBW;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n0 = 32 * t + 8 * j + 4 * h;
+                const f32x4 wr = *reinterpret_cast<const f32x4*>(w2 + n0);
+                const f32x4 wg = *reinterpret_cast<const f32x4*>(w2 + 128 + n0);
+                const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + n0);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(vec + VEC_BIAS + (li_last + 1) * 256 + n0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = (odd_tail ? accA[t][4 * j + e] : accB[t][4 * j + e]) + bv[e];
+                    if (v > 0.f) mk[t >> 1] |= 1u << ((t & 1) * 16 + 4 * j + e);
+                    v = fmaxf(v, 0.f);
+                    pr = fmaf(wr[e], v, pr); pg = fmaf(wg[e], v, pg); pb = fmaf(wb[e], v, pb);
+                }
+            }
+        if (io.masks) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mk[0], mk[1], 0u, 0u);
+    }
+    const float cr = pr + __shfl_xor(pr, 32, 64) + vec[VEC_MISC + 4];
+    const float cg = pg + __shfl_xor(pg, 32, 64) + vec[VEC_MISC + 5];
+    const float cb = pb + __shfl_xor(pb, 32, 64) + vec[VEC_MISC + 6];
+
+    if (live && lane < 32) {
+        if (io.sigmas) io.sigmas[gp] = o_sigma;
+        if (io.rgbs) { io.rgbs[gp * 3] = cr; io.rgbs[gp * 3 + 1] = cg; io.rgbs[gp * 3 + 2] = cb; }
+    }
+    if (MODE == 1) {
+        float* comp = reinterpret_cast<float*>(lds + OFF_COMP);
+        if (lane < 32) {
+            float* c = comp + (wave * 32 + p) * COMP_STRIDE;
+            c[0] = o_sigma; c[1] = cr; c[2] = cg; c[3] = cb;      // c[4] = composite depth, parked there at the start
+        }
+        __syncthreads();
+        const int S = g.S;
+        const int rays_here = 128 / S;
+        const bool white = g.flags & SNR_WHITE_BKGD;
+        for (int r = wave; r < rays_here; r += 4) {
+            const long long ray = tile128 * rays_here + r;
+            if (ray >= g.n_rays) break;
+            const float* c0 = comp + r * S * COMP_STRIDE;
+            RayOut o = composite_ray_fwd(S, lane, white, [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
+                const float* c = c0 + k * COMP_STRIDE;
+                s_ = c[0]; r_ = c[1]; g_ = c[2]; b_ = c[3]; z_ = c[4];
+                zn_ = (k < S - 1) ? c[COMP_STRIDE + 4] : 0.f;
+            });
+            if (lane == 0) {
+                out_rgb[ray * 3] = o.r; out_rgb[ray * 3 + 1] = o.g; out_rgb[ray * 3 + 2] = o.b;
+                out_depth[ray] = o.depth; out_acc[ray] = o.acc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// Sum 16 accumulator registers over the 32 points of the wave (butterfly reduce-scatter, 16 shuffles) and store
+// the 32 feature totals of this tile.  dst points at the tile's 32 features.
+__device__ __forceinline__ void reduce_tile_store(const f32x16& acc, float* __restrict__ dst, int lane) {
+    const int p = lane & 31, h = lane >> 5;
+    float a8[8], a4[4], a2[2], a1;
+    {
+        const bool up = p & 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a8[i] = (up ? acc[i + 8] : acc[i]) + __shfl_xor(up ? acc[i] : acc[i + 8], 16, 64);
+    }
+    {
+        const bool up = p & 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a4[i] = (up ? a8[i + 4] : a8[i]) + __shfl_xor(up ? a8[i] : a8[i + 4], 8, 64);
+    }
+    {
+        const bool up = p & 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a2[i] = (up ? a4[i + 2] : a4[i]) + __shfl_xor(up ? a4[i] : a4[i + 2], 4, 64);
+    }
+    {
+        const bool up = p & 2;
+        a1 = (up ? a2[1] : a2[0]) + __shfl_xor(up ? a2[0] : a2[1], 2, 64);
+    }
+    a1 += __shfl_xor(a1, 1, 64);
+    const int r = (p >> 1) & 15;                 // 8 b4 + 4 b3 + 2 b2 + b1
+    if ((p & 1) == 0) dst[8 * (r >> 2) + 4 * h + (r & 3)] = a1;
+}
+
+// What happens to a finished gradient tile (wrt the input of the layer above = output of layer l [+ latent]):
+// per-object reduction for the latent gradient, layer l's ReLU bits, the density-head term below enc_shape.
+struct BwdEpi {
+    uint32_t m[4];        // ReLU bits of layer l (all ones when it has no activation)
+    const float* wsig;    // LDS: density-head weights below enc_shape (a block of zeros otherwise)
+    float dpre;           // d loss / d (pre-softplus density) of this lane's point
+    float* dz;            // global: this wave tile's partial latent gradient (256 floats), or null
+};
+template <int T, int HALF>
+__device__ __forceinline__ void bwd_half_tile(const f32x16& acc, XOp& out, const BwdEpi& c, int h, int lane) {
+    if (HALF == 0 && c.dz) reduce_tile_store(acc, c.dz + 32 * T, lane);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * HALF + jj;
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(c.wsig + 32 * T + 8 * j + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * j + e;
+            float v = fmaf(c.dpre, wv[e], acc[r]);
+            v = ((c.m[T >> 1] >> ((T & 1) * 16 + r)) & 1u) ? v : 0.f;
+            split_store(v, out, r & 7);
+        }
+    }
+    asm volatile("" : "+v"(out.hi), "+v"(out.lo));      // produced here, not sunk to its use (see pin() above)
+}
+
+// One transposed layer: 16 operand steps from accP, NT (+1 with `ninth`) output tiles into accC (+ acc9).
+template <int NT>
+__device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], f32x16& acc9, XOp (&x)[16], Ring& ring, char* lds,
+                                          const BwdEpi& c, bool ninth, int tid, int lane) {
+    const int h = lane >> 5;
+    constexpr int SPC = (NT == 8) ? 2 : 8;                  // steps per chunk (NT == 2: enc_xyz^T, 8 steps of 4 KiB)
+    const int step_bytes = (NT + (ninth ? 1 : 0)) * 2 * 1024;
+    acc_zero<NT, 8>(accC);
+    bwd_half_tile<0, 0>(accP[0], x[0], c, h, lane);
+    const char* w = nullptr;
+#define SNR_BSTEP(S)                                                                                      \
+    if ((S) % SPC == 0) w = ring_acquire(ring, lds, tid) + lane * 16;                                     \
+    {                                                                                                     \
+        const char* ws = w + ((S) % SPC) * step_bytes;                                                    \
+        step_mma<NT, 8>(accC, x[S], ws);                                                                  \
+        if (NT == 8 && ninth) {                                                                           \
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + 16 * 1024);                           \
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ws + 17 * 1024);                           \
+            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x[S].hi, acc9, 0, 0, 0);                   \
+            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x[S].lo, acc9, 0, 0, 0);                   \
+            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, x[S].hi, acc9, 0, 0, 0);                   \
+        }                                                                                                 \
+        if constexpr ((S) + 1 < 16) bwd_half_tile<(((S) + 1) >> 1), (((S) + 1) & 1)>(accP[((S) + 1) >> 1], x[(S) + 1], c, h, lane); \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
+    SNR_BSTEP(0) SNR_BSTEP(1) SNR_BSTEP(2) SNR_BSTEP(3) SNR_BSTEP(4) SNR_BSTEP(5) SNR_BSTEP(6) SNR_BSTEP(7)
+    SNR_BSTEP(8) SNR_BSTEP(9) SNR_BSTEP(10) SNR_BSTEP(11) SNR_BSTEP(12) SNR_BSTEP(13) SNR_BSTEP(14) SNR_BSTEP(15)
+#undef SNR_BSTEP
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 1)
+bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom g) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
+    const long long tile128 = blockIdx.x;
+    const long long tile32 = tile128 * 4 + wave;
+    const long long gp_raw = tile128 * 128 + wave * 32 + p;
+    const bool live = gp_raw < io.n_points;
+    const long long gp = live ? gp_raw : io.n_points - 1;
+    const int sb = io.sb, tb = io.tb;
+    const int n_relu = n_relu_layers(sb, tb);
+    const int li_encshape = sb + 1, li_view = sb + 2, li_last = sb + tb + 2;
+    float* vec = reinterpret_cast<float*>(lds + OFF_VEC);
+
+    // ---- everything that needs an ordinary global load happens before the DMA ring starts
+    vec[VEC_SIGW + tid] = io.packed[L.sigma_w + tid];
+    vec[VEC_ZERO + tid] = 0.f;
+    for (int i = tid; i < 384; i += 256) vec[VEC_RGBW + i] = io.packed[L.rgb2_w + i];
+    uint4 mk[MAX_LAYERS - 1];                                  // ReLU bits of every ReLU layer of this wave tile
+#pragma unroll
+    for (int s = 0; s < MAX_LAYERS - 1; ++s) mk[s] = (s < n_relu) ? io.masks[(tile32 * n_relu + s) * 64 + lane] : make_uint4(0, 0, 0, 0);
+    float px_, py_, pz_, dx, dy, dz, tval = 0.f, zc = 0.f;
+    long long ray = 0;
+    if (MODE == 0) {
+        px_ = xyz[gp * 3]; py_ = xyz[gp * 3 + 1]; pz_ = xyz[gp * 3 + 2];
+        dx = viewdir[gp * 3]; dy = viewdir[gp * 3 + 1]; dz = viewdir[gp * 3 + 2];
+    } else {
+        ray = gp / g.S;
+        const SamplePoint sp = make_sample(g, ray, (int)(gp - ray * g.S));
+        px_ = sp.x; py_ = sp.y; pz_ = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc; tval = sp.t;
+    }
+    float gs = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gzc = 0.f;
+    if (MODE == 0) {
+        if (live) {
+            gs = io.d_sigmas ? io.d_sigmas[gp] : 0.f;
+            if (io.d_rgbs) { gr = io.d_rgbs[gp * 3]; gg = io.d_rgbs[gp * 3 + 1]; gb = io.d_rgbs[gp * 3 + 2]; }
+        }
+    } else {
+        float* comp = reinterpret_cast<float*>(lds + OFF_COMP);
+        if (lane < 32) comp[(wave * 32 + p) * COMP_STRIDE + 5] = zc;
+        __syncthreads();
+        const int S = g.S;
+        const int rays_here = 128 / S;
+        const bool white = g.flags & SNR_WHITE_BKGD;
+        for (int r = wave; r < rays_here; r += 4) {
+            const long long rr = tile128 * rays_here + r;
+            if (rr >= g.n_rays) break;
+            float* c0 = comp + r * S * COMP_STRIDE;
+            const float* srow = io.sigmas + rr * S;
+            const float* crow = io.rgbs + rr * S * 3;
+            const float ur = io.d_rgb ? io.d_rgb[rr * 3] : 0.f, ug = io.d_rgb ? io.d_rgb[rr * 3 + 1] : 0.f,
+                        ub = io.d_rgb ? io.d_rgb[rr * 3 + 2] : 0.f;
+            const float ud = io.d_depth ? io.d_depth[rr] : 0.f, ua = io.d_acc ? io.d_acc[rr] : 0.f;
+            composite_ray_bwd<2>(S, lane, white, ur, ug, ub, ud, ua,
+                [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
+                    s_ = srow[k]; r_ = crow[3 * k]; g_ = crow[3 * k + 1]; b_ = crow[3 * k + 2];
+                    z_ = c0[k * COMP_STRIDE + 5];
+                    zn_ = (k < S - 1) ? c0[(k + 1) * COMP_STRIDE + 5] : 0.f;
+                },
+                [&](int k, float ds, float dcr, float dcg, float dcb, float dzz) {
+                    float* c = c0 + k * COMP_STRIDE;
+                    c[0] = ds; c[1] = dcr; c[2] = dcg; c[3] = dcb; c[4] = dzz;
+                });
+        }
+        __syncthreads();
+        if (live) {
+            const float* c = comp + (wave * 32 + p) * COMP_STRIDE;
+            gs = c[0]; gr = c[1]; gg = c[2]; gb = c[3]; gzc = c[4];
+        }
+    }
+    const float dpre = gs * (1.f - expf(-io.sigmas[gp]));
+    __syncthreads();
+
+    Ring ring;
+    const int total_chunks = 4 + 8 * tb + 8 + 8 * (sb + 1) + 2;
+    ring_start(ring, reinterpret_cast<const char*>(io.packed + L.bf_bwd), total_chunks, 4 + 8 * tb, lds, tid);   // enc_viewdir^T chunks are 36 KiB
+
+    XOp x[16];
+    auto mask_words = [&](int slot, uint32_t (&m)[4]) {        // runtime slot out of the register array (static unroll)
+        m[0] = m[1] = m[2] = m[3] = 0xffffffffu;
+#pragma unroll
+        for (int s = 0; s < MAX_LAYERS - 1; ++s) if (s == slot) { m[0] = mk[s].x; m[1] = mk[s].y; m[2] = mk[s].z; m[3] = mk[s].w; }
+    };
+    // ---- colour head backward on the VALU: g_h = W2^T d_rgb masked by rgb.0's ReLU -> 8 operand steps
+    {
+        uint32_t m[4];
+        mask_words(n_relu - 1, m);
+        const float* w2 = vec + VEC_RGBW;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n0 = 32 * t + 8 * j + 4 * h;
+                const f32x4 wr = *reinterpret_cast<const f32x4*>(w2 + n0);
+                const f32x4 wg = *reinterpret_cast<const f32x4*>(w2 + 128 + n0);
+                const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + n0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * j + e;
+                    float v = wr[e] * gr + wg[e] * gg + wb[e] * gb;
+                    v = ((m[t >> 1] >> ((t & 1) * 16 + r)) & 1u) ? v : 0.f;
+                    split_store(v, x[2 * t + (r >> 3)], r & 7);
+                }
+            }
+    }
+
+    f32x16 accA[8], accB[8], acc9;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc9[r] = 0.f;
+    // ---- rgb.0^T : K = 128 (8 steps) -> accA
+    acc_zero<8, 8>(accA);
+    {
+        const char* w = nullptr;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if ((s & 1) == 0) w = ring_acquire(ring, lds, tid) + lane * 16;
+            step_mma<8, 8>(accA, x[s], w + (s & 1) * 16 * 1024);
+        }
+    }
+
+    auto epi_of = [&](int l) {      // how the gradient wrt (output of layer l [+ latent]) becomes the operand of W_l^T
+        BwdEpi c;
+        mask_words(l == li_encshape ? -1 : relu_slot(l, sb), c.m);
+        c.wsig = (l == li_encshape) ? vec + VEC_SIGW : vec + VEC_ZERO;
+        c.dpre = (l == li_encshape) ? dpre : 0.f;
+        const int la = latent_after(l, sb, tb);
+        c.dz = (la >= 0 && io.partial) ? io.partial + (tile32 * L.n_lat + la) * 256 : nullptr;
+        return c;
+    };
+    int li = li_last;
+#pragma unroll 1
+    for (; li - 1 >= 1; li -= 2) {
+        layer_bwd<8>(accA, accB, acc9, x, ring, lds, epi_of(li), li == li_view, tid, lane);
+        layer_bwd<8>(accB, accA, acc9, x, ring, lds, epi_of(li - 1), li - 1 == li_view, tid, lane);
+    }
+    const bool odd_tail = (li == 1);
+    if (odd_tail) layer_bwd<8>(accA, accB, acc9, x, ring, lds, epi_of(1), 1 == li_view, tid, lane);
+    // ---- enc_xyz^T : 256 -> 64 positional-encoding features (two tiles, fp32)
+    if (odd_tail) layer_bwd<2>(accB, accA, acc9, x, ring, lds, epi_of(0), false, tid, lane);
+    else          layer_bwd<2>(accA, accB, acc9, x, ring, lds, epi_of(0), false, tid, lane);
+
+    // ---- positional-encoding backward through the scratch rows (the ring is idle now)
+    __syncthreads();
+    float* sc = reinterpret_cast<float*>(lds + OFF_PE) + (wave * 32 + p) * PE_ROWF;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        sc[8 * (r >> 2) + 4 * h + (r & 3)] = odd_tail ? accA[0][r] : accB[0][r];
+        sc[32 + 8 * (r >> 2) + 4 * h + (r & 3)] = odd_tail ? accA[1][r] : accB[1][r];
+    }
+    float gx = 0.f, gy = 0.f, gz = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < 15; ++i) {
+        const int q = 15 * h + i, a = q % 3, f = q / 3;
+        float sn, cs;
+        sincosf(ldexpf(pick3(px_, py_, pz_, a), f), &sn, &cs);
+        const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * XYZ_FREQ + q] * sn, f);
+        gx += a == 0 ? v : 0.f; gy += a == 1 ? v : 0.f; gz += a == 2 ? v : 0.f;
+    }
+    if (h == 0) { gx += sc[0]; gy += sc[1]; gz += sc[2]; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[8 * (r >> 2) + 4 * h + (r & 3)] = acc9[r];
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) {
+        const int q = 6 * h + i, a = q % 3, f = q / 3;
+        float sn, cs;
+        sincosf(ldexpf(pick3(dx, dy, dz, a), f), &sn, &cs);
+        const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * DIR_FREQ + q] * sn, f);
+        hx += a == 0 ? v : 0.f; hy += a == 1 ? v : 0.f; hz += a == 2 ? v : 0.f;
+    }
+    if (h == 0) { hx += sc[0]; hy += sc[1]; hz += sc[2]; }
+    gx += __shfl_xor(gx, 32, 64); gy += __shfl_xor(gy, 32, 64); gz += __shfl_xor(gz, 32, 64);
+    hx += __shfl_xor(hx, 32, 64); hy += __shfl_xor(hy, 32, 64); hz += __shfl_xor(hz, 32, 64);
+
+    if (MODE == 0) {
+        if (live && h == 0) {
+            if (io.d_xyz) { io.d_xyz[gp * 3] = gx; io.d_xyz[gp * 3 + 1] = gy; io.d_xyz[gp * 3 + 2] = gz; }
+            if (io.d_dir) { io.d_dir[gp * 3] = hx; io.d_dir[gp * 3 + 1] = hy; io.d_dir[gp * 3 + 2] = hz; }
+        }
+        return;
+    }
+    {
+        const long long obj = ray / g.rays_per_obj;
+        const float sc_ = g.xyz_mul / g.xyz_div[obj];
+        const float qx0 = (g.m[0] * gx + g.m[3] * gy + g.m[6] * gz) * sc_;
+        const float qy0 = (g.m[1] * gx + g.m[4] * gy + g.m[7] * gz) * sc_;
+        const float qz0 = (g.m[2] * gx + g.m[5] * gy + g.m[8] * gz) * sc_;
+        const float qx = g.m[0] * hx + g.m[3] * hy + g.m[6] * hz;
+        const float qy = g.m[1] * hx + g.m[4] * hy + g.m[7] * hz;
+        const float qz = g.m[2] * hx + g.m[5] * hy + g.m[8] * hz;
+        const float rdx = g.rays_d[ray * 3], rdy = g.rays_d[ray * 3 + 1], rdz = g.rays_d[ray * 3 + 2];
+        float c[6] = {qx0, qy0, qz0, tval * qx0 + qx, tval * qy0 + qy, tval * qz0 + qz};
+        float dt = rdx * qx0 + rdy * qy0 + rdz * qz0;
+        if (g.flags & SNR_METRIC_Z) {
+            const float zs = g.z_scale[obj];
+            const float k = zc > 0.f ? gzc * zs * zs * tval / zc : 0.f;
+            dt += k * (rdx * rdx + rdy * rdy + rdz * rdz);
+            c[3] += k * tval * rdx; c[4] += k * tval * rdy; c[5] += k * tval * rdz;
+        } else {
+            dt += gzc;
+        }
+        if (!(live && h == 0)) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) c[i] = 0.f;
+        }
+        if (io.d_t && live && h == 0) io.d_t[gp] = dt;
+        if (io.d_rays_o || io.d_rays_d) {
+            const int S = g.S;
+            const int G = S < 32 ? S : 32;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                for (int off = 1; off < G; off <<= 1) c[i] += __shfl_xor(c[i], off, 64);
+            if (S <= 32) {
+                if (live && h == 0 && (p % S) == 0) {
+                    if (io.d_rays_o) { io.d_rays_o[ray * 3] = c[0]; io.d_rays_o[ray * 3 + 1] = c[1]; io.d_rays_o[ray * 3 + 2] = c[2]; }
+                    if (io.d_rays_d) { io.d_rays_d[ray * 3] = c[3]; io.d_rays_d[ray * 3 + 1] = c[4]; io.d_rays_d[ray * 3 + 2] = c[5]; }
+                }
+            } else {
+                float* part = reinterpret_cast<float*>(lds + OFF_COMP);
+                __syncthreads();
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) part[wave * 8 + i] = c[i];
+                }
+                __syncthreads();
+                const int waves_per_ray = S / 32;
+                const int rays_here = 128 / S;
+                if (tid < rays_here * 6) {
+                    const int r = tid / 6, i = tid % 6;
+                    const long long rr = tile128 * rays_here + r;
+                    if (rr < g.n_rays) {
+                        float s = 0.f;
+                        for (int w = 0; w < waves_per_ray; ++w) s += part[(r * waves_per_ray + w) * 8 + i];
+                        float* dst = i < 3 ? io.d_rays_o : io.d_rays_d;
+                        if (dst) dst[rr * 3 + (i % 3)] = s;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ packing
+// One thread per (k16-step, tile, lane, j): writes the hi and the lo element of the layer image
+//   [s][tile][plane hi/lo][lane][8].
+//   forward  (transpose == 0): value = W[row][k]           row = output feature, k = input feature
+//   backward (transpose == 1): value = W[k][row]           row = input feature,  k = output feature
+__global__ void pack_bf16_kernel(const float* __restrict__ Wt, int n_out, int k_in, int transpose, int n_tiles, int KS,
+                                 __bf16* __restrict__ dst) {
+    const long long total = (long long)n_tiles * KS * 64 * 8;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        const int lane = (int)((i >> 3) & 63);
+        const int tile = (int)((i >> 9) % n_tiles);
+        const int s = (int)((i >> 9) / n_tiles);
+        const int row = 32 * tile + (lane & 31), hh = lane >> 5;
+        const int k = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+        float v = 0.f;
+        if (!transpose) { if (row < n_out && k < k_in) v = Wt[(long long)row * k_in + k]; }
+        else            { if (row < k_in && k < n_out) v = Wt[(long long)k * k_in + row]; }
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)hi);
+        const long long base = (((long long)s * n_tiles + tile) * 2) * 512;      // bf16 elements; plane stride 512
+        dst[base + lane * 8 + j] = hi;
+        dst[base + 512 + lane * 8 + j] = lo;
+    }
+}
+
+}  // namespace bf
+}  // namespace snr
+
+using namespace snr;
+
+// ---- host side ---------------------------------------------------------------------------------------------
+int snr_bf16_supported_(int sb, int tb, long long points_per_obj) {
+    return (sb + tb + 4 <= bf::MAX_LAYERS) && (sb + tb <= bf::MAX_LAT) && (points_per_obj % 32 == 0);
+}
+
+int snr_bf16_pack_(const float* const* W /* per-point weight tensors in MFMA-layer order */, int sb, int tb, float* packed, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    const Layout L = make_layout(sb, tb);
+    auto launch = [&](const float* w, int n_out, int k_in, int transpose, int n_tiles, int KS, __bf16* dst) {
+        const long long total = (long long)n_tiles * KS * 512;
+        int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+        bf::pack_bf16_kernel<<<grid, 256, 0, st>>>(w, n_out, k_in, transpose, n_tiles, KS, dst);
+    };
+    const int n_layers = sb + tb + 4;
+    // forward stream
+    char* f = reinterpret_cast<char*>(packed + L.bf_fwd);
+    for (int li = 0; li < n_layers; ++li) {
+        const bool is_xyz = li == 0, is_view = li == sb + 2, is_rgb0 = li == n_layers - 1;
+        const int n_out = is_rgb0 ? 128 : 256;
+        const int k_in = is_xyz ? D_XYZ : (is_view ? 256 + D_DIR : 256);
+        const int KS = is_xyz ? 4 : (is_view ? 18 : 16);
+        const int n_tiles = n_out / 32;
+        launch(W[li], n_out, k_in, 0, n_tiles, KS, reinterpret_cast<__bf16*>(f));
+        f += (long long)n_tiles * 2 * KS * 1024;
+    }
+    if (f - reinterpret_cast<char*>(packed + L.bf_fwd) != L.bf_fwd_bytes) return SNR_E_SHAPE;
+    // backward stream: rgb.0^T, texture^T (reverse), enc_viewdir^T, enc_shape^T, shape^T (reverse), enc_xyz^T
+    char* b = reinterpret_cast<char*>(packed + L.bf_bwd);
+    for (int li = n_layers - 1; li >= 0; --li) {
+        const bool is_xyz = li == 0, is_view = li == sb + 2, is_rgb0 = li == n_layers - 1;
+        const int n_out = is_rgb0 ? 128 : 256;
+        const int k_in = is_xyz ? D_XYZ : (is_view ? 256 + D_DIR : 256);
+        const int KS = n_out / 16;                                 // reduction over the layer's outputs
+        const int n_tiles = is_xyz ? 2 : (is_view ? 9 : 8);        // tiles of 32 input features
+        launch(W[li], n_out, k_in, 1, n_tiles, KS, reinterpret_cast<__bf16*>(b));
+        b += (long long)n_tiles * 2 * KS * 1024;
+    }
+    if (b - reinterpret_cast<char*>(packed + L.bf_bwd) != L.bf_bwd_bytes) return SNR_E_SHAPE;
+    return snr_check_launch_();
+}
+
+int snr_bf16_launch_fwd_(int mode, const DecoderIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
+                         float* depth, float* acc, void* stream_) {
+    const unsigned grid = (unsigned)((io.n_points + 127) / 128);
+    if (mode == 0) bf::bf16_fwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+    else bf::bf16_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+    return snr_check_launch_();
+}
+
+int snr_bf16_launch_bwd_(int mode, const BwdIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, void* stream_) {
+    const unsigned grid = (unsigned)((io.n_points + 127) / 128);
+    if (mode == 0) bf::bf16_bwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
+    else bf::bf16_bwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
+    return snr_check_launch_();
+}

@@ -43,9 +43,21 @@ struct Layout {
     int64_t sigma_b;     // 1 (padded to 4)
     int64_t rgb2_w;      // 3 x 128
     int64_t rgb2_b;      // 3 (padded to 4)
+    int64_t bf_fwd;      // split-bf16 forward stream (offset in floats; contents are bf16 pairs)
+    int64_t bf_bwd;      // split-bf16 backward stream
     int64_t total;       // floats
     int64_t fwd_floats, bwd_floats;
+    int64_t bf_fwd_bytes, bf_bwd_bytes;
 };
+
+// ---- split-bf16 ("bf16x3") streams -------------------------------------------------------------------
+// Every fp32 weight w is stored as hi = bf16(w), lo = bf16(w - hi).  A chunk holds the weights of TPC
+// 32-row output tiles for the layer's whole reduction depth K = 16*KS as the exact LDS image the kernel reads:
+//   [tile][plane hi/lo][k16-step s][lane 0..63][8 bf16]          (1 KiB per (plane, s): lane-linear)
+// where element j of lane (n = lane&31, h = lane>>5) is W[row 32*tile + n][k = 16 s + 8 (j>>2) + 4 h + (j&3)] --
+// the k order in which a 32x32 fp32 accumulator tile re-enters v_mfma_f32_32x32x16_bf16 as the B operand.
+constexpr int BF_CHUNK = 32768;          // bytes of every chunk except the forward enc_viewdir ones
+constexpr int BF_CHUNK_VIEW = 36864;     // 18 k16-steps
 
 SNR_HD inline Layout make_layout(int sb, int tb) {
     Layout L;
@@ -66,6 +78,13 @@ SNR_HD inline Layout make_layout(int sb, int tb) {
     L.sigma_b = o; o += 4;
     L.rgb2_w = o; o += 3 * 128;
     L.rgb2_b = o; o += 4;
+    // forward: enc_xyz 2 chunks (4 tiles each, K=64), 8 per 256-layer, 8 x enc_viewdir (K=288), rgb.0 4 chunks
+    L.bf_fwd_bytes = 2ll * BF_CHUNK + (int64_t)(sb + 1 + tb) * 8 * BF_CHUNK + 8ll * BF_CHUNK_VIEW + 4ll * BF_CHUNK;
+    // backward: rgb.0^T 4 chunks (2 tiles each, K=128), 8 per 256-layer, enc_viewdir^T 9 tiles, enc_xyz^T 2 tiles
+    L.bf_bwd_bytes = 4ll * BF_CHUNK + (int64_t)tb * 8 * BF_CHUNK + 9ll * BF_CHUNK + (int64_t)(sb + 1) * 8 * BF_CHUNK + 2ll * BF_CHUNK;
+    o = (o + 3) & ~3ll;                       // 16-byte alignment for the LDS-DMA source
+    L.bf_fwd = o; o += L.bf_fwd_bytes / 4;
+    L.bf_bwd = o; o += L.bf_bwd_bytes / 4;
     L.total = o;
     return L;
 }

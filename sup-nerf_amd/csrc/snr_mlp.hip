@@ -223,10 +223,21 @@ decoder_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const 
 
 using namespace snr;
 
+int snr_bf16_supported_(int sb, int tb, long long points_per_obj);
+int snr_bf16_launch_fwd_(int mode, const DecoderIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
+                         float* depth, float* acc, void* stream_);
+
 extern "C" {
 
+int snr_precision_supported(int precision, int sb, int tb, int64_t points_per_obj) {
+    if (sb < 0 || tb < 0 || sb > MAX_BLOCKS || tb > MAX_BLOCKS) return 0;
+    if (precision == SNR_FP32) return 1;
+    if (precision == SNR_BF16X3) return snr_bf16_supported_(sb, tb, points_per_obj);
+    return 0;
+}
+
 int snr_decoder_fwd(const float* xyz, const float* viewdir, const float* latent, const float* packed, int64_t n_points,
-                    int64_t points_per_obj, int sb, int tb, float* sigmas, float* rgbs, void* relu_masks, void* stream_) {
+                    int64_t points_per_obj, int sb, int tb, float* sigmas, float* rgbs, void* relu_masks, int precision, void* stream_) {
     if (!xyz || !viewdir || !latent || !packed) return SNR_E_ARG;
     if (sb < 0 || tb < 0 || sb > MAX_BLOCKS || tb > MAX_BLOCKS || n_points < 0) return SNR_E_ARG;
     if (points_per_obj < 1 || (n_points % points_per_obj) != 0) return SNR_E_SHAPE;
@@ -234,6 +245,11 @@ int snr_decoder_fwd(const float* xyz, const float* viewdir, const float* latent,
     DecoderIO io{packed, latent, sb, tb, (long long)n_points, (long long)points_per_obj, sigmas, rgbs, (uint4*)relu_masks};
     RayGeom g{};
     const Layout L = make_layout(sb, tb);
+    if (precision == SNR_BF16X3) {
+        if (!snr_bf16_supported_(sb, tb, points_per_obj)) return SNR_E_UNSUPPORTED;
+        return snr_bf16_launch_fwd_(0, io, L, xyz, viewdir, g, nullptr, nullptr, nullptr, stream_);
+    }
+    if (precision != SNR_FP32) return SNR_E_ARG;
     const unsigned grid = (unsigned)((n_points + 127) / 128);
     decoder_fwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g, nullptr, nullptr, nullptr);
     return snr_check_launch_();
@@ -251,6 +267,11 @@ int snr_render_fwd(const snr_render_args* a, float* rgb, float* depth, float* ac
     DecoderIO io{a->packed, a->latent, a->shape_blocks, a->texture_blocks, P, a->rays_per_obj * a->n_samples, sigmas, rgbs,
                  (uint4*)relu_masks};
     const Layout L = make_layout(a->shape_blocks, a->texture_blocks);
+    if (a->precision == SNR_BF16X3) {
+        if (!snr_bf16_supported_(a->shape_blocks, a->texture_blocks, a->rays_per_obj * a->n_samples)) return SNR_E_UNSUPPORTED;
+        return snr_bf16_launch_fwd_(1, io, L, nullptr, nullptr, g, rgb, depth, acc_trans, stream_);
+    }
+    if (a->precision != SNR_FP32) return SNR_E_ARG;
     const unsigned grid = (unsigned)((P + 127) / 128);
     decoder_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g, rgb, depth, acc_trans);
     return snr_check_launch_();

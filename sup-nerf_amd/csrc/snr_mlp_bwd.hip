@@ -17,28 +17,6 @@
 
 namespace snr {
 
-struct BwdIO {
-    const float* packed;
-    const float* latent;
-    int sb, tb;
-    long long n_points;
-    long long points_per_obj;
-    const uint4* masks;
-    const float* sigmas;     // (P) saved by the forward
-    const float* rgbs;       // (P,3) saved by the forward (render mode)
-    const float* d_sigmas;   // (P)   upstream, points mode
-    const float* d_rgbs;     // (P,3) upstream, points mode
-    const float* d_rgb;      // (N,3) upstream, render mode (nullable)
-    const float* d_depth;    // (N)
-    const float* d_acc;      // (N)
-    float* partial;          // [tiles32][n_lat][256] or null
-    float* d_xyz;            // (P,3) points mode, nullable
-    float* d_dir;            // (P,3) points mode, nullable
-    float* d_rays_o;         // (N,3) render mode, nullable
-    float* d_rays_d;         // (N,3)
-    float* d_t;              // (N,S) per-ray depths only
-};
-
 // accumulators -> operand registers with the saved ReLU bits applied (mask == nullptr: pass through);
 // `add` (nullable) is a per-feature vector scaled by `scale` added first (density-head path).
 template <int NT>
@@ -365,6 +343,8 @@ using namespace snr;
 int snr_launch_reduce_latent_(const float* partial, float* scratch, long long tiles_per_obj, int n_lat, long long n_obj, float* d_latent,
                               void* stream);
 long long snr_reduce_scratch_floats_(long long tiles_per_obj, int n_lat, long long n_obj);
+int snr_bf16_supported_(int sb, int tb, long long points_per_obj);
+int snr_bf16_launch_bwd_(int mode, const BwdIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, void* stream_);
 
 // workspace = per-wave-tile partial latent gradients [tiles32][n_lat][256] + the reduction tree's scratch
 static size_t bwd_ws_bytes(int64_t n_points, int64_t points_per_obj, int sb, int tb) {
@@ -381,7 +361,7 @@ size_t snr_decoder_bwd_ws_bytes(int64_t n_points, int64_t points_per_obj, int sb
 
 int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent, const float* packed, const void* relu_masks,
                     const float* sigmas, const float* d_sigmas, const float* d_rgbs, int64_t n_points, int64_t points_per_obj, int sb,
-                    int tb, float* d_latent, float* d_xyz, float* d_viewdir, void* workspace, size_t ws_bytes, void* stream_) {
+                    int tb, float* d_latent, float* d_xyz, float* d_viewdir, void* workspace, size_t ws_bytes, int precision, void* stream_) {
     if (n_points == 0) return SNR_OK;
     if (!xyz || !viewdir || !latent || !packed || !relu_masks || !sigmas) return SNR_E_ARG;
     if (sb < 0 || tb < 0 || sb > MAX_BLOCKS || tb > MAX_BLOCKS || n_points < 0) return SNR_E_ARG;
@@ -398,9 +378,15 @@ int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent,
     io.d_xyz = d_xyz; io.d_dir = d_viewdir;
     RayGeom g{};
     const Layout L = make_layout(sb, tb);
-    const unsigned grid = (unsigned)((n_points + 127) / 128);
-    decoder_bwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
-    int rc = snr_check_launch_();
+    int rc;
+    if (precision == SNR_BF16X3) {
+        if (!snr_bf16_supported_(sb, tb, points_per_obj)) return SNR_E_UNSUPPORTED;
+        rc = snr_bf16_launch_bwd_(0, io, L, xyz, viewdir, g, stream_);
+    } else if (precision == SNR_FP32) {
+        const unsigned grid = (unsigned)((n_points + 127) / 128);
+        decoder_bwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
+        rc = snr_check_launch_();
+    } else return SNR_E_ARG;
     if (rc != SNR_OK) return rc;
     if (want_lat)
         return snr_launch_reduce_latent_(io.partial, io.partial + ((n_points + 31) / 32) * (int64_t)(sb + tb) * 256, points_per_obj / 32, sb + tb,
@@ -438,9 +424,14 @@ int snr_render_bwd(const snr_render_args* a, const float* sigmas, const float* r
     io.partial = want_lat ? (float*)workspace : nullptr;
     io.d_rays_o = d_rays_o; io.d_rays_d = d_rays_d; io.d_t = d_t;
     const Layout L = make_layout(sb, tb);
-    const unsigned grid = (unsigned)((P + 127) / 128);
-    decoder_bwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g);
-    rc = snr_check_launch_();
+    if (a->precision == SNR_BF16X3) {
+        if (!snr_bf16_supported_(sb, tb, ppo)) return SNR_E_UNSUPPORTED;
+        rc = snr_bf16_launch_bwd_(1, io, L, nullptr, nullptr, g, stream_);
+    } else if (a->precision == SNR_FP32) {
+        const unsigned grid = (unsigned)((P + 127) / 128);
+        decoder_bwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g);
+        rc = snr_check_launch_();
+    } else return SNR_E_ARG;
     if (rc != SNR_OK) return rc;
     if (want_lat)
         return snr_launch_reduce_latent_(io.partial, io.partial + ((P + 31) / 32) * (long long)(sb + tb) * 256, ppo / 32, sb + tb,

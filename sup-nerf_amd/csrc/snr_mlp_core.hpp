@@ -136,4 +136,26 @@ struct DecoderIO {
     uint4* masks;             // optional
 };
 
+struct BwdIO {
+    const float* packed;
+    const float* latent;
+    int sb, tb;
+    long long n_points;
+    long long points_per_obj;
+    const uint4* masks;
+    const float* sigmas;     // (P) saved by the forward
+    const float* rgbs;       // (P,3) saved by the forward (render mode)
+    const float* d_sigmas;   // (P)   upstream, points mode
+    const float* d_rgbs;     // (P,3) upstream, points mode
+    const float* d_rgb;      // (N,3) upstream, render mode (nullable)
+    const float* d_depth;    // (N)
+    const float* d_acc;      // (N)
+    float* partial;          // [tiles32][n_lat][256] or null
+    float* d_xyz;            // (P,3) points mode, nullable
+    float* d_dir;            // (P,3) points mode, nullable
+    float* d_rays_o;         // (N,3) render mode, nullable
+    float* d_rays_d;         // (N,3)
+    float* d_t;              // (N,S) per-ray depths only
+};
+
 }  // namespace snr

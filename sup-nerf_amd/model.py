@@ -48,6 +48,8 @@ class _DecoderBase(nn.Module):
         self.rgb = nn.Sequential(nn.Linear(W, W // 2), nn.ReLU(), nn.Linear(W // 2, 3))
         self._packed = None
         self._packed_key = None
+        # arithmetic of the per-point GEMMs: "fp32" (exact), "bf16x3" (split-bf16) or "auto" (bf16x3 where supported)
+        self.precision = "auto"
 
     # ---- packed per-point weights, re-packed only when a tensor changed
     def _per_point_params(self):
@@ -82,12 +84,14 @@ class _DecoderBase(nn.Module):
         lead = xyz.shape[:-1]
         lat = self.latent_terms(shape_latent, texture_latent)
         sig, rgb = ops.DecoderPoints.apply(xyz.reshape(-1, 3), viewdir.reshape(-1, 3), lat, self.packed_weights(),
-                                           self.shape_blocks, self.texture_blocks)
+                                           self.shape_blocks, self.texture_blocks, self.precision)
         return sig.view(*lead, 1), rgb.view(*lead, 3)
 
     def fused_render(self, rays_o, rays_d, t_vals, xyz_div, z_scale, shape_latent, texture_latent, cfg: "ops.RenderCfg"):
         """rays -> (rgb (N,3), depth (N,), acc_trans (N,)) in one launch (see ops.FusedRender)."""
         lat = self.latent_terms(shape_latent, texture_latent)
+        if cfg.precision is None:
+            cfg.precision = self.precision
         return ops.FusedRender.apply(rays_o, rays_d, t_vals, xyz_div, z_scale, lat, self.packed_weights(), cfg)
 
 

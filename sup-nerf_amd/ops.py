@@ -8,9 +8,27 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import METRIC_Z, WHITE_BKGD, Z_PER_OBJECT, Z_PER_RAY, Z_SHARED, RenderArgs, SnrError, check
+from ._lib import BF16X3, FP32, METRIC_Z, WHITE_BKGD, Z_PER_OBJECT, Z_PER_RAY, Z_SHARED, RenderArgs, SnrError, check
 
 IDENTITY_FRAME = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
+PRECISIONS = {"fp32": FP32, "bf16x3": BF16X3}
+
+
+def resolve_precision(precision, shape_blocks, texture_blocks, points_per_obj) -> int:
+    """'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16, ~2^-17 operand error, several times faster) or 'auto'
+    (bf16x3 where the kernel supports the configuration, else fp32).  Asking for 'bf16x3' where it is unsupported raises."""
+    if isinstance(precision, int):
+        return precision
+    if precision == "auto":
+        ok = _lib.lib().snr_precision_supported(BF16X3, shape_blocks, texture_blocks, int(points_per_obj))
+        return BF16X3 if ok else FP32
+    if precision not in PRECISIONS:
+        raise SnrError(f"unknown precision {precision!r}")
+    code = PRECISIONS[precision]
+    if not _lib.lib().snr_precision_supported(code, shape_blocks, texture_blocks, int(points_per_obj)):
+        raise SnrError(f"precision {precision!r} is not available for shape_blocks={shape_blocks}, texture_blocks={texture_blocks}, "
+                       f"{points_per_obj} points per object (needs <= 4 blocks in total and whole 32-point tiles per object)")
+    return code
 
 
 def _need_gpu(*ts):
@@ -133,7 +151,7 @@ class Composite(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------ decoder on points
-def decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=False):
+def decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=False, precision="fp32"):
     """xyz, viewdir (P,3); latent (B,NLAT,256) -> sigmas (P,), rgbs (P,3)[, relu masks]."""
     xyz, viewdir, latent = _f32c(xyz), _f32c(viewdir), _f32c(latent)
     _need_gpu(xyz, viewdir, latent, packed)
@@ -149,12 +167,14 @@ def decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save
         masks = torch.empty(_lib.lib().snr_mask_bytes(P, shape_blocks, texture_blocks), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         check(_lib.lib().snr_decoder_fwd(_p(xyz), _p(viewdir), _p(latent), _p(packed), P, P // B if B else 1, shape_blocks,
-                                         texture_blocks, _p(sig), _p(rgb), _p(masks), _stream(dev)), "snr_decoder_fwd")
+                                         texture_blocks, _p(sig), _p(rgb), _p(masks),
+                                         resolve_precision(precision, shape_blocks, texture_blocks, P // B if B else 1), _stream(dev)),
+              "snr_decoder_fwd")
     return sig, rgb, masks
 
 
 def decoder_bwd(xyz, viewdir, latent, packed, masks, sigmas, d_sig, d_rgb, shape_blocks, texture_blocks,
-                need_latent=True, need_xyz=True, need_dir=True):
+                need_latent=True, need_xyz=True, need_dir=True, precision="fp32"):
     P, B = xyz.shape[0], latent.shape[0]
     dev = xyz.device
     d_latent = torch.empty_like(latent) if need_latent else None
@@ -165,7 +185,8 @@ def decoder_bwd(xyz, viewdir, latent, packed, masks, sigmas, d_sig, d_rgb, shape
     with torch.cuda.device(dev):
         check(_lib.lib().snr_decoder_bwd(_p(xyz), _p(viewdir), _p(latent), _p(packed), _p(masks), _p(sigmas), _p(_f32c(d_sig)),
                                          _p(_f32c(d_rgb)), P, P // B, shape_blocks, texture_blocks, _p(d_latent), _p(d_xyz),
-                                         _p(d_dir), _p(ws), ws_bytes, _stream(dev)), "snr_decoder_bwd")
+                                         _p(d_dir), _p(ws), ws_bytes, resolve_precision(precision, shape_blocks, texture_blocks, P // B),
+                                         _stream(dev)), "snr_decoder_bwd")
     return d_latent, d_xyz, d_dir
 
 
@@ -174,27 +195,28 @@ class DecoderPoints(torch.autograd.Function):
     treated as constants on this path)."""
 
     @staticmethod
-    def forward(ctx, xyz, viewdir, latent, packed, shape_blocks, texture_blocks):
+    def forward(ctx, xyz, viewdir, latent, packed, shape_blocks, texture_blocks, precision="fp32"):
         xyz, viewdir, latent = _f32c(xyz), _f32c(viewdir), _f32c(latent)
         need = any(ctx.needs_input_grad[:3])
-        sig, rgb, masks = decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=need)
+        prec = resolve_precision(precision, shape_blocks, texture_blocks, xyz.shape[0] // max(latent.shape[0], 1))
+        sig, rgb, masks = decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=need, precision=prec)
         if need:
             ctx.save_for_backward(xyz, viewdir, latent, packed, masks, sig)
-            ctx.cfg = (shape_blocks, texture_blocks)
+            ctx.cfg = (shape_blocks, texture_blocks, prec)
         return sig, rgb
 
     @staticmethod
     def backward(ctx, d_sig, d_rgb):
         xyz, viewdir, latent, packed, masks, sig = ctx.saved_tensors
-        sb, tb = ctx.cfg
+        sb, tb, prec = ctx.cfg
         d_lat, d_xyz, d_dir = decoder_bwd(xyz, viewdir, latent, packed, masks, sig, d_sig, d_rgb, sb, tb,
-                                          ctx.needs_input_grad[2], ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return d_xyz, d_dir, d_lat, None, None, None
+                                          ctx.needs_input_grad[2], ctx.needs_input_grad[0], ctx.needs_input_grad[1], precision=prec)
+        return d_xyz, d_dir, d_lat, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------ fused render
 def _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, frame, xyz_mul, z_mode, flags, rays_per_obj,
-                 n_samples, shape_blocks, texture_blocks):
+                 n_samples, shape_blocks, texture_blocks, precision=FP32):
     a = RenderArgs()
     a.rays_o, a.rays_d, a.t_vals = rays_o.data_ptr(), rays_d.data_ptr(), t_vals.data_ptr()
     a.xyz_div = xyz_div.data_ptr()
@@ -206,6 +228,7 @@ def _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, frame
     a.z_mode, a.flags = int(z_mode), int(flags)
     a.n_rays, a.rays_per_obj = int(rays_o.shape[0]), int(rays_per_obj)
     a.n_samples, a.shape_blocks, a.texture_blocks = int(n_samples), int(shape_blocks), int(texture_blocks)
+    a.precision = int(precision)
     return a
 
 
@@ -218,8 +241,9 @@ class RenderCfg:
     """Per-launch constants of the render operators (not tensors)."""
 
     def __init__(self, n_samples, z_mode, rays_per_obj, shape_blocks, texture_blocks, frame=IDENTITY_FRAME, xyz_mul=1.0,
-                 white_bkgd=False, metric_z=False):
+                 white_bkgd=False, metric_z=False, precision="fp32"):
         self.n_samples, self.z_mode, self.rays_per_obj = n_samples, z_mode, rays_per_obj
+        self.precision = precision
         self.shape_blocks, self.texture_blocks = shape_blocks, texture_blocks
         self.frame, self.xyz_mul = tuple(float(v) for v in frame), float(xyz_mul)
         self.flags = (WHITE_BKGD if white_bkgd else 0) | (METRIC_Z if metric_z else 0)
@@ -240,8 +264,9 @@ def render_fwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg: Re
         sig = torch.empty(N * S, device=dev)
         rgbs = torch.empty(N * S, 3, device=dev)
         masks = torch.empty(_lib.lib().snr_mask_bytes(N * S, cfg.shape_blocks, cfg.texture_blocks), dtype=torch.uint8, device=dev)
+    prec = resolve_precision(cfg.precision, cfg.shape_blocks, cfg.texture_blocks, cfg.rays_per_obj * S)
     a = _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg.frame, cfg.xyz_mul, cfg.z_mode, cfg.flags,
-                     cfg.rays_per_obj, S, cfg.shape_blocks, cfg.texture_blocks)
+                     cfg.rays_per_obj, S, cfg.shape_blocks, cfg.texture_blocks, prec)
     with torch.cuda.device(dev):
         check(_lib.lib().snr_render_fwd(C.byref(a), _p(rgb), _p(depth), _p(acc), _p(sig), _p(rgbs), _p(masks), _stream(dev)),
               "snr_render_fwd")
@@ -276,7 +301,8 @@ class FusedRender(torch.autograd.Function):
         d_d = torch.zeros_like(rays_d) if ctx.needs_input_grad[1] else None
         d_t = torch.empty_like(t_vals) if need_t else None
         a = _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg.frame, cfg.xyz_mul, cfg.z_mode, cfg.flags,
-                         cfg.rays_per_obj, cfg.n_samples, cfg.shape_blocks, cfg.texture_blocks)
+                         cfg.rays_per_obj, cfg.n_samples, cfg.shape_blocks, cfg.texture_blocks,
+                         resolve_precision(cfg.precision, cfg.shape_blocks, cfg.texture_blocks, cfg.rays_per_obj * cfg.n_samples))
         ws_bytes = _lib.lib().snr_render_bwd_ws_bytes(C.byref(a))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):

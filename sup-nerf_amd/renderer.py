@@ -101,7 +101,8 @@ class NeRFRenderer(torch.nn.Module):
         if frame is None:
             frame = U._frame(False, kitti2nusc, False)
         cfg = ops.RenderCfg(S, Z_PER_RAY, max(rays_o.shape[0] // B, 1), getattr(model, "shape_blocks", 0),
-                            getattr(model, "texture_blocks", 0), frame=frame, xyz_mul=adjust_scale, white_bkgd=white_bkgd, metric_z=True)
+                            getattr(model, "texture_blocks", 0), frame=frame, xyz_mul=adjust_scale, white_bkgd=white_bkgd, metric_z=True,
+                            precision=None)
         one = torch.ones(B, device=dev)
         zs = torch.full((B,), float(diag / 2), device=dev)
         if rays_o.shape[0] == 0:

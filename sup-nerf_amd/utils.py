@@ -174,7 +174,7 @@ def _render_shared_z(model, device, rays_o, viewdir, z, obj_diag, frame, shapeco
     B = shapecode.shape[0]
     div = torch.full((B,), float(obj_diag), device=dev)
     cfg = ops.RenderCfg(S, Z_SHARED, rays_o.shape[0] // B, getattr(model, "shape_blocks", 0), getattr(model, "texture_blocks", 0),
-                        frame=frame)
+                        frame=frame, precision=None)
     if rays_o.shape[0] == 0:
         e = torch.empty(0, device=dev)
         return e.view(0, 3), e, e

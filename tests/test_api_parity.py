@@ -27,10 +27,12 @@ def amd():
     return supnerf_amd
 
 
-@pytest.fixture(scope="module")
-def model(amd, dev, oracle_params):
+@pytest.fixture(scope="module", params=["fp32", "auto"])
+def model(amd, dev, oracle_params, request):
+    """Every API test runs twice: exact fp32 MFMA kernels, and 'auto' (= split-bf16 wherever the shape allows it)."""
     m = amd.CodeNeRF(shape_blocks=3, texture_blocks=1)
     m.load_state_dict(oracle_params, strict=True)
+    m.precision = request.param
     return m.to(dev)
 
 

@@ -160,20 +160,27 @@ def test_encode_family_b_metric_depth(amd, dev, golden):
 
 
 # ------------------------------------------------------------------ decoder
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("tag", ["b1_s32", "b3_s64", "b2_s7"])
-def test_decoder_forward_golden(amd, dev, golden, packed, tag):
+def test_decoder_forward_golden(amd, dev, golden, packed, tag, precision):
     g = golden("decoder_" + tag)
     pk, p = packed
     N, S = g["xyz"].shape[:2]
     lat = g["latent_terms"].to(dev)
-    sig, rgb, _ = amd.ops.decoder_fwd(g["xyz"].reshape(-1, 3).to(dev), g["viewdir"].reshape(-1, 3).to(dev), lat, pk, 3, 1)
+    if tag == "b2_s7" and precision == "bf16x3":      # 35 points per object: not whole 32-point tiles -> must refuse loudly
+        with pytest.raises(amd.SnrError):
+            amd.ops.decoder_fwd(g["xyz"].reshape(-1, 3).to(dev), g["viewdir"].reshape(-1, 3).to(dev), lat, pk, 3, 1, precision=precision)
+        return
+    sig, rgb, _ = amd.ops.decoder_fwd(g["xyz"].reshape(-1, 3).to(dev), g["viewdir"].reshape(-1, 3).to(dev), lat, pk, 3, 1,
+                                      precision=precision)
     assert maxdiff(sig.view(N, S, 1), g["sigmas"]) < 2e-5
     assert maxdiff(rgb.view(N, S, 3), g["rgbs"]) < 2e-5
 
 
 def test_decoder_forward_other_block_counts(amd, dev):
     """shape_blocks / texture_blocks are run-time parameters (CodeNeRF default 2/1, SUPNeRF default 5/5)."""
-    for sb, tb in [(2, 1), (5, 5), (0, 0), (1, 2)]:
+    for sb, tb, prec in [(2, 1, "fp32"), (2, 1, "bf16x3"), (5, 5, "fp32"), (0, 0, "fp32"), (0, 0, "bf16x3"), (1, 2, "bf16x3"), (2, 2, "auto"),
+                         (5, 5, "auto")]:
         params = O.init_decoder_params(shape_blocks=sb, texture_blocks=tb, seed=3 + sb)
         gen = torch.Generator().manual_seed(sb * 10 + tb)
         N, S, B = 6, 16, 2
@@ -185,21 +192,23 @@ def test_decoder_forward_other_block_counts(amd, dev):
             lat = O.latent_terms(params, sc, tc) if sb + tb else torch.zeros(B, 0, 256)
         pk = amd.ops.pack_weights({k: v.to(dev) for k, v in params.items()}, sb, tb)
         lat_d = lat.to(dev) if sb + tb else torch.zeros(B, 1, 256, device=dev)
-        sig, rgb, _ = amd.ops.decoder_fwd(xyz.reshape(-1, 3).to(dev), vd.reshape(-1, 3).to(dev), lat_d, pk, sb, tb)
-        assert maxdiff(sig.view(N, S, 1), sig_o) < 2e-5, (sb, tb)
-        assert maxdiff(rgb.view(N, S, 3), rgb_o) < 2e-5, (sb, tb)
+        sig, rgb, _ = amd.ops.decoder_fwd(xyz.reshape(-1, 3).to(dev), vd.reshape(-1, 3).to(dev), lat_d, pk, sb, tb, precision=prec)
+        assert maxdiff(sig.view(N, S, 1), sig_o) < 2e-5, (sb, tb, prec)
+        assert maxdiff(rgb.view(N, S, 3), rgb_o) < 2e-5, (sb, tb, prec)
 
 
 # ------------------------------------------------------------------ fused render
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("tag", ["a_nusc", "a_kitti", "a_demo"])
-def test_render_family_a_golden(amd, dev, golden, packed, oracle_params, tag):
+def test_render_family_a_golden(amd, dev, golden, packed, oracle_params, tag, precision):
     g = golden("render_" + tag)
     ops = amd.ops
     pk, p = packed
     S = int(g["n_samples"])
     ro, vd, z = _geom_family_a(g, dev, S, bool(g["shapenet_obj_cood"]))
     lat = O.latent_terms(oracle_params, g["shapecode"], g["texturecode"]).to(dev)
-    cfg = ops.RenderCfg(S, ops.Z_SHARED, ro.shape[0], 3, 1, frame=frame_matrix(False, bool(g["kitti2nusc"]), bool(g["shapenet_obj_cood"])))
+    cfg = ops.RenderCfg(S, ops.Z_SHARED, ro.shape[0], 3, 1, frame=frame_matrix(False, bool(g["kitti2nusc"]), bool(g["shapenet_obj_cood"])),
+                        precision=precision)
     div = torch.tensor([float(g["obj_diag"])], device=dev)
     rgb, depth, acc, *_ = ops.render_fwd(ro, vd, z, div, None, lat, pk, cfg)
     assert maxdiff(rgb, g["rgb"]) < TOL_RGB
