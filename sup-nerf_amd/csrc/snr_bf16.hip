@@ -62,18 +62,27 @@ __device__ __forceinline__ int ring_bytes(const Ring& r, int i) { return (i >= r
 // two-chunk prefetch every step); completion is counted by hand in ring_acquire (vmcnt(N) + s_barrier before the reads).
 // M0 (LDS destination base, wave-uniform) is written and restored inside the statement that uses it.
 __device__ __forceinline__ void ring_dma(const Ring& r, const char* g, char* lds, int bytes, int tid) {
-    const int n = bytes >> 12;
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + r.wave_lds;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + r.wave_lds);
     const unsigned voff = threadIdx.x * 16u;
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-        if (i < n) {
-            unsigned keep;
-            const char* gi = g + i * 4096;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + i * 4096u);
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(voff), "s"(gi), "s"(dst) : "memory");
-        }
+    unsigned keep, vt;
+    // 8 rows of 4 KiB (every chunk), M0 += 4 KiB and the per-lane source offset += 4 KiB between rows
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\tv_mov_b32 %1, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&v"(vt) : "v"(voff), "s"(g), "s"(dst) : "memory");
+    if (bytes > BF_CHUNK) {      // ninth row of a 36 KiB enc_viewdir^T chunk
+        const unsigned dst9 = dst + 0x8000u;
+        const char* g9 = g + 0x8000;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(g9), "s"(dst9) : "memory");
+    }
 }
 
 // prologue: chunks 0 and 1 in flight
@@ -92,9 +101,15 @@ __device__ __forceinline__ void ring_start(Ring& r, const char* stream, int tota
 __device__ __forceinline__ const char* ring_acquire(Ring& r, char* lds, int tid) {
     // every chunk is issued as 8 (32 KiB) or 9 (36 KiB) DMA instructions per wave; leaving the 8 youngest in flight
     // retires chunk ci completely (and at most one instruction of a 36 KiB chunk ci+1)
-    if (r.ci + 1 < r.total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef SNR_EXP_NOSYNC      /* timing experiments only: results are garbage without the rendezvous */
+#ifndef SNR_EXP_NOVM
+    if (r.ci + 1 < r.total) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+#ifndef SNR_EXP_NOBAR
     __builtin_amdgcn_s_barrier();
+#endif
+#endif
     if (r.ci + 2 < r.total) {
         const int b = ring_bytes(r, r.ci + 2);
         ring_dma(r, r.next, lds + r.fill * WB_BYTES, b, tid);
@@ -119,6 +134,26 @@ __device__ __forceinline__ void step_mma(f32x16 (&acc)[NA], const XOp& x, const 
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x.hi, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x.lo, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, x.hi, acc[t], 0, 0, 0);
+    }
+}
+
+// A fragments of half a step (NTH tiles, hi and lo planes): loaded half a step ahead of the MFMAs that use them
+template <int NTH> struct Frags { bf16x8 hi[NTH], lo[NTH]; };
+template <int NTH, int T0>
+__device__ __forceinline__ void load_frags(Frags<NTH>& f, const char* ws) {
+#pragma unroll
+    for (int t = 0; t < NTH; ++t) {
+        f.hi[t] = *reinterpret_cast<const bf16x8*>(ws + (2 * (T0 + t)) * 1024);
+        f.lo[t] = *reinterpret_cast<const bf16x8*>(ws + (2 * (T0 + t) + 1) * 1024);
+    }
+}
+template <int NTH, int T0, int NA>
+__device__ __forceinline__ void mma_half(f32x16 (&acc)[NA], const XOp& x, const Frags<NTH>& f) {
+#pragma unroll
+    for (int t = 0; t < NTH; ++t) {
+        acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.hi[t], x.hi, acc[T0 + t], 0, 0, 0);
+        acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.hi[t], x.lo, acc[T0 + t], 0, 0, 0);
+        acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.lo[t], x.hi, acc[T0 + t], 0, 0, 0);
     }
 }
 
@@ -158,22 +193,40 @@ struct FwdEpi {
 // step (behind the barrier), which serialises it with that step's MFMAs instead of hiding it under this step's
 __device__ __forceinline__ void pin(XOp& o) { asm volatile("" : "+v"(o.hi), "+v"(o.lo)); }
 
-template <int T, int HALF>
-__device__ __forceinline__ void fwd_half_tile(const f32x16& acc, XOp& out, const FwdEpi& c, int h, uint32_t (&mask)[4]) {
+// one quarter of a tile's epilogue: registers 8*HALF + 4*JJ .. +3 -> elements 4*JJ .. +3 of operand step 2*T + HALF.
+// MASKS = false (no gradient will be asked for): the ReLU bits are not collected, which saves ~3 of ~10 VALU ops per value --
+// with one wave per SIMD the layer chain is bounded by instruction ISSUE (about six 4-cycle slots per 32-cycle MFMA).
+// bias and latent vectors of one quarter: fetched from LDS at the top of a step, consumed half a step or more later, so no
+// lgkmcnt wait sits between the MFMAs (an exposed LDS round trip there stalls the in-order wave AND the matrix pipe)
+struct EpiVec { f32x4 b, z; };
+template <int T, int HALF, int JJ>
+__device__ __forceinline__ void fwd_quarter_load(EpiVec& v, const FwdEpi& c, int h) {
+    const int j = 2 * HALF + JJ;
+    v.b = *reinterpret_cast<const f32x4*>(c.bias + 32 * T + 8 * j + 4 * h);
+    v.z = *reinterpret_cast<const f32x4*>(c.zl + 32 * T + 8 * j + 4 * h);
+}
+template <int T, int HALF, int JJ, bool MASKS>
+__device__ __forceinline__ void fwd_quarter(const f32x16& acc, XOp& out, const FwdEpi& c, const EpiVec& v, uint32_t (&mask)[4]) {
+#ifdef SNR_EXP_NOEPI
+    return;
+#endif
+    const int j = 2 * HALF + JJ;
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int j = 2 * HALF + jj;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(c.bias + 32 * T + 8 * j + 4 * h);
-        const f32x4 zv = *reinterpret_cast<const f32x4*>(c.zl + 32 * T + 8 * j + 4 * h);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = 4 * j + e;
-            const float a = acc[r] + bv[e];
-            mask[T >> 1] |= (a > 0.f ? 1u : 0u) << ((T & 1) * 16 + r);      // only stored for ReLU layers
-            split_store(fmaxf(a, c.floor) + zv[e], out, r & 7);
-        }
+    for (int e = 0; e < 4; ++e) {
+        const int r = 4 * j + e;
+        const float a = acc[r] + v.b[e];
+        if (MASKS) mask[T >> 1] |= (a > 0.f ? 1u : 0u) << ((T & 1) * 16 + r);      // only stored for ReLU layers
+        split_store(__builtin_amdgcn_fmed3f(a, c.floor, __builtin_inff()) + v.z[e], out, r & 7);   // max(a, floor) in one op
     }
-    pin(out);
+    if (JJ == 1) pin(out);
+}
+template <int T, int HALF, bool MASKS>
+__device__ __forceinline__ void fwd_half_tile(const f32x16& acc, XOp& out, const FwdEpi& c, int h, uint32_t (&mask)[4]) {
+    EpiVec v0, v1;
+    fwd_quarter_load<T, HALF, 0>(v0, c, h);
+    fwd_quarter_load<T, HALF, 1>(v1, c, h);
+    fwd_quarter<T, HALF, 0, MASKS>(acc, out, c, v0, mask);
+    fwd_quarter<T, HALF, 1, MASKS>(acc, out, c, v1, mask);
 }
 
 // density head on finished enc_shape accumulators (+ its bias): this lane's share of w_sigma . y
@@ -193,31 +246,52 @@ __device__ __forceinline__ float sigma_partial(const f32x16 (&acc)[8], const flo
     return (d0 + d1) + (d2 + d3);
 }
 
-// Step s of a layer whose operands come from the previous layer's accumulators: produce x[S+1] (if any) from accP
-// while the MFMAs of step S (operand x[S]) run.  Written as one straight block so the scheduler can interleave.
-template <int S, int NT>
-__device__ __forceinline__ void fwd_step(f32x16 (&accP)[8], f32x16 (&accC)[8], XOp (&x)[16], const char* ws, const FwdEpi& c, int h,
-                                         uint32_t (&mask)[4]) {
-    step_mma<NT, 8>(accC, x[S], ws);
-    if constexpr (S + 1 < 16) fwd_half_tile<((S + 1) >> 1), ((S + 1) & 1)>(accP[(S + 1) >> 1], x[S + 1], c, h, mask);
-    __builtin_amdgcn_sched_barrier(0);      // keep live ranges inside one step: nothing is hoisted across steps
-}
-
 // One layer with 16 operand steps taken from accP (+ 2 direction steps for enc_viewdir), NT output tiles into accC.
-template <int NT>
+// Each step is two half-steps of NT/2 tiles.  The A fragments of a half-step are fetched from LDS while the previous
+// half-step's MFMAs run (two fragment buffers), the next chunk is acquired half a step before it is needed, and the
+// previous layer's epilogue for operand step S+1 is split over the two half-steps of step S.
+template <int NT, bool MASKS>
 __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], XOp (&x)[16], const char* xdir_lds, Ring& ring, char* lds,
                                           const FwdEpi& c, bool extra, uint32_t (&mask)[4], int tid, int lane) {
     const int h = lane >> 5;
+    constexpr int NTH = NT / 2;
     constexpr int SPC = (NT == 8) ? 2 : 4;            // steps per 32 KiB chunk
     constexpr int STEP_BYTES = NT * 2 * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) mask[i] = 0u;
     acc_zero<NT, 8>(accC);
-    fwd_half_tile<0, 0>(accP[0], x[0], c, h, mask);
-    const char* w = nullptr;
-#define SNR_FSTEP(S)                                                                         \
-    if ((S) % SPC == 0) w = ring_acquire(ring, lds, tid) + lane * 16;                        \
-    fwd_step<S, NT>(accP, accC, x, w + ((S) % SPC) * STEP_BYTES, c, h, mask);
+    fwd_half_tile<0, 0, MASKS>(accP[0], x[0], c, h, mask);
+    Frags<NTH> fa, fb;
+    const char* w = ring_acquire(ring, lds, tid) + lane * 16;
+    load_frags<NTH, 0>(fa, w);
+// interleave request for one half-step region: after every MFMA one LDS read (while there are any) and two VALU ops, so the
+// fragment fetches for the next half-step and the previous layer's epilogue are spread under the MFMAs instead of in blocks
+#define SNR_INTERLEAVE(N_MFMA)                                                           \
+    _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA); ++g_) {                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                               \
+    }
+#define SNR_FSTEP(S)                                                                                                   \
+    {                                                                                                                  \
+        const char* ws = w + ((S) % SPC) * STEP_BYTES;                                                                 \
+        EpiVec v0, v1;                                                                                                 \
+        load_frags<NTH, NTH>(fb, ws);                                                                                  \
+        if constexpr ((S) + 1 < 16) {                                                                                  \
+            fwd_quarter_load<(((S) + 1) >> 1), (((S) + 1) & 1), 0>(v0, c, h);                                          \
+            fwd_quarter_load<(((S) + 1) >> 1), (((S) + 1) & 1), 1>(v1, c, h);                                          \
+        }                                                                                                              \
+        mma_half<NTH, 0, 8>(accC, x[S], fa);                                                                           \
+        if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0, MASKS>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v0, mask); \
+        SNR_INTERLEAVE(3 * NTH)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + STEP_BYTES);                                   \
+        else if constexpr ((S) + 1 < 16) { w = ring_acquire(ring, lds, tid) + lane * 16; load_frags<NTH, 0>(fa, w); }  \
+        mma_half<NTH, NTH, 8>(accC, x[S], fb);                                                                         \
+        if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1, MASKS>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v1, mask); \
+        SNR_INTERLEAVE(3 * NTH)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }
     SNR_FSTEP(0) SNR_FSTEP(1) SNR_FSTEP(2) SNR_FSTEP(3) SNR_FSTEP(4) SNR_FSTEP(5) SNR_FSTEP(6) SNR_FSTEP(7)
     SNR_FSTEP(8) SNR_FSTEP(9) SNR_FSTEP(10) SNR_FSTEP(11) SNR_FSTEP(12) SNR_FSTEP(13) SNR_FSTEP(14) SNR_FSTEP(15)
 #undef SNR_FSTEP
@@ -232,7 +306,14 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
 }
 
 // ------------------------------------------------------------------------------------------ forward kernel
-template <int MODE>
+#ifdef SNR_STAMPS
+#define SNR_STAMP(i) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    reinterpret_cast<unsigned long long*>(io.sigmas)[tile32 * 16 + (i)] = t_; } } while (0)
+#else
+#define SNR_STAMP(i) do {} while (0)
+#endif
+
+template <int MODE, bool MASKS>
 __global__ void __launch_bounds__(256, 1)
 bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom g,
                 float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_acc) {
@@ -248,6 +329,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     const int li_encshape = sb + 1, li_view = sb + 2, li_last = sb + tb + 2;
     float* vec = reinterpret_cast<float*>(lds + OFF_VEC);
     float* latw = reinterpret_cast<float*>(lds + OFF_LAT) + wave * MAX_LAT * 256;
+    SNR_STAMP(0);
 
     // ---- stage the small vectors and this wave's latent terms in LDS (plain loads, before any DMA is queued)
     {
@@ -273,6 +355,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         if (lane < 32) reinterpret_cast<float*>(lds + OFF_COMP)[(wave * 32 + p) * COMP_STRIDE + 4] = zc;
     }
     __syncthreads();
+    SNR_STAMP(1);
 
     // ---- weight ring: chunks 0,1 in flight while the positional encodings are computed (scratch = ring buffer 2)
     Ring ring;
@@ -320,6 +403,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     f32x16 accA[8], accB[8];
     uint32_t mask[4];
     float sig_dot = 0.f;
+    SNR_STAMP(2);
 
     // ---- enc_xyz: 4 operand steps straight from the encoding -> accA
     acc_zero<8, 8>(accA);
@@ -332,6 +416,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         step_mma<8, 8>(accA, x[3], w + 16 * 1024);
     }
 
+    SNR_STAMP(3);
     // ---- 256-wide layers: layer li consumes the accumulators of layer li-1 (epilogue fused into its steps)
     auto epi_of = [&](int l) {     // epilogue configuration of MFMA layer l's output
         FwdEpi c;
@@ -342,29 +427,32 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         return c;
     };
     auto store_mask = [&](int l) {   // ReLU bits of layer l (complete once the next layer has consumed all its tiles)
-        if (l != li_encshape && io.masks)
+        if (MASKS && l != li_encshape)
             io.masks[(tile32 * n_relu + relu_slot(l, sb)) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
     };
     int li = 1;
 #pragma unroll 1
     for (; li + 1 <= li_last; li += 2) {
-        layer_fwd<8>(accA, accB, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
+        layer_fwd<8, MASKS>(accA, accB, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
         store_mask(li - 1);
         if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_BIAS + li * 256, vec + VEC_SIGW, h);
-        layer_fwd<8>(accB, accA, x, xdir, ring, lds, epi_of(li), li + 1 == li_view, mask, tid, lane);
+        SNR_STAMP(3 + li);
+        layer_fwd<8, MASKS>(accB, accA, x, xdir, ring, lds, epi_of(li), li + 1 == li_view, mask, tid, lane);
         store_mask(li);
         if (li + 1 == li_encshape) sig_dot = sigma_partial(accA, vec + VEC_BIAS + (li + 1) * 256, vec + VEC_SIGW, h);
+        SNR_STAMP(4 + li);
     }
     const bool odd_tail = (li == li_last);
     if (odd_tail) {
-        layer_fwd<8>(accA, accB, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
+        layer_fwd<8, MASKS>(accA, accB, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
         store_mask(li - 1);
         if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_BIAS + li * 256, vec + VEC_SIGW, h);
     }
     // ---- rgb.0: 256 -> 128 (4 tiles) from the last 256-wide layer's accumulators
-    if (odd_tail) layer_fwd<4>(accB, accA, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
-    else          layer_fwd<4>(accA, accB, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
+    if (odd_tail) layer_fwd<4, MASKS>(accB, accA, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
+    else          layer_fwd<4, MASKS>(accA, accB, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
     store_mask(li_last);
+    SNR_STAMP(12);
 
     // density head (enc_shape's output dotted with w_sigma inside the epilogues)
     const float pre = sig_dot + __shfl_xor(sig_dot, 32, 64) + vec[VEC_MISC + 0];
@@ -387,21 +475,24 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = (odd_tail ? accA[t][4 * j + e] : accB[t][4 * j + e]) + bv[e];
-                    if (v > 0.f) mk[t >> 1] |= 1u << ((t & 1) * 16 + 4 * j + e);
+                    if (MASKS && v > 0.f) mk[t >> 1] |= 1u << ((t & 1) * 16 + 4 * j + e);
                     v = fmaxf(v, 0.f);
                     pr = fmaf(wr[e], v, pr); pg = fmaf(wg[e], v, pg); pb = fmaf(wb[e], v, pb);
                 }
             }
-        if (io.masks) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mk[0], mk[1], 0u, 0u);
+        if (MASKS) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mk[0], mk[1], 0u, 0u);
     }
     const float cr = pr + __shfl_xor(pr, 32, 64) + vec[VEC_MISC + 4];
     const float cg = pg + __shfl_xor(pg, 32, 64) + vec[VEC_MISC + 5];
     const float cb = pb + __shfl_xor(pb, 32, 64) + vec[VEC_MISC + 6];
 
+    SNR_STAMP(13);
+#ifndef SNR_STAMPS
     if (live && lane < 32) {
         if (io.sigmas) io.sigmas[gp] = o_sigma;
         if (io.rgbs) { io.rgbs[gp * 3] = cr; io.rgbs[gp * 3 + 1] = cg; io.rgbs[gp * 3 + 2] = cb; }
     }
+#endif
     if (MODE == 1) {
         float* comp = reinterpret_cast<float*>(lds + OFF_COMP);
         if (lane < 32) {
@@ -427,6 +518,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
             }
         }
     }
+    SNR_STAMP(14);
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -832,8 +924,14 @@ int snr_bf16_pack_(const float* const* W /* per-point weight tensors in MFMA-lay
 int snr_bf16_launch_fwd_(int mode, const DecoderIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
                          float* depth, float* acc, void* stream_) {
     const unsigned grid = (unsigned)((io.n_points + 127) / 128);
-    if (mode == 0) bf::bf16_fwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
-    else bf::bf16_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+    hipStream_t st = (hipStream_t)stream_;
+    if (io.masks) {
+        if (mode == 0) bf::bf16_fwd_kernel<0, true><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+        else bf::bf16_fwd_kernel<1, true><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+    } else {
+        if (mode == 0) bf::bf16_fwd_kernel<0, false><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+        else bf::bf16_fwd_kernel<1, false><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+    }
     return snr_check_launch_();
 }
 

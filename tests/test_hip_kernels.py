@@ -183,7 +183,7 @@ def test_decoder_forward_other_block_counts(amd, dev):
                          (5, 5, "auto")]:
         params = O.init_decoder_params(shape_blocks=sb, texture_blocks=tb, seed=3 + sb)
         gen = torch.Generator().manual_seed(sb * 10 + tb)
-        N, S, B = 6, 16, 2
+        N, S, B = 8, 16, 2          # 64 points per object: whole 32-point tiles (needed by bf16x3)
         xyz = torch.rand(N, S, 3, generator=gen) - 0.5
         vd = torch.randn(N, S, 3, generator=gen); vd = vd / vd.norm(dim=-1, keepdim=True)
         sc, tc = torch.randn(B, 256, generator=gen) * 0.3, torch.randn(B, 256, generator=gen) * 0.3

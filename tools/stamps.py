@@ -1,0 +1,46 @@
+"""Diagnostic: per-phase timeline of the bf16x3 forward kernel from in-kernel s_memtime stamps
+(library built with -DSNR_STAMPS into tools/_diag/; outputs of that build are not valid renders)."""
+import sys, os, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import supnerf_amd as A
+from supnerf_amd import _lib, ops, synthetic as SY, utils as U
+good = _lib.lib()                                   # regular library for packing
+stamps = C.CDLL(os.path.join(ROOT, "tools", "_diag", os.environ.get("SNR_STAMP_LIB", "libsupnerf_stamps.so")), mode=os.RTLD_NOW | os.RTLD_DEEPBIND)   # own symbols first
+stamps.snr_render_fwd.restype = C.c_int
+stamps.snr_render_fwd.argtypes = _lib._SIGS["snr_render_fwd"][1]
+dev = torch.device("cuda:0")
+model = A.CodeNeRF(3, 1); model.load_state_dict(SY.init_decoder_params()); model = model.to(dev)
+N, S = 4096, 64
+ob = SY.synthetic_object(100)
+g = torch.Generator().manual_seed(100)
+sc = (torch.randn(1, 256, generator=g) * 0.3).to(dev); tc = (torch.randn(1, 256, generator=g) * 0.3).to(dev)
+with torch.no_grad():
+    ro, vd = U.get_rays(ob["K"], ob["cam_pose"].to(dev), ob["roi"], uv_steps=[64, 64])
+    near, far = U._sphere_bounds(ob["cam_pose"], ob["obj_diag"])
+    z = U._shared_depths(near, far, S, dev, jitter=torch.rand(S, generator=g))
+    lat = model.latent_terms(sc, tc).contiguous()
+pk = model.packed_weights()
+div = torch.full((1,), float(ob["obj_diag"]), device=dev)
+ro, vd = ro.contiguous(), vd.contiguous()
+a = ops._render_args(ro, vd, z, div, None, lat, pk, U._frame(False, False, True), 1.0, ops.Z_SHARED, 0, N, S, 3, 1, 1)
+rgb = torch.empty(N, 3, device=dev); depth = torch.empty(N, device=dev); acc = torch.empty(N, device=dev)
+dbg = torch.zeros(N * S, device=dev)               # "sigmas" buffer receives the stamps: 16 x u64 per wave tile
+for _ in range(3):
+    rc = stamps.snr_render_fwd(C.byref(a), rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), dbg.data_ptr(), None, None,
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+torch.cuda.synchronize()
+t = dbg.cpu().numpy().view(np.uint64).reshape(-1, 16)[: N * S // 32].astype(np.int64)
+names = ["start", "staged", "PE done", "L0 done"] + [f"layer {i} done" for i in range(1, 7)] + ["", "", "rgb0 done", "heads done", "end"]
+d = t - t[:, :1]
+print("cycles from kernel start (median over %d wave tiles):" % len(t))
+prev = 0
+for i, n in enumerate(names):
+    if not n: continue
+    m = float(np.median(d[:, i]))
+    print(f"  {n:14s} {m:10.0f}  (+{m - prev:8.0f})")
+    prev = m
+print("first start -> last end (cycles):", int(t[:, 14].max() - t[:, 0].min()), " waves:", len(t))
