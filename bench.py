@@ -30,7 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_RAY = 57.56e6          # forward, S = 64
-PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_TFLOPS = {"fp32": 157.3,    # MI355X_MICROARCH.md "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f32
+               "bf16x3": 2500.0}  # dense BF16 MFMA peak; the split-bf16 path issues 3 MFMAs per algorithmic product
 N_RAYS, N_SAMPLES, IM_SZ = 4096, 64, 64
 
 
@@ -57,6 +58,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
+                    help="decoder GEMM arithmetic of the headline run (the other mode is timed too and reported under 'extra')")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -87,11 +90,14 @@ def main():
         lat = model.latent_terms(w["sc"], w["tc"])
     packed = model.packed_weights()
     div = torch.full((1,), float(ob["obj_diag"]), device=dev)
-    cfg = ops.RenderCfg(N_SAMPLES, ops.Z_SHARED, N_RAYS, 3, 1, frame=U._frame(False, False, True))
+    cfg = ops.RenderCfg(N_SAMPLES, ops.Z_SHARED, N_RAYS, 3, 1, frame=U._frame(False, False, True), precision=args.precision)
+    other = "fp32" if args.precision == "bf16x3" else "bf16x3"
+    cfg_other = ops.RenderCfg(N_SAMPLES, ops.Z_SHARED, N_RAYS, 3, 1, frame=U._frame(False, False, True), precision=other)
+    model.precision = args.precision
     assert rays_o.shape[0] == N_RAYS
 
-    def step():
-        return ops.render_fwd(rays_o, viewdir, z, div, None, lat, packed, cfg)
+    def step(c=cfg):
+        return ops.render_fwd(rays_o, viewdir, z, div, None, lat, packed, c)
 
     def barrier():
         if dist is not None:
@@ -122,6 +128,18 @@ def main():
     torch.cuda.synchronize()
     kern_ms = e0.elapsed_time(e1) / args.steps
     achieved = N_RAYS * FLOP_PER_RAY / (kern_ms * 1e-3) / 1e12
+    # the other arithmetic mode, same launches (reported, not the headline)
+    for _ in range(5):
+        step(cfg_other)
+    torch.cuda.synchronize()
+    e0.record()
+    n_other = max(10, args.steps // 4)
+    for _ in range(n_other):
+        out_other = step(cfg_other)
+    e1.record()
+    torch.cuda.synchronize()
+    other_ms = e0.elapsed_time(e1) / n_other
+    other_tf = N_RAYS * FLOP_PER_RAY / (other_ms * 1e-3) / 1e12
 
     # ---- forward + backward leg (the optimiser's inner iteration: gradients wrt codes and pose)
     sc_g, tc_g = w["sc"].clone().requires_grad_(), w["tc"].clone().requires_grad_()
@@ -150,18 +168,57 @@ def main():
         fb_elapsed = float(t.item())
     fwd_bwd_rays = world * N_RAYS * n_fb / fb_elapsed
 
+    # ---- the two HBM-bound stand-alone kernels (encode with PE output, composite) at 16 objects x 4096 x 64: achieved GB/s
+    hbm = {}
+    if rank == 0:
+        Bh = 16
+        ro_h, vd_h = rays_o.repeat(Bh, 1), viewdir.repeat(Bh, 1)
+        z_h = z[None].repeat(Bh, 1).contiguous()
+        div_h = div.repeat(Bh)
+        cfg_h = ops.RenderCfg(N_SAMPLES, ops.Z_PER_OBJECT, N_RAYS, 3, 1, frame=U._frame(False, False, True))
+        P_h = Bh * N_RAYS * N_SAMPLES
+
+        def timed(fn, n=10):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n * 1e-3
+        t_enc = timed(lambda: ops.encode(ro_h, vd_h, z_h, div_h, None, cfg_h, want_pe=True))
+        enc_bytes = P_h * (12 + 12 + 4 + 63 * 4) + Bh * N_RAYS * (24 + 27 * 4)          # xyz, viewdir, z, PE(xyz) per point; rays in, PE(dir) out
+        sig_h = torch.rand(Bh * N_RAYS, N_SAMPLES, device=dev)
+        rgb_h = torch.rand(Bh * N_RAYS, N_SAMPLES, 3, device=dev)
+        t_cmp = timed(lambda: ops.composite_fwd(sig_h, rgb_h, z_h, ops.Z_PER_OBJECT, False, N_RAYS))
+        cmp_bytes = P_h * 16 + Bh * N_RAYS * 20
+        hbm = {"encode": {"GB_per_s": enc_bytes / t_enc / 1e9, "ms": t_enc * 1e3, "bytes": enc_bytes, "frac_of_8TBps": enc_bytes / t_enc / 8e12},
+               "composite_fwd": {"GB_per_s": cmp_bytes / t_cmp / 1e9, "ms": t_cmp * 1e3, "bytes": cmp_bytes, "frac_of_8TBps": cmp_bytes / t_cmp / 8e12},
+               "shape": f"{Bh} objects x {N_RAYS} rays x {N_SAMPLES} samples"}
+        del sig_h, rgb_h
+
     result = {
         "metric": "rays/sec at 4096 rays x 64 samples (fused render forward)",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": "supnerf.nusc.vehicle.car.json decoder (shape_blocks 3, texture_blocks 1, W 256), 1 object per GPU, "
-                               "4096 rays x 64 samples, family-A render (render_rays_v2 tail), fp32 MFMA",
+                               "4096 rays x 64 samples, family-A render (render_rays_v2 tail)", "precision": args.precision,
                    "rays": N_RAYS, "samples": N_SAMPLES, "objects_per_gpu": 1, "sharding": "objects across ranks, no data-path collective"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
-                     "kernel": "decoder_fwd_kernel<1>", "kernel_ms": kern_ms, "flop_per_launch": N_RAYS * FLOP_PER_RAY},
-        "extra": {"fwd_bwd_rays_per_s": fwd_bwd_rays, "fwd_bwd_ms_per_iter": fb_elapsed / n_fb * 1e3,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": None,
+                     "kernel": "bf16_fwd_kernel<1,false>" if args.precision == "bf16x3" else "decoder_fwd_kernel<1>",
+                     "kernel_ms": kern_ms, "flop_per_launch": N_RAYS * FLOP_PER_RAY,
+                     "note": "achieved = ALGORITHMIC flops (57.56 MFLOP/ray) / kernel time; bf16x3 issues 3x that on the bf16 MFMA pipe "
+                             "(mfma_pipe_frac), fp32 issues 1x on the fp32 MFMA pipe",
+                     "mfma_pipe_frac": (3.0 if args.precision == "bf16x3" else 1.0) * achieved / PEAK_TFLOPS[args.precision]},
+        "extra": {other + "_mode": {"rays_per_s": N_RAYS / (other_ms * 1e-3), "kernel_ms": other_ms, "achieved_tflops": other_tf,
+                                    "frac_of_peak": other_tf / PEAK_TFLOPS[other]},
+                  "hbm_bound_kernels": hbm,
+                  "fwd_bwd_rays_per_s": fwd_bwd_rays, "fwd_bwd_ms_per_iter": fb_elapsed / n_fb * 1e3,
                   "fwd_bwd_note": "forward + backward to shape/texture codes and camera pose, incl. ray generation and loss in torch"},
     }
 

@@ -559,48 +559,67 @@ struct BwdEpi {
     float dpre;           // d loss / d (pre-softplus density) of this lane's point
     float* dz;            // global: this wave tile's partial latent gradient (256 floats), or null
 };
+template <int T, int HALF, int JJ>
+__device__ __forceinline__ void bwd_quarter(const f32x16& acc, XOp& out, const BwdEpi& c, const f32x4& wv, int lane) {
+    if (HALF == 0 && JJ == 0 && c.dz) reduce_tile_store(acc, c.dz + 32 * T, lane);
+    const int j = 2 * HALF + JJ;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int r = 4 * j + e;
+        float v = fmaf(c.dpre, wv[e], acc[r]);
+        v = ((c.m[T >> 1] >> ((T & 1) * 16 + r)) & 1u) ? v : 0.f;
+        split_store(v, out, r & 7);
+    }
+    if (JJ == 1) pin(out);
+}
 template <int T, int HALF>
 __device__ __forceinline__ void bwd_half_tile(const f32x16& acc, XOp& out, const BwdEpi& c, int h, int lane) {
-    if (HALF == 0 && c.dz) reduce_tile_store(acc, c.dz + 32 * T, lane);
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int j = 2 * HALF + jj;
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(c.wsig + 32 * T + 8 * j + 4 * h);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = 4 * j + e;
-            float v = fmaf(c.dpre, wv[e], acc[r]);
-            v = ((c.m[T >> 1] >> ((T & 1) * 16 + r)) & 1u) ? v : 0.f;
-            split_store(v, out, r & 7);
-        }
-    }
-    asm volatile("" : "+v"(out.hi), "+v"(out.lo));      // produced here, not sunk to its use (see pin() above)
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(c.wsig + 32 * T + 8 * (2 * HALF) + 4 * h);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(c.wsig + 32 * T + 8 * (2 * HALF + 1) + 4 * h);
+    bwd_quarter<T, HALF, 0>(acc, out, c, w0, lane);
+    bwd_quarter<T, HALF, 1>(acc, out, c, w1, lane);
 }
 
-// One transposed layer: 16 operand steps from accP, NT (+1 with `ninth`) output tiles into accC (+ acc9).
+// One transposed layer: 16 operand steps from accP, NT (+1 with `ninth`) output tiles into accC (+ acc9); same
+// half-step pipeline as layer_fwd.
 template <int NT>
 __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], f32x16& acc9, XOp (&x)[16], Ring& ring, char* lds,
                                           const BwdEpi& c, bool ninth, int tid, int lane) {
     const int h = lane >> 5;
+    constexpr int NTH = NT / 2;
     constexpr int SPC = (NT == 8) ? 2 : 8;                  // steps per chunk (NT == 2: enc_xyz^T, 8 steps of 4 KiB)
     const int step_bytes = (NT + (ninth ? 1 : 0)) * 2 * 1024;
     acc_zero<NT, 8>(accC);
     bwd_half_tile<0, 0>(accP[0], x[0], c, h, lane);
-    const char* w = nullptr;
-#define SNR_BSTEP(S)                                                                                      \
-    if ((S) % SPC == 0) w = ring_acquire(ring, lds, tid) + lane * 16;                                     \
-    {                                                                                                     \
-        const char* ws = w + ((S) % SPC) * step_bytes;                                                    \
-        step_mma<NT, 8>(accC, x[S], ws);                                                                  \
-        if (NT == 8 && ninth) {                                                                           \
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + 16 * 1024);                           \
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ws + 17 * 1024);                           \
-            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x[S].hi, acc9, 0, 0, 0);                   \
-            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x[S].lo, acc9, 0, 0, 0);                   \
-            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, x[S].hi, acc9, 0, 0, 0);                   \
-        }                                                                                                 \
-        if constexpr ((S) + 1 < 16) bwd_half_tile<(((S) + 1) >> 1), (((S) + 1) & 1)>(accP[((S) + 1) >> 1], x[(S) + 1], c, h, lane); \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
+    Frags<NTH> fa, fb;
+    const char* w = ring_acquire(ring, lds, tid) + lane * 16;
+    load_frags<NTH, 0>(fa, w);
+#define SNR_BSTEP(S)                                                                                                   \
+    {                                                                                                                  \
+        const char* ws = w + ((S) % SPC) * step_bytes;                                                                 \
+        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;                                                                      \
+        load_frags<NTH, NTH>(fb, ws);                                                                                  \
+        if constexpr ((S) + 1 < 16) {                                                                                  \
+            w0 = *reinterpret_cast<const f32x4*>(c.wsig + 32 * (((S) + 1) >> 1) + 8 * (2 * (((S) + 1) & 1)) + 4 * h);     \
+            w1 = *reinterpret_cast<const f32x4*>(c.wsig + 32 * (((S) + 1) >> 1) + 8 * (2 * (((S) + 1) & 1) + 1) + 4 * h); \
+        }                                                                                                              \
+        mma_half<NTH, 0, 8>(accC, x[S], fa);                                                                           \
+        if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, w0, lane); \
+        SNR_INTERLEAVE(3 * NTH)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (NT == 8 && ninth) {                                                                                        \
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + 16 * 1024);                                        \
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ws + 17 * 1024);                                        \
+            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x[S].hi, acc9, 0, 0, 0);                                \
+            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x[S].lo, acc9, 0, 0, 0);                                \
+            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, x[S].hi, acc9, 0, 0, 0);                                \
+        }                                                                                                              \
+        if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + step_bytes);                                   \
+        else if constexpr ((S) + 1 < 16) { w = ring_acquire(ring, lds, tid) + lane * 16; load_frags<NTH, 0>(fa, w); }  \
+        mma_half<NTH, NTH, 8>(accC, x[S], fb);                                                                         \
+        if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, w1, lane); \
+        SNR_INTERLEAVE(3 * NTH)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
     SNR_BSTEP(0) SNR_BSTEP(1) SNR_BSTEP(2) SNR_BSTEP(3) SNR_BSTEP(4) SNR_BSTEP(5) SNR_BSTEP(6) SNR_BSTEP(7)
     SNR_BSTEP(8) SNR_BSTEP(9) SNR_BSTEP(10) SNR_BSTEP(11) SNR_BSTEP(12) SNR_BSTEP(13) SNR_BSTEP(14) SNR_BSTEP(15)
