@@ -194,3 +194,25 @@ def test_metric_gather_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_reference_file_formats_round_trip(amd, tmp_path):
+    """models.pth / codes+poses.pth with the reference's keys (src/trainer_unified_nuscenes.py:476-490, src/optimizer_nuscenes.py:1463-1476)."""
+    m = amd.SUPNeRF(shape_blocks=3, texture_blocks=1)
+    g = torch.Generator().manual_seed(0)
+    sc, tc = torch.randn(5, 256, generator=g), torch.randn(5, 256, generator=g)
+    opt = torch.tensor([1., 0., 1., 1., 0.])
+    p = str(tmp_path / "ck" / "models.pth")
+    amd.io.save_checkpoint(p, m, sc, tc, niter=7, nepoch=2, optimized_idx=opt)
+    saved = torch.load(p, weights_only=False)
+    assert set(saved) == {"model_params", "shape_code_params", "texture_code_params", "niter", "nepoch", "instoken2idx", "optimized_idx"}
+    m2 = amd.CodeNeRF(shape_blocks=3, texture_blocks=1)          # decoder-only module: extra pose-head keys are skipped
+    ms, mt, _, missing = amd.io.load_checkpoint(p, m2)
+    assert torch.equal(ms, sc[[0, 2, 3]].mean(0, keepdim=True)) and torch.equal(mt, tc[[0, 2, 3]].mean(0, keepdim=True))
+    assert all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), list(m.state_dict().values())[:28]))
+    rows = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 12)
+    ps, de, R, T = amd.io.metric_rows_to_eval_dicts(rows, [10, 11])
+    out = amd.io.save_opts_w_pose(str(tmp_path / "res"), 2, {}, {}, {}, ps, de, R, T)
+    d = torch.load(out, weights_only=False)
+    assert d["psnr_eval"]["10_0"] == [0.0, 4.0, 8.0] and d["T_eval"]["11_0"] == [15.0, 19.0, 23.0]
+    assert set(d) >= {"num_obj", "optimized_shapecodes", "optimized_texturecodes", "optimized_poses", "psnr_eval", "depth_err_mean", "R_eval", "T_eval"}
