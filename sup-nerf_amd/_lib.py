@@ -37,9 +37,9 @@ _SIGS = {
     "snr_unpack_weight_grads": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.c_int, _P]),
     "snr_mask_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "snr_precision_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64]),
-    "snr_decoder_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "snr_decoder_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "snr_decoder_bwd_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int]),
-    "snr_decoder_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P,
+    "snr_decoder_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P,
                                   C.c_size_t, C.c_int, _P]),
     "snr_render_fwd": (C.c_int, [C.POINTER(RenderArgs), _P, _P, _P, _P, _P, _P, _P]),
     "snr_render_bwd_ws_bytes": (C.c_size_t, [C.POINTER(RenderArgs)]),
@@ -67,7 +67,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)       # AttributeError if the header and the library disagree
             fn.restype, fn.argtypes = res, args
-        if l.snr_abi_version() != 2:
+        if l.snr_abi_version() != 3:
             raise SnrError("libsupnerf_hip.so ABI version mismatch")
         _lib = l
     return _lib

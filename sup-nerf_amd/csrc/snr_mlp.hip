@@ -24,7 +24,7 @@ namespace snr {
 // lane's point p = lane & 31 (both half-waves hold the same point).  Outputs sigma, r, g, b valid in
 // every lane.  All four waves of the workgroup must call it together (block-wide barriers inside).
 // -------------------------------------------------------------------------------------------
-__device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const Layout& L, float* lds, long long gp /*clamped point id*/,
+__device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const Layout& L, float* lds, long long gp /*clamped point id*/, bool live,
                                                      long long tile32, float x, float y, float z, float dx, float dy, float dz,
                                                      float& o_sigma, float& o_r, float& o_g, float& o_b) {
     const int tid = threadIdx.x;
@@ -86,6 +86,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         const int la = latent_after(0, sb, tb);
         epilogue<8, 8>(acc, in, true, la >= 0 ? lat + la * 256 : nullptr, h, mask);
         if (io.masks) io.masks[(tile32 * n_relu + 0) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
+        if (io.act && live) dump_operand<8>(in, io.act + ((long long)0 * io.n_points + gp) * 256, h);
     }
 
     // ---- the 256-wide middle layers: shape blocks, enc_shape, enc_viewdir, texture blocks
@@ -110,6 +111,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         epilogue<8, 8>(acc, in, relu, la >= 0 ? lat + la * 256 : nullptr, h, mask);
         if (relu && io.masks)
             io.masks[(tile32 * n_relu + relu_slot(li, sb)) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
+        if (io.act && live) dump_operand<8>(in, io.act + ((long long)li * io.n_points + gp) * 256, h);
         if (li == li_encshape) {
             // density head: softplus(w_sigma . y + b)   (src/model_supnerf.py:257)
             const float* ws = io.packed + L.sigma_w;
@@ -139,6 +141,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     step<4, 8>(acc, in[7], pipe, lds, 0, tid);
     epilogue<4, 8>(acc, in, true, nullptr, h, mask);
     if (io.masks) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mask[0], mask[1], 0u, 0u);
+    if (io.act && live) dump_operand<4>(in, io.act + ((long long)(li_last + 1) * io.n_points + gp) * 256, h);
     {
         const float* w2 = io.packed + L.rgb2_w;
         float pr = 0.f, pg = 0.f, pb = 0.f;
@@ -187,7 +190,7 @@ decoder_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const 
         x = sp.x; y = sp.y; z = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc;
     }
     float sg, cr, cg, cb;
-    decoder_forward_tile(io, L, lds, gp, tile128 * 4 + wave, x, y, z, dx, dy, dz, sg, cr, cg, cb);
+    decoder_forward_tile(io, L, lds, gp, live, tile128 * 4 + wave, x, y, z, dx, dy, dz, sg, cr, cg, cb);
     if (live && lane < 32) {
         if (io.sigmas) io.sigmas[gp] = sg;
         if (io.rgbs) { io.rgbs[gp * 3] = cr; io.rgbs[gp * 3 + 1] = cg; io.rgbs[gp * 3 + 2] = cb; }
@@ -237,12 +240,14 @@ int snr_precision_supported(int precision, int sb, int tb, int64_t points_per_ob
 }
 
 int snr_decoder_fwd(const float* xyz, const float* viewdir, const float* latent, const float* packed, int64_t n_points,
-                    int64_t points_per_obj, int sb, int tb, float* sigmas, float* rgbs, void* relu_masks, int precision, void* stream_) {
+                    int64_t points_per_obj, int sb, int tb, float* sigmas, float* rgbs, void* relu_masks, float* activations, int precision,
+                    void* stream_) {
     if (!xyz || !viewdir || !latent || !packed) return SNR_E_ARG;
+    if (activations && precision != SNR_FP32) return SNR_E_UNSUPPORTED;      /* training dumps come from the fp32 kernels */
     if (sb < 0 || tb < 0 || sb > MAX_BLOCKS || tb > MAX_BLOCKS || n_points < 0) return SNR_E_ARG;
     if (points_per_obj < 1 || (n_points % points_per_obj) != 0) return SNR_E_SHAPE;
     if (n_points == 0) return SNR_OK;
-    DecoderIO io{packed, latent, sb, tb, (long long)n_points, (long long)points_per_obj, sigmas, rgbs, (uint4*)relu_masks};
+    DecoderIO io{packed, latent, sb, tb, (long long)n_points, (long long)points_per_obj, sigmas, rgbs, (uint4*)relu_masks, activations, false};
     RayGeom g{};
     const Layout L = make_layout(sb, tb);
     if (precision == SNR_BF16X3) {
@@ -265,7 +270,7 @@ int snr_render_fwd(const snr_render_args* a, float* rgb, float* depth, float* ac
     if (a->n_rays == 0) return SNR_OK;
     const long long P = a->n_rays * a->n_samples;
     DecoderIO io{a->packed, a->latent, a->shape_blocks, a->texture_blocks, P, a->rays_per_obj * a->n_samples, sigmas, rgbs,
-                 (uint4*)relu_masks};
+                 (uint4*)relu_masks, nullptr, false};
     const Layout L = make_layout(a->shape_blocks, a->texture_blocks);
     if (a->precision == SNR_BF16X3) {
         if (!snr_bf16_supported_(a->shape_blocks, a->texture_blocks, a->rays_per_obj * a->n_samples)) return SNR_E_UNSUPPORTED;

@@ -184,6 +184,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
                 }
             }
     }
+    if (io.gdump && live) dump_operand<4>(in, io.gdump + ((long long)(li_last + 1) * io.n_points + gp) * 256, h);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -203,6 +204,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
         // acc = gradient wrt the OUTPUT of layer li; enc_shape's output also feeds the density head
         masked_to_operand<8>(acc, in, relu ? io.masks + (tile32 * n_relu + relu_slot(li, sb)) * 64 + lane : nullptr,
                              li == li_encshape ? io.packed + L.sigma_w : nullptr, dpre, h);
+        if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)li * io.n_points + gp) * 256, h);
         acc_zero<9>(acc);
         const int rows = rows_of(li), rows_after = rows_of(li - 1);
         step<8, 9>(acc, in[0], pipe, lds, rows, tid, is_view);
@@ -224,6 +226,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
 
     // ---- enc_xyz^T : 256 -> 64 positional-encoding features
     masked_to_operand<8>(acc, in, io.masks + (tile32 * n_relu + 0) * 64 + lane, nullptr, 0.f, h);
+    if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)0 * io.n_points + gp) * 256, h);
     acc_zero<2>(acc);
     step<2, 9>(acc, in[0], pipe, lds, 64, tid);
     step<2, 9>(acc, in[1], pipe, lds, 64, tid);
@@ -361,7 +364,8 @@ size_t snr_decoder_bwd_ws_bytes(int64_t n_points, int64_t points_per_obj, int sb
 
 int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent, const float* packed, const void* relu_masks,
                     const float* sigmas, const float* d_sigmas, const float* d_rgbs, int64_t n_points, int64_t points_per_obj, int sb,
-                    int tb, float* d_latent, float* d_xyz, float* d_viewdir, void* workspace, size_t ws_bytes, int precision, void* stream_) {
+                    int tb, float* d_latent, float* d_xyz, float* d_viewdir, float* layer_grads, void* workspace, size_t ws_bytes, int precision,
+                    void* stream_) {
     if (n_points == 0) return SNR_OK;
     if (!xyz || !viewdir || !latent || !packed || !relu_masks || !sigmas) return SNR_E_ARG;
     if (sb < 0 || tb < 0 || sb > MAX_BLOCKS || tb > MAX_BLOCKS || n_points < 0) return SNR_E_ARG;
@@ -376,6 +380,8 @@ int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent,
     io.masks = (const uint4*)relu_masks; io.sigmas = sigmas; io.d_sigmas = d_sigmas; io.d_rgbs = d_rgbs;
     io.partial = want_lat ? (float*)workspace : nullptr;
     io.d_xyz = d_xyz; io.d_dir = d_viewdir;
+    io.gdump = layer_grads;
+    if (layer_grads && precision != SNR_FP32) return SNR_E_UNSUPPORTED;
     RayGeom g{};
     const Layout L = make_layout(sb, tb);
     int rc;

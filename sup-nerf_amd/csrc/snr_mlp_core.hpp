@@ -134,7 +134,21 @@ struct DecoderIO {
     float* sigmas;            // (P) optional
     float* rgbs;              // (P,3) optional
     uint4* masks;             // optional
+    float* act;               // optional, training: inputs of MFMA layers 1..NL-1 and of rgb.2, [slot][P][256]
+    bool live;                // this lane's point exists (set per lane by the kernel)
 };
+
+// registers (operand layout) -> row-major [P][256] dump of NT*32 features of one point
+template <int NT>
+__device__ __forceinline__ void dump_operand(const float (&in)[9][16], float* __restrict__ row /* base of this point's 256 floats */, int h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = {in[t][4 * j], in[t][4 * j + 1], in[t][4 * j + 2], in[t][4 * j + 3]};
+            *reinterpret_cast<f32x4*>(row + 32 * t + 8 * j + 4 * h) = v;
+        }
+}
 
 struct BwdIO {
     const float* packed;
@@ -156,6 +170,7 @@ struct BwdIO {
     float* d_rays_o;         // (N,3) render mode, nullable
     float* d_rays_d;         // (N,3)
     float* d_t;              // (N,S) per-ray depths only
+    float* gdump;            // optional, training: gradient wrt the pre-activation of every MFMA layer, [layer][P][256]
 };
 
 }  // namespace snr

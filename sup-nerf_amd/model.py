@@ -50,6 +50,9 @@ class _DecoderBase(nn.Module):
         self._packed_key = None
         # arithmetic of the per-point GEMMs: "fp32" (exact), "bf16x3" (split-bf16) or "auto" (bf16x3 where supported)
         self.precision = "auto"
+        # False (optimise / inference, the default): codes, latent layers and poses receive gradients, the per-point decoder
+        # weights are constants.  True (training): forward() also differentiates the per-point weights (fp32 kernels).
+        self.train_decoder_weights = False
 
     # ---- packed per-point weights, re-packed only when a tensor changed
     def _per_point_params(self):
@@ -60,9 +63,6 @@ class _DecoderBase(nn.Module):
         pp = self._per_point_params()
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in pp.values())
         if self._packed is None or key != self._packed_key:
-            if torch.is_grad_enabled() and getattr(self, "train_decoder_weights", False):
-                raise NotImplementedError("gradients wrt the per-point decoder weights (training mode) are not built yet; "
-                                          "this path differentiates codes and poses only")
             self._packed = ops.pack_weights(pp, self.shape_blocks, self.texture_blocks)
             self._packed_key = key
         return self._packed
@@ -83,6 +83,12 @@ class _DecoderBase(nn.Module):
             raise SnrError("the number of rays must be divisible by the number of codes (object-major batching)")
         lead = xyz.shape[:-1]
         lat = self.latent_terms(shape_latent, texture_latent)
+        if self.train_decoder_weights and torch.is_grad_enabled():
+            # training mode (src/trainer_unified_nuscenes.py:120-129,334): gradients also reach the per-point decoder weights
+            w = [p for p in self._per_point_params().values()]
+            sig, rgb = ops.DecoderPointsTrain.apply(xyz.reshape(-1, 3), viewdir.reshape(-1, 3), lat, self.shape_blocks,
+                                                    self.texture_blocks, *w)
+            return sig.view(*lead, 1), rgb.view(*lead, 3)
         sig, rgb = ops.DecoderPoints.apply(xyz.reshape(-1, 3), viewdir.reshape(-1, 3), lat, self.packed_weights(),
                                            self.shape_blocks, self.texture_blocks, self.precision)
         return sig.view(*lead, 1), rgb.view(*lead, 3)

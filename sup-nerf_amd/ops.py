@@ -151,7 +151,7 @@ class Composite(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------ decoder on points
-def decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=False, precision="fp32"):
+def decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=False, precision="fp32", activations=None):
     """xyz, viewdir (P,3); latent (B,NLAT,256) -> sigmas (P,), rgbs (P,3)[, relu masks]."""
     xyz, viewdir, latent = _f32c(xyz), _f32c(viewdir), _f32c(latent)
     _need_gpu(xyz, viewdir, latent, packed)
@@ -167,14 +167,14 @@ def decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save
         masks = torch.empty(_lib.lib().snr_mask_bytes(P, shape_blocks, texture_blocks), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         check(_lib.lib().snr_decoder_fwd(_p(xyz), _p(viewdir), _p(latent), _p(packed), P, P // B if B else 1, shape_blocks,
-                                         texture_blocks, _p(sig), _p(rgb), _p(masks),
+                                         texture_blocks, _p(sig), _p(rgb), _p(masks), _p(activations),
                                          resolve_precision(precision, shape_blocks, texture_blocks, P // B if B else 1), _stream(dev)),
               "snr_decoder_fwd")
     return sig, rgb, masks
 
 
 def decoder_bwd(xyz, viewdir, latent, packed, masks, sigmas, d_sig, d_rgb, shape_blocks, texture_blocks,
-                need_latent=True, need_xyz=True, need_dir=True, precision="fp32"):
+                need_latent=True, need_xyz=True, need_dir=True, precision="fp32", layer_grads=None):
     P, B = xyz.shape[0], latent.shape[0]
     dev = xyz.device
     d_latent = torch.empty_like(latent) if need_latent else None
@@ -185,7 +185,7 @@ def decoder_bwd(xyz, viewdir, latent, packed, masks, sigmas, d_sig, d_rgb, shape
     with torch.cuda.device(dev):
         check(_lib.lib().snr_decoder_bwd(_p(xyz), _p(viewdir), _p(latent), _p(packed), _p(masks), _p(sigmas), _p(_f32c(d_sig)),
                                          _p(_f32c(d_rgb)), P, P // B, shape_blocks, texture_blocks, _p(d_latent), _p(d_xyz),
-                                         _p(d_dir), _p(ws), ws_bytes, resolve_precision(precision, shape_blocks, texture_blocks, P // B),
+                                         _p(d_dir), _p(layer_grads), _p(ws), ws_bytes, resolve_precision(precision, shape_blocks, texture_blocks, P // B),
                                          _stream(dev)), "snr_decoder_bwd")
     return d_latent, d_xyz, d_dir
 
@@ -212,6 +212,72 @@ class DecoderPoints(torch.autograd.Function):
         d_lat, d_xyz, d_dir = decoder_bwd(xyz, viewdir, latent, packed, masks, sig, d_sig, d_rgb, sb, tb,
                                           ctx.needs_input_grad[2], ctx.needs_input_grad[0], ctx.needs_input_grad[1], precision=prec)
         return d_xyz, d_dir, d_lat, None, None, None, None
+
+
+class DecoderPointsTrain(torch.autograd.Function):
+    """Training-mode decoder (SURVEY 8a9 mode B): like DecoderPoints but the per-point decoder WEIGHTS are inputs too and
+    receive gradients.  The fp32 kernels additionally write every layer's input X_l (forward) and pre-activation
+    gradient G_l (backward) to HBM, and the weight gradients are plain GEMMs dW_l = G_l^T X_l, db_l = sum_p G_l on the
+    library BLAS (hipBLASLt through torch.matmul).  ``weights`` = the per-point tensors in per_point_tensor_names order."""
+
+    @staticmethod
+    def forward(ctx, xyz, viewdir, latent, shape_blocks, texture_blocks, *weights):
+        xyz, viewdir, latent = _f32c(xyz), _f32c(viewdir), _f32c(latent)
+        names = per_point_tensor_names(shape_blocks, texture_blocks)
+        packed = pack_weights(dict(zip(names, weights)), shape_blocks, texture_blocks)
+        P, dev = xyz.shape[0], xyz.device
+        n_slots = shape_blocks + texture_blocks + 4
+        act = torch.empty(n_slots, P, 256, device=dev)
+        sig, rgb, masks = decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=True, precision="fp32",
+                                      activations=act)
+        ctx.save_for_backward(xyz, viewdir, latent, packed, masks, sig, act, *weights)
+        ctx.cfg = (shape_blocks, texture_blocks)
+        return sig, rgb
+
+    @staticmethod
+    def backward(ctx, d_sig, d_rgb):
+        xyz, viewdir, latent, packed, masks, sig, act, *weights = ctx.saved_tensors
+        sb, tb = ctx.cfg
+        P, dev = xyz.shape[0], xyz.device
+        n_slots = sb + tb + 4
+        G = torch.empty(n_slots, P, 256, device=dev)
+        d_sig, d_rgb = _f32c(d_sig), _f32c(d_rgb)
+        d_lat, d_xyz, d_dir = decoder_bwd(xyz, viewdir, latent, packed, masks, sig, d_sig, d_rgb, sb, tb,
+                                          ctx.needs_input_grad[2], ctx.needs_input_grad[0], ctx.needs_input_grad[1], precision="fp32",
+                                          layer_grads=G)
+        # ---- weight gradients: one GEMM per layer (X of layer 0 and the direction features are recomputed, they are tiny)
+        def pe(v, L):
+            arg = torch.cat([v * (2.0 ** i) for i in range(L)], -1)
+            return torch.cat([v, torch.sin(arg), torch.cos(arg)], -1)
+        li_view, li_rgb0 = sb + 2, sb + tb + 3
+        grads = []
+        for li in range(n_slots):              # MFMA layers in order; the two small heads are interleaved below
+            g = G[li, :, :128] if li == li_rgb0 else G[li]
+            if li == 0:
+                x_in = pe(xyz, 10)
+            elif li == li_view:
+                x_in = torch.cat([act[li - 1], pe(viewdir, 4)], -1)
+            else:
+                x_in = act[li - 1]
+            dW, db = g.t() @ x_in, g.sum(0)
+            grads.append((li, dW, db))
+        by_layer = {li: (dW, db) for li, dW, db in grads}
+        # sigma head: pre = w . y4 + b with y4 = input of enc_viewdir; d pre = d_sig * sigmoid(pre) = d_sig * (1 - exp(-sigma))
+        dpre = d_sig * (1 - torch.exp(-sig))
+        y4 = act[li_view - 1]
+        d_sigma_w, d_sigma_b = (dpre[None, :] @ y4), dpre.sum().reshape(1)
+        h7 = act[n_slots - 1][:, :128]
+        d_rgb2_w, d_rgb2_b = d_rgb.t() @ h7, d_rgb.sum(0)
+        out = []
+        order = [0] + list(range(1, sb + 1)) + [sb + 1, "sigma", li_view] + list(range(sb + 3, sb + 3 + tb)) + [li_rgb0, "rgb2"]
+        for k in order:
+            if k == "sigma":
+                out += [d_sigma_w, d_sigma_b]
+            elif k == "rgb2":
+                out += [d_rgb2_w, d_rgb2_b]
+            else:
+                out += list(by_layer[k])
+        return (d_xyz, d_dir, d_lat, None, None, *out)
 
 
 # ------------------------------------------------------------------------------------ fused render

@@ -268,6 +268,36 @@ def test_training_shapes_volume_rendering_batch(amd, dev, model, golden):
     assert close_grad(sc.grad, g["d_shapecode"]) and close_grad(tc.grad, g["d_texturecode"])
 
 
+def test_training_step_weight_gradients(amd, dev, oracle_params, golden):
+    """Training mode (src/trainer_unified_nuscenes.py:120-129,334): loss.backward() also reaches every decoder weight.
+    Checked against the reference's own gradients: every bias and small tensor in full, every weight's first row,
+    and sum / abs-sum of every tensor."""
+    g = golden("train_step")
+    m = amd.CodeNeRF(shape_blocks=3, texture_blocks=1)
+    m.load_state_dict(oracle_params, strict=True)
+    m = m.to(dev)
+    m.train_decoder_weights = True
+    B, n, S = g["xyz"].shape[:3]
+    sc = g["shapecode"].to(dev).requires_grad_()
+    tc = g["texturecode"].to(dev).requires_grad_()
+    sig, rgb = m(g["xyz"].flatten(0, 1).to(dev), g["viewdir"].flatten(0, 1).to(dev), sc, tc)
+    out = amd.utils.volume_rendering_batch(sig.view(B, n, S, 1), rgb.view(B, n, S, 3), g["z_vals"].to(dev))
+    loss = ((out[0] - g["tgt"].to(dev)) ** 2).mean() + 0.1 * out[2].mean()
+    loss.backward()
+    assert md(out[0], g["rgb"]) < TOL_RGB and abs(float(loss) - float(g["loss"])) < 1e-5
+    assert close_grad(sc.grad, g["d_shapecode"]) and close_grad(tc.grad, g["d_texturecode"])
+    for name, p in m.named_parameters():
+        key = name.replace(".", "_")
+        assert p.grad is not None, name
+        sums = g["dWsum_" + key].double()
+        got = torch.stack([p.grad.double().sum(), p.grad.double().abs().sum()]).cpu()
+        assert float((got - sums).abs().max()) <= 2e-4 * float(sums[1]) + 1e-7, (name, got, sums)
+        if "dW_" + key in g:
+            assert close_grad(p.grad, g["dW_" + key]), name
+        if "dWrow0_" + key in g:
+            assert close_grad(p.grad[0], g["dWrow0_" + key]), name
+
+
 # ------------------------------------------------------------------ batched objects, full size properties
 def test_batched_objects_equal_single_objects(amd, dev, model):
     """C3 shape in miniature: B objects in one launch == B single-object launches (object-major codes, per-object z)."""
