@@ -522,6 +522,23 @@ def optimise_losses(rgb_rays, acc_trans_rays, rgb_tgt, occ_pixels, loss_occ_coef
     return loss, loss_rgb, loss_occ, psnr
 
 
+def training_losses(params, xyz_batch, viewdir_batch, shapecode_batch, texturecode_batch, z_vals_batch, rgb_tgt_batch,
+                    occ_pixels_batch, loss_occ_coef=0.1):
+    """NeRF half of ParallelModel.forward (src/trainer_unified_nuscenes.py:117-148): per-object masked losses, then the
+    mean over the objects of the batch.  Returns (loss_total, loss_rgb, loss_occ, loss_reg, psnr)."""
+    B, n, S = xyz_batch.shape[:3]
+    sig, rgb = decoder_forward(params, xyz_batch.flatten(0, 1), viewdir_batch.flatten(0, 1), shapecode_batch, texturecode_batch)
+    rgb_rays, _, acc = volume_rendering_batch(sig.view(B, n, S, 1), rgb.view(B, n, S, 3), z_vals_batch)
+    a = torch.abs(occ_pixels_batch)
+    denom = torch.sum(a, dim=[-2, -1]) + 1e-9
+    loss_rgb = torch.sum((rgb_rays - rgb_tgt_batch) ** 2 * a, dim=[-2, -1]) / denom
+    loss_occ = torch.sum(torch.exp(-occ_pixels_batch * (0.5 - acc.unsqueeze(-1))) * a, dim=[-2, -1]) / denom
+    loss_reg = torch.norm(shapecode_batch, dim=-1) + torch.norm(texturecode_batch, dim=-1)
+    psnr = -10.0 * torch.log(loss_rgb.mean()) / math.log(10.0)
+    total = loss_rgb.mean() + loss_occ_coef * loss_occ.mean()
+    return total, loss_rgb.mean(), loss_occ.mean(), loss_reg.mean(), psnr.detach()
+
+
 # --------------------------------------------------------------------------
 # synthetic "nuScenes car" objects (SURVEY.md section 8d) -- shared by tests & bench
 # --------------------------------------------------------------------------

@@ -76,3 +76,48 @@ def test_sharded_objects_single_process():
     assert full.shape == (3, 12) and bool(torch.isfinite(full).all())
     # rank 1 of 2 owns object 2 only (tail kept); same seeds -> same rows as in the full run up to the jitter stream
     assert list(D.shard_slice(3, 2, 1)) == [2]
+
+
+def test_training_step_matches_oracle(oracle_params):
+    """supnerf_amd.trainer.train_step on the HIP training path: losses and EVERY gradient of the first
+    iteration against the oracle's autograd on the CPU, then three more iterations must keep lowering the loss."""
+    import supnerf_amd
+    T = supnerf_amd.trainer
+    dev = torch.device("cuda:0")
+    m = supnerf_amd.CodeNeRF(shape_blocks=3, texture_blocks=1)
+    m.load_state_dict(oracle_params, strict=True)
+    m = m.to(dev)
+    m.train_decoder_weights = True
+    codes = T.CodeTables(5, 256, seed=4).to(dev)
+    g = torch.Generator().manual_seed(21)
+    B, n, S = 2, 32, 64
+    batch = dict(code_idx=torch.tensor([3, 1]), xyz=torch.rand(B, n, S, 3, generator=g) - 0.5,
+                 viewdir=torch.nn.functional.normalize(torch.randn(B, n, 1, 3, generator=g), dim=-1).repeat(1, 1, S, 1),
+                 z_vals=torch.sort(torch.rand(B, S, generator=g) * 4 + 9, dim=-1)[0], rgb_tgt=torch.rand(B, n, 3, generator=g),
+                 occ_pixels=(torch.randint(0, 3, (B, n, 1), generator=g) - 1).float())
+    # oracle gradients (CPU autograd)
+    p_cpu = {k: v.detach().cpu().clone().requires_grad_() for k, v in m.named_parameters()}
+    w_sc = codes.shape_codes.weight.detach().cpu().clone().requires_grad_()
+    w_tc = codes.texture_codes.weight.detach().cpu().clone().requires_grad_()
+    ref = O.training_losses(p_cpu, batch["xyz"], batch["viewdir"], w_sc[batch["code_idx"]], w_tc[batch["code_idx"]], batch["z_vals"],
+                            batch["rgb_tgt"], batch["occ_pixels"], 0.1)
+    ref[0].backward()
+    # product path
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    params = list(m.parameters()) + list(codes.parameters())
+    bucket = T.GradBucket(params)
+    sc, tc = codes(batch["code_idx"])
+    losses_all, total = T.nerf_losses(m, batch["xyz"], batch["viewdir"], sc, tc, batch["z_vals"], batch["rgb_tgt"], batch["occ_pixels"], 0.1)
+    total.backward()
+    bucket.check_views()
+    assert abs(float(total) - float(ref[0])) < 1e-5 and abs(float(losses_all["psnr"]) - float(ref[4])) < 0.01
+    assert abs(float(losses_all["loss_reg"]) - float(ref[3])) < 1e-5
+    for (name, p) in list(m.named_parameters()) + [("shape_codes", codes.shape_codes.weight), ("texture_codes", codes.texture_codes.weight)]:
+        want = {"shape_codes": w_sc, "texture_codes": w_tc}.get(name, p_cpu.get(name)).grad
+        err = float((p.grad.cpu() - want).abs().max())
+        assert err <= 2e-4 * float(want.abs().max()) + 1e-7, (name, err, float(want.abs().max()))
+    bucket.zero()
+    hp = dict(lr_schedule=[dict(lr=1e-4, interval=100), dict(lr=1e-3, interval=100)])
+    opt = T.make_optimizer(m, codes, hp)
+    trace = [float(T.train_step(m, codes, opt, bucket, batch, 0.1)["loss_total"]) for _ in range(4)]
+    assert all(b < a for a, b in zip(trace, trace[1:])), trace

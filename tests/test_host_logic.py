@@ -196,6 +196,93 @@ def test_metric_gather_two_ranks_gloo(tmp_path):
     assert all("ok" in o for o in outs)
 
 
+_TRAIN_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+import supnerf_amd
+from supnerf_amd import trainer as T
+from oracle import supnerf_oracle as O
+rank = int(sys.argv[1])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+torch.set_num_threads(2)
+hp = dict(lr_schedule=[dict(lr=1e-3, interval=100), dict(lr=1e-2, interval=100)])
+
+
+def world(seed_codes=3):
+    m = supnerf_amd.CodeNeRF(shape_blocks=1, texture_blocks=1)          # parameters only; the CPU forward below is the oracle's
+    m.load_state_dict(O.init_decoder_params(seed=0, shape_blocks=1, texture_blocks=1), strict=True)
+    codes = T.CodeTables(4, 256, seed=seed_codes)
+    fwd = lambda xyz, vd, sc, tc: O.decoder_forward(dict(m.named_parameters()), xyz, vd, sc, tc)
+    params = list(m.parameters()) + list(codes.parameters())
+    return m, codes, fwd, params
+
+
+g = torch.Generator().manual_seed(11)
+B, n, S = 2, 6, 8
+full = dict(code_idx=torch.tensor([2, 0]), xyz=torch.rand(B, n, S, 3, generator=g) - 0.5,
+            viewdir=torch.nn.functional.normalize(torch.randn(B, n, 1, 3, generator=g), dim=-1).repeat(1, 1, S, 1),
+            z_vals=torch.sort(torch.rand(B, S, generator=g) * 4 + 9, dim=-1)[0], rgb_tgt=torch.rand(B, n, 3, generator=g),
+            occ_pixels=torch.tensor([1., -1., 0., 1., 1., -1.]).view(1, n, 1).repeat(B, 1, 1))
+mine = {{k: v[rank:rank + 1] for k, v in full.items()}}
+
+# two ranks, one object each, two iterations
+m, codes, fwd, params = world()
+bucket = T.GradBucket(params)
+opt = T.make_optimizer(m, codes, hp)
+for it in range(2):
+    out = T.train_step(fwd, codes, opt, bucket, mine, 0.1, composite=O.volume_rendering_batch)
+
+# the same two iterations in one process on the whole batch (what DataParallel's loss.mean() computes)
+m1, codes1, fwd1, params1 = world()
+opt1 = T.make_optimizer(m1, codes1, hp)
+for it in range(2):
+    sc, tc = codes1(full["code_idx"])
+    total = O.training_losses(dict(m1.named_parameters()), full["xyz"], full["viewdir"], sc, tc, full["z_vals"], full["rgb_tgt"],
+                              full["occ_pixels"], 0.1)[0]
+    opt1.zero_grad()
+    total.backward()
+    opt1.step()
+worst = max(float((a - b).abs().max()) for a, b in zip(params, params1))
+assert worst < 2e-5, worst          # AdamW normalises: rounding of near-zero gradients is amplified to ~1e-4 of a step
+flat = torch.cat([p.detach().flatten() for p in params])
+other = [torch.empty_like(flat) for _ in range(2)]
+dist.all_gather(other, flat)
+assert torch.equal(other[0], other[1])                      # replicas stay bit-identical
+assert float(bucket.flat.abs().max()) == 0.0                # zeroed for the next iteration, views intact
+bucket.check_views()
+dist.destroy_process_group()
+print("ok", rank, worst)
+"""
+
+
+def test_training_step_two_ranks_gloo(tmp_path):
+    """DDP-style step: per-rank batch slice + one bucket all-reduce == single-process step on the full batch."""
+    port = 31500 + (os.getpid() % 2000)
+    script = tmp_path / "t.py"
+    script.write_text(_TRAIN_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
+
+
+def test_grad_bucket_and_lr_schedule(amd):
+    T = amd.trainer
+    lin = torch.nn.Linear(4, 3)
+    b = T.GradBucket(lin.parameters())
+    lin(torch.ones(2, 4)).sum().backward()
+    assert b.flat.numel() == 15 and torch.equal(b.flat[:12].view(3, 4), torch.full((3, 4), 2.0)) and torch.equal(b.flat[12:], torch.full((3,), 2.0))
+    b.allreduce_mean()                                           # no process group: a no-op
+    lin.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError):
+        b.check_views()
+    hp = dict(lr_schedule=[dict(lr=1e-4, interval=10), dict(lr=1e-3, interval=4)])
+    assert T.learning_rates(hp, 0) == (1e-4, 1e-3) and T.learning_rates(hp, 25) == (1e-4 / 4, 1e-3 / 64)
+    c = T.CodeTables(3, 256, mean_shape=torch.ones(1, 256), mean_texture=torch.zeros(1, 256))
+    assert float(c.shape_codes.weight.min()) == 1.0 and float(c.texture_codes.weight.abs().max()) == 0.0
+
+
 def test_reference_file_formats_round_trip(amd, tmp_path):
     """models.pth / codes+poses.pth with the reference's keys (src/trainer_unified_nuscenes.py:476-490, src/optimizer_nuscenes.py:1463-1476)."""
     m = amd.SUPNeRF(shape_blocks=3, texture_blocks=1)
