@@ -156,6 +156,16 @@ int snr_render_bwd(const snr_render_args* a, const float* sigmas, const float* r
                    void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Multi-object scene pixels: replaces the per-pixel depth sort + scatter + volume_rendering3(white) of
+ * OptimizerDemo.vis_scene (scripts/demo.py:555-565).  Every pixel carries n_per_pixel = Nb * S samples (the S samples of
+ * each of Nb objects, any order; depth -1 marks empty space and carries sigma 0); they are merged by depth and composited.
+ * Samples of exactly equal depth collapse like the reference's scatter: the last one in memory order survives.  sigmas, z_vals (P, n); rgbs (P, n, 3) -> rgb (P,3), depth (P) [nullable], acc_trans (P) [nullable].
+ * flags: SNR_WHITE_BKGD.  n_per_pixel <= 1706 (LDS).
+ * ---------------------------------------------------------------------------------- */
+int snr_scene_composite_fwd(const float* sigmas, const float* rgbs, const float* z_vals, int64_t n_pixels, int n_per_pixel,
+                            int flags, float* rgb, float* depth, float* acc_trans, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Alpha composite alone: replaces volume_rendering2 / volume_rendering_batch
  * (src/utils.py:202-233), NeRFRenderer.volume_render (src/renderer.py:43-65) and
  * volume_rendering3 (src/renderer.py:355-379).

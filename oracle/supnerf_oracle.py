@@ -540,6 +540,139 @@ def training_losses(params, xyz_batch, viewdir_batch, shapecode_batch, textureco
 
 
 # --------------------------------------------------------------------------
+# multi-object scene compositing (scripts/demo.py:425-579, OptimizerDemo.vis_scene)
+# --------------------------------------------------------------------------
+
+def box_corners(obj_poses: Tensor, wlh: Tensor) -> Tensor:
+    """(Nb,3,8) corners of oriented boxes, nuScenes order (x forward, y left, z up).
+    Restates ``corners_of_box_batch(..., is_kitti=False)`` (src/utils.py:1110-1148)."""
+    sx = torch.tensor([1, 1, 1, 1, -1, -1, -1, -1], dtype=wlh.dtype)
+    sy = torch.tensor([1, -1, -1, 1, 1, -1, -1, 1], dtype=wlh.dtype)
+    sz = torch.tensor([1, 1, -1, -1, 1, 1, -1, -1], dtype=wlh.dtype)
+    w, l, h = wlh[:, 0:1], wlh[:, 1:2], wlh[:, 2:3]
+    local = torch.stack([l / 2 * sx, w / 2 * sy, h / 2 * sz], dim=1)            # (Nb,3,8)
+    return torch.matmul(obj_poses[:, :, :3], local) + obj_poses[:, :, 3:4]
+
+
+def project_points(points: Tensor, K: Tensor) -> Tensor:
+    """Perspective projection of (Nb,3,n) camera-frame points, (Nb,3,n) with rows (u, v, 1).
+    Restates ``view_points_batch(points, K, normalize=True)`` (src/utils.py:1032-1075)."""
+    uvw = torch.matmul(K, points)
+    return uvw / uvw[:, 2:3, :]
+
+
+def clip_roi(roi: Tensor, H: int, W: int) -> Tensor:
+    """``roi_process(roi, H, W, roi_margin=0, sq_pad=False)`` (src/utils.py:1392-1415): clip to the image."""
+    out = roi.clone()
+    out[0:2] = torch.maximum(out[0:2], torch.as_tensor(0))
+    out[2] = torch.minimum(out[2], torch.as_tensor(W - 1))
+    out[3] = torch.minimum(out[3], torch.as_tensor(H - 1))
+    return out
+
+
+def scene_rays(obj_poses: Tensor, obj_wlh: Tensor, K: Tensor, H: int, W: int, manipulation=(0.0, 0.0, 0.0),
+               rend_aabb: bool = True):
+    """Per-pixel, per-object ray table (H,W,Nb,8) = [origin/(diag/2) (3), unit dir (3), near, far] with -1 where an
+    object does not cover the pixel, plus the pixel mask of rays that hit anything and the diagonals.
+    Restates scripts/demo.py:437-523."""
+    Nb = obj_poses.shape[0]
+    all_rays = torch.ones((H, W, Nb, 8), dtype=torch.float32) * (-1)
+    poses = obj_poses.clone()
+    poses[:, :, 3] += torch.tensor(manipulation, dtype=torch.float32).unsqueeze(0)
+    uv = project_points(box_corners(poses, obj_wlh), K.unsqueeze(0).repeat(Nb, 1, 1))
+    rois = torch.stack([uv[:, 0].min(dim=1)[0], uv[:, 1].min(dim=1)[0], uv[:, 0].max(dim=1)[0], uv[:, 1].max(dim=1)[0]], dim=1)
+    rois = rois.type(torch.int32)
+    diags = []
+    for i in range(Nb):
+        roi = clip_roi(rois[i], H, W)
+        R_c2o = poses[i, :3, :3].transpose(0, 1)
+        cam_pose = torch.cat([R_c2o, -R_c2o @ poses[i, :3, 3:4]], dim=1)
+        rays_o, viewdir = pixel_rays(K, cam_pose, roi)
+        wlh = np.asarray(obj_wlh[i])
+        diag = np.linalg.norm(wlh).astype(np.float32)
+        diags.append(diag)
+        x0, y0, x1, y1 = [int(v) for v in roi]
+        all_rays[y0:y1, x0:x1, i, :3] = rays_o.view(y1 - y0, x1 - x0, -1) / (diag / 2)
+        all_rays[y0:y1, x0:x1, i, 3:6] = viewdir.view(y1 - y0, x1 - x0, -1)
+        if rend_aabb:
+            ow, ol, oh = wlh
+            bmax = np.asarray([ol / diag, ow / diag, oh / diag]).reshape(1, 3).repeat(rays_o.shape[0], axis=0)
+            o_np = rays_o.numpy() / (diag / 2)                 # numpy slab test, float64 box like the reference's np.asarray
+            t_near, t_far, hit = slab_intersect(torch.from_numpy(o_np), torch.from_numpy(viewdir.numpy().astype(o_np.dtype)),
+                                                torch.from_numpy(-bmax), torch.from_numpy(bmax))
+            near = all_rays[y0:y1, x0:x1, i, 6].flatten(0, 1)
+            far = all_rays[y0:y1, x0:x1, i, 7].flatten(0, 1)
+            near[hit] = t_near[hit].type(torch.float32)
+            far[hit] = t_far[hit].type(torch.float32)
+            all_rays[y0:y1, x0:x1, i, 6] = near.view(y1 - y0, x1 - x0)
+            all_rays[y0:y1, x0:x1, i, 7] = far.view(y1 - y0, x1 - x0)
+        else:
+            dist = torch.linalg.norm(cam_pose[:, -1])
+            all_rays[y0:y1, x0:x1, i, 6] = (dist - diag / 2) / (diag / 2)
+            all_rays[y0:y1, x0:x1, i, 7] = (dist + diag / 2) / (diag / 2)
+    diags = torch.tensor(diags, dtype=torch.float32)
+    valid = (all_rays[:, :, :, 7].view(H * W, Nb) - all_rays[:, :, :, 6].view(H * W, Nb)).max(-1)[0] > 0
+    return all_rays, valid, diags
+
+
+def scene_composite(sigmas: Tensor, rgbs: Tensor, z_vals: Tensor, white_bkgd: bool = True):
+    """Merge the Nb*S samples of a pixel by depth, then ``volume_rendering3``.  sigmas, z_vals (P, n); rgbs (P, n, 3).
+    Restates scripts/demo.py:555-565 including its scatter through ``searchsorted`` (equal depths collapse onto one
+    slot and leave zero-density slots behind)."""
+    z_sort = torch.sort(z_vals, 1).values
+    z_args = torch.searchsorted(z_sort, z_vals)
+    rgbs_sort = torch.zeros_like(rgbs).scatter_(1, z_args[:, :, None].repeat(1, 1, 3), rgbs)
+    sig_sort = torch.zeros_like(sigmas).scatter_(1, z_args, sigmas)
+    return composite(sig_sort, rgbs_sort, z_sort, white_bkgd=white_bkgd)
+
+
+def scene_batch_samples(batch_rays: Tensor, diags: Tensor, n_samples: int, jitter: Optional[Tensor] = None,
+                        adjust_scale: float = 1.0, shapenet_obj_cood: bool = True):
+    """Sample points of one ray batch (Nr, Nb, 8): object-major xyz / viewdir (Nb*Nr, S, 3) for the batched decoder,
+    metric depths z (Nr*Nb, S) and the empty-space mask.  Restates scripts/demo.py:528-551."""
+    Nr, Nb = batch_rays.shape[:2]
+    rays = batch_rays.reshape(-1, 8)
+    z_coarse = unit_interval_samples(rays[:, 6:7], rays[:, 7:8], n_samples, jitter)
+    empty = z_coarse == -1
+    xyz = rays[:, None, :3] + z_coarse[:, :, None] * rays[:, None, 3:6]
+    viewdir = rays[:, 3:6].unsqueeze(-2).repeat(1, n_samples, 1)
+    d = diags.view(1, -1, 1, 1).repeat(Nr, 1, 1, 1).flatten(0, 1)
+    z_vals = torch.norm((xyz - rays[:, None, :3]) * (d / 2), p=2, dim=-1)
+    z_vals[empty] = -1
+    xyz = xyz.view(Nr, Nb, n_samples, 3).permute(1, 0, 2, 3).flatten(0, 1) * adjust_scale
+    viewdir = viewdir.view(Nr, Nb, n_samples, 3).permute(1, 0, 2, 3).flatten(0, 1)
+    if shapenet_obj_cood:
+        xyz = xyz[:, :, [1, 0, 2]]; xyz[:, :, 0] *= (-1)
+        viewdir = viewdir[:, :, [1, 0, 2]]; viewdir[:, :, 0] *= (-1)
+    return xyz, viewdir, z_vals, empty
+
+
+def vis_scene(model, obj_poses, obj_wlh, shapecodes, texturecodes, K, H, W, n_samples, manipulation=(0.0, 0.0, 0.0),
+              ray_batch_size=2048, rend_aabb=True, shapenet_obj_cood=True, adjust_scale=1.0, jitters=None):
+    """Float canvas (H*W,3) and the uint8 image (H,W,3) of all objects rendered into one view (white background).
+    ``jitters``: list with one (Nr*Nb, S) draw per ray batch (the reference draws ``rand_like`` per batch)."""
+    all_rays, valid, diags = scene_rays(obj_poses, obj_wlh, K, H, W, manipulation, rend_aabb)
+    Nb = obj_poses.shape[0]
+    valid_rays = all_rays.view(H * W, -1, 8)[valid, ...]
+    out = []
+    with torch.no_grad():
+        for bi, batch in enumerate(torch.split(valid_rays, ray_batch_size)):
+            Nr = batch.shape[0]
+            jit = None if jitters is None else jitters[bi]
+            xyz, viewdir, z_vals, empty = scene_batch_samples(batch, diags, n_samples, jit, adjust_scale, shapenet_obj_cood)
+            sig, rgb = _decode(model, xyz, viewdir, shapecodes, texturecodes)
+            rgb = rgb.view(Nb, Nr, n_samples, 3).permute(1, 0, 2, 3).flatten(0, 1)
+            sig = sig.view(Nb, Nr, n_samples).permute(1, 0, 2).flatten(0, 1)
+            rgb[empty, ...] = 1
+            sig[empty] = 0
+            out.append(scene_composite(sig.view(-1, Nb * n_samples), rgb.view(-1, Nb * n_samples, 3), z_vals.view(-1, Nb * n_samples))[0])
+    canvas = torch.ones(H * W, 3)
+    if out:
+        canvas[valid, :] = torch.cat(out, 0)
+    return canvas, (canvas.view(H, W, 3).numpy() * 255).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------
 # synthetic "nuScenes car" objects (SURVEY.md section 8d) -- shared by tests & bench
 # --------------------------------------------------------------------------
 

@@ -4,7 +4,7 @@ Host side: Python on PyTorch-ROCm mirroring the reference's own function signatu
 (``utils.render_rays_v2`` ..., ``renderer.NeRFRenderer``, ``SUPNeRF.forward``).  Device side: hand-written
 HIP kernels in ``libsupnerf_hip.so`` behind the C ABI of ``include/supnerf_hip.h``.
 """
-from . import _lib, ops, model, utils, renderer, synthetic, driver, io, trainer  # noqa: F401
+from . import _lib, ops, model, utils, renderer, synthetic, driver, io, trainer, scene  # noqa: F401
 from ._lib import SnrError  # noqa: F401
 from .model import CodeNeRF, SUPNeRF  # noqa: F401
 from .renderer import NeRFRenderer, render_rays_v3, volume_rendering3  # noqa: F401

@@ -72,6 +72,72 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restr
     }
 }
 
+// ============================================================================ scene composite (multi-object pixels)
+// One wave per pixel.  The pixel's n = Nb*S samples (Nb per-object lists) are merged by depth with a rank sort in LDS --
+// every lane ranks its own elements against broadcast reads of the depth row -- then composited front to back with the same wave scan as every other composite here.  HBM-bound:
+// 20 B per sample in, 20 B per pixel out; the n^2/64 compares per lane stay below the load time up to n ~ 512.
+__global__ void __launch_bounds__(256) scene_composite_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                              const float* __restrict__ zv, long long n_pixels, int n, int flags,
+                                                              float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ acc) {
+    extern __shared__ __attribute__((aligned(16))) float scene_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* zs = scene_lds + (size_t)wave * 6 * n;          // unsorted depths | sorted sigma, r, g, b, z
+    float* s_sig = zs + n; float* s_r = s_sig + n; float* s_g = s_r + n; float* s_b = s_g + n; float* s_z = s_b + n;
+    const long long wave0 = (long long)blockIdx.x * 4 + wave;
+    const long long n_waves = (long long)gridDim.x * 4;
+    const bool white = flags & SNR_WHITE_BKGD;
+    for (long long pix = wave0; pix < n_pixels; pix += n_waves) {
+        const float* zrow = zv + pix * n;
+        const float* srow = sigmas + pix * n;
+        const float* crow = rgbs + pix * n * 3;
+        for (int i = lane; i < n; i += 64) zs[i] = zrow[i];
+        __builtin_amdgcn_wave_barrier();
+        // The reference scatters through searchsorted(sorted, z): samples with EQUAL depth land on one slot, the last one in
+        // memory order wins and the group's other slots keep zero density / zero colour (torch scatter_ on the CPU).  Equal
+        // depths are the rule for empty space (-1) and happen for ~1 % of pixels between real samples (fp32 depth grid), so
+        // that is reproduced: the sorted depth row is complete, data goes to the group's first slot from its last member.
+        for (int base = 0; base < n; base += 256) {           // up to four own elements per pass
+            float zi[4]; int lt[4], eb[4], ea[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int i = base + 64 * c + lane; zi[c] = (i < n) ? zs[i] : 0.f; lt[c] = eb[c] = ea[c] = 0; }
+            for (int j = 0; j < n; ++j) {
+                const float zj = zs[j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int i = base + 64 * c + lane;
+                    lt[c] += (zj < zi[c]) ? 1 : 0;
+                    eb[c] += (zj == zi[c] && j < i) ? 1 : 0;
+                    ea[c] += (zj == zi[c] && j > i) ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = base + 64 * c + lane;
+                if (i < n) {
+                    const int pos = lt[c] + eb[c];
+                    s_z[pos] = zi[c];
+                    if (eb[c] > 0) { s_sig[pos] = 0.f; s_r[pos] = 0.f; s_g[pos] = 0.f; s_b[pos] = 0.f; }
+                    if (ea[c] == 0) {
+                        const int r = lt[c];
+                        s_sig[r] = srow[i]; s_r[r] = crow[3 * i]; s_g[r] = crow[3 * i + 1]; s_b[r] = crow[3 * i + 2];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        RayOut o = composite_ray_fwd(n, lane, white, [&](int k, float& sg, float& cr, float& cg, float& cb, float& z, float& zn) {
+            sg = s_sig[k]; cr = s_r[k]; cg = s_g[k]; cb = s_b[k];
+            z = s_z[k]; zn = (k < n - 1) ? s_z[k + 1] : 0.f;
+        });
+        if (lane == 0) {
+            rgb[pix * 3] = o.r; rgb[pix * 3 + 1] = o.g; rgb[pix * 3 + 2] = o.b;
+            if (depth) depth[pix] = o.depth;
+            if (acc) acc[pix] = o.acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int NCH>
 __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                                                             const float* __restrict__ zv, int z_mode, int flags, long long n_rays,
@@ -339,6 +405,22 @@ int snr_composite_fwd(const float* sigmas, const float* rgbs, const float* z_val
     if (rays_per_obj < 1) rays_per_obj = n_rays;
     const int grid = grid_for(n_rays * 64, 256, 8192);
     composite_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(sigmas, rgbs, z_vals, z_mode, flags, n_rays, rays_per_obj, S, rgb, depth, acc);
+    return snr_check_launch_();
+}
+
+int snr_scene_composite_fwd(const float* sigmas, const float* rgbs, const float* z_vals, int64_t n_pixels, int n_per_pixel, int flags,
+                            float* rgb, float* depth, float* acc, void* stream_) {
+    if (n_pixels == 0) return SNR_OK;
+    if (!sigmas || !rgbs || !z_vals || !rgb) return SNR_E_ARG;
+    if (n_pixels < 0 || n_per_pixel < 1) return SNR_E_ARG;
+    const size_t lds = (size_t)4 * 6 * n_per_pixel * sizeof(float);
+    if (lds > 160 * 1024) return SNR_E_UNSUPPORTED;            /* more than 1706 samples per pixel */
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scene_composite_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return snr_check_launch_();
+    }
+    const int grid = grid_for(n_pixels * 64, 256, 8192);
+    scene_composite_kernel<<<grid, 256, lds, (hipStream_t)stream_>>>(sigmas, rgbs, z_vals, n_pixels, n_per_pixel, flags, rgb, depth, acc);
     return snr_check_launch_();
 }
 

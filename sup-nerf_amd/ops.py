@@ -112,6 +112,22 @@ def composite_fwd(sigmas, rgbs, z_vals, z_mode, white_bkgd, rays_per_obj=0):
     return rgb, depth, acc
 
 
+def scene_composite(sigmas, rgbs, z_vals, white_bkgd=True):
+    """Per-pixel depth merge of n = Nb*S samples + composite (scripts/demo.py:555-565): sigmas, z_vals (P, n); rgbs (P, n, 3)
+    -> rgb (P,3), depth (P), acc_trans (P).  Inference only (the reference runs it under no_grad)."""
+    sigmas, rgbs, z_vals = _f32c(sigmas), _f32c(rgbs), _f32c(z_vals)
+    _need_gpu(sigmas, rgbs, z_vals)
+    if sigmas.dim() != 2 or rgbs.shape != (*sigmas.shape, 3) or z_vals.shape != sigmas.shape:
+        raise SnrError(f"scene_composite: expected sigmas/z (P,n) and rgbs (P,n,3), got {tuple(sigmas.shape)}, {tuple(z_vals.shape)}, {tuple(rgbs.shape)}")
+    P, n = sigmas.shape
+    dev = sigmas.device
+    rgb = torch.empty(P, 3, device=dev); depth = torch.empty(P, device=dev); acc = torch.empty(P, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().snr_scene_composite_fwd(_p(sigmas), _p(rgbs), _p(z_vals), P, n, WHITE_BKGD if white_bkgd else 0,
+                                                 _p(rgb), _p(depth), _p(acc), _stream(dev)), "snr_scene_composite_fwd")
+    return rgb, depth, acc
+
+
 def composite_bwd(sigmas, rgbs, z_vals, z_mode, white_bkgd, rays_per_obj, d_rgb, d_depth, d_acc, need_dz):
     S = rgbs.shape[-2]
     n_rays = rgbs.numel() // (3 * S) if rgbs.numel() else 0

@@ -139,11 +139,110 @@ def make_model(codenerf, seed=0, sigma_bias=-2.0):
     return model, params
 
 
+def scene_fixture(RU, RR, model, params):
+    """(vii) multi-object scene: scripts/demo.py (OptimizerDemo.vis_scene) cannot be imported (nuscenes-devkit, pytorch3d, cv2
+    drawing), so the same sequence of calls is made here into the reference's OWN building blocks -- corners_of_box_batch,
+    view_points_batch, roi_process, get_rays, ray_box_intersection, sample_from_rays_v2, the decoder, volume_rendering3 --
+    and the oracle's restatement is checked against every intermediate."""
+    H, W, S, bs = 60, 80, 16, 700
+    K = torch.tensor([[100., 0, 40], [0, 100., 30], [0, 0, 1]])
+    flip = np.array([[0, -1, 0], [0, 0, -1], [1, 0, 0]], dtype=np.float32)          # object (x fwd, y left, z up) -> camera axes
+
+    def pose(yaw, t):
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        R = flip @ np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], dtype=np.float32)
+        return torch.from_numpy(np.concatenate([R, np.asarray(t, dtype=np.float32).reshape(3, 1)], 1))
+    poses = torch.stack([pose(0.4, [-1.5, 0.3, 9.0]), pose(-0.7, [1.0, 0.2, 12.0]), pose(1.3, [0.2, 0.1, 15.0])])
+    wlh = torch.tensor([[1.9, 4.6, 1.7], [2.0, 4.9, 1.6], [1.8, 4.4, 1.5]])
+    wlh_np = wlh.numpy()
+    g = torch.Generator().manual_seed(77)
+    sc = torch.randn(3, 256, generator=g) * 0.3
+    tc = torch.randn(3, 256, generator=g) * 0.3
+    Nb = 3
+    # --- reference building blocks, in the order vis_scene uses them
+    rays_tab = torch.ones((H, W, Nb, 8), dtype=torch.float32) * (-1)
+    uv = RU.view_points_batch(RU.corners_of_box_batch(poses, wlh, is_kitti=False), K.unsqueeze(0).repeat(Nb, 1, 1), normalize=True)
+    rois = torch.stack([uv[:, 0].min(axis=1)[0], uv[:, 1].min(axis=1)[0], uv[:, 0].max(axis=1)[0], uv[:, 1].max(axis=1)[0]], 1).type(torch.int32)
+    for i in range(Nb):
+        rois[i] = RU.roi_process(rois[i], H, W, roi_margin=0, sq_pad=False)
+    diags = []
+    for i, roi in enumerate(rois):
+        Rc = poses[i][:3, :3].transpose(0, 1)
+        cam = torch.cat([Rc, -Rc @ np.expand_dims(poses[i][:3, 3], -1)], dim=1)
+        ro, vd = RU.get_rays(K, cam, roi)
+        dg = np.linalg.norm(wlh_np[i]).astype(np.float32)
+        diags.append(dg)
+        x0, y0, x1, y1 = roi
+        rays_tab[y0:y1, x0:x1, i, :3] = ro.view(y1 - y0, x1 - x0, -1) / (dg / 2)
+        rays_tab[y0:y1, x0:x1, i, 3:6] = vd.view(y1 - y0, x1 - x0, -1)
+        ow, ol, oh = wlh_np[i]
+        bmax = np.asarray([ol / dg, ow / dg, oh / dg]).reshape((1, 3)).repeat(ro.shape[0], axis=0)
+        z_in, z_out, hit = RU.ray_box_intersection(ro.numpy() / (dg / 2), vd.numpy(), aabb_min=-bmax, aabb_max=bmax)
+        nr, fr = rays_tab[y0:y1, x0:x1, i, 6].flatten(0, 1), rays_tab[y0:y1, x0:x1, i, 7].flatten(0, 1)
+        nr[hit] = torch.from_numpy(z_in); fr[hit] = torch.from_numpy(z_out)
+        rays_tab[y0:y1, x0:x1, i, 6] = nr.view(y1 - y0, x1 - x0)
+        rays_tab[y0:y1, x0:x1, i, 7] = fr.view(y1 - y0, x1 - x0)
+    diags = torch.tensor(diags, dtype=torch.float32)
+    valid = (rays_tab[:, :, :, 7].view(H * W, Nb) - rays_tab[:, :, :, 6].view(H * W, Nb)).max(-1)[0] > 0
+    o_tab, o_valid, o_diags = O.scene_rays(poses, wlh, K, H, W)
+    assert_same("scene ray table", o_tab, rays_tab)
+    assert_same("scene valid", o_valid, valid); assert_same("scene diags", o_diags, diags)
+    picked = rays_tab.view(H * W, -1, 8)[valid, ...]
+    outs, jit, inter = [], [], {}
+    torch.manual_seed(123)
+    with torch.no_grad():
+        for bi, batch in enumerate(torch.split(picked, bs)):
+            rays = batch.view(-1, 8); Nr = batch.shape[0]
+            with RandTap() as tap:
+                zc = RU.sample_from_rays_v2(rays, S)
+            jit.append(tap.draws[0])
+            empty = zc == -1
+            xyz = rays[:, None, :3] + zc[:, :, None] * rays[:, None, 3:6]
+            vdir = rays[:, 3:6].unsqueeze(-2).repeat(1, S, 1)
+            dd = diags.view(1, -1, 1, 1).repeat(Nr, 1, 1, 1).flatten(0, 1)
+            zv = torch.norm((xyz - rays[:, None, :3]) * (dd / 2), p=2, dim=-1)
+            zv[empty] = -1
+            xyz = xyz.view(Nr, Nb, S, 3).permute((1, 0, 2, 3)).flatten(0, 1)
+            vdir = vdir.view(Nr, Nb, S, 3).permute((1, 0, 2, 3)).flatten(0, 1)
+            xyz = xyz[:, :, [1, 0, 2]]; xyz[:, :, 0] *= (-1)
+            vdir = vdir[:, :, [1, 0, 2]]; vdir[:, :, 0] *= (-1)
+            sig, rgb = model(xyz, vdir, sc, tc)
+            rgb = rgb.view(Nb, Nr, S, 3).permute((1, 0, 2, 3)).flatten(0, 1)
+            sig = sig.view(Nb, Nr, S).permute((1, 0, 2)).flatten(0, 1)
+            rgb[empty, ...] = 1; sig[empty] = 0
+            zv = zv.view(-1, Nb * S)
+            zs = torch.sort(zv, 1).values
+            za = torch.searchsorted(zs, zv)
+            rgb = rgb.view(-1, Nb * S, 3)
+            rgb_s = torch.zeros_like(rgb).scatter_(1, za[:, :, None].repeat(1, 1, 3), rgb)
+            sig = sig.view(-1, Nb * S)
+            sig_s = torch.zeros_like(sig).scatter_(1, za, sig)
+            out = RR.volume_rendering3(sig_s, rgb_s, zs, white_bkgd=True)
+            outs.append(out)
+            if bi == 0:
+                inter = dict(b0_sigmas=sig, b0_rgbs=rgb, b0_z=zv, b0_rgb=out[0], b0_depth=out[1], b0_acc=out[2])
+                oc = O.scene_composite(sig, rgb, zv)
+                for a, b, nm in zip(oc, out, ("rgb", "depth", "acc")):
+                    assert_same("scene composite " + nm, a, b)
+    canvas = torch.ones(H * W, 3)
+    canvas[valid, :] = torch.cat([o[0] for o in outs], 0)
+    img8 = (canvas.view(H, W, 3).numpy() * 255).astype(np.uint8)
+    o_canvas, o_img8 = O.vis_scene(params, poses, wlh, sc, tc, K, H, W, S, ray_batch_size=bs, jitters=jit)
+    assert_same("scene canvas", o_canvas, canvas)
+    assert np.array_equal(o_img8, img8)
+    save("scene", obj_poses=poses, obj_wlh=wlh, K=K, H=np.array(H), W=np.array(W), n_samples=np.array(S), ray_batch_size=np.array(bs),
+         shapecodes=sc, texturecodes=tc, jitter=torch.cat(jit, 0), jitter_rows=np.array([j.shape[0] for j in jit]),
+         valid=valid, canvas=canvas, image=img8, **inter)
+
+
 def main():
     torch.set_num_threads(8)
     codenerf, RU, RR = import_reference()
     check_decoder_twins()
     model, params = make_model(codenerf)
+    if "--scene-only" in sys.argv:
+        scene_fixture(RU, RR, model, params)
+        return
     digest = weights_digest(params)
     print("weights digest", digest)
 
@@ -454,6 +553,7 @@ def main():
     rows = {("dWrow0_" + k.replace(".", "_")): v[0] for k, v in wg.items() if v.dim() == 2}
     save("train_step", xyz=xyz, viewdir=vd, z_vals=z, shapecode=sc, texturecode=tc, tgt=tgt, loss=loss,
          rgb=out[0], depth=out[1], acc=out[2], d_shapecode=sc.grad, d_texturecode=tc.grad, **small, **sums, **rows)
+    scene_fixture(RU, RR, model, params)
     print("all reference-vs-oracle checks passed; fixtures written to", HERE)
 
 

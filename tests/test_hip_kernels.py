@@ -99,6 +99,46 @@ def test_composite_empty(amd, dev):
     assert out[0].shape == (0, 3) and out[1].shape == (0,)
 
 
+def test_scene_composite_golden(amd, dev, golden):
+    """Per-pixel depth merge + white-background composite (scripts/demo.py:555-565) on the reference's own batch."""
+    g = golden("scene")
+    rgb, depth, acc = amd.ops.scene_composite(g["b0_sigmas"].to(dev), g["b0_rgbs"].to(dev), g["b0_z"].to(dev))
+    assert maxdiff(rgb, g["b0_rgb"]) < TOL_RGB and maxdiff(acc, g["b0_acc"]) < TOL_ACC
+    assert float((depth.cpu() - g["b0_depth"]).abs().mean()) < TOL_DEPTH_MEAN and maxdiff(depth, g["b0_depth"]) < TOL_DEPTH_MAX
+
+
+@pytest.mark.parametrize("Nb,S,P", [(1, 64, 37), (3, 64, 501), (5, 64, 130), (8, 64, 64), (7, 33, 50), (16, 64, 9), (2, 5, 1000)])
+def test_scene_composite_shapes(amd, dev, Nb, S, P):
+    """Other object counts incl. samples per pixel that are no multiple of 64, empty objects (depth -1) and exact ties
+    between objects; checked against the oracle's restatement of the reference (sort + searchsorted scatter)."""
+    gen = torch.Generator().manual_seed(Nb * 1000 + S)
+    near = torch.rand(P, Nb, 1, generator=gen) * 20 + 2
+    z = near + torch.sort(torch.rand(P, Nb, S, generator=gen), dim=-1)[0] * 4
+    sig = torch.rand(P, Nb, S, generator=gen) * 2 - 0.3                       # some negative densities (relu in the composite)
+    rgb = torch.rand(P, Nb, S, 3, generator=gen)
+    empty = torch.rand(P, Nb, generator=gen) < 0.3                            # objects that miss the pixel
+    z[empty] = -1; sig[empty] = 0; rgb[empty] = 1
+    z, sig, rgb = z.view(P, Nb * S), sig.view(P, Nb * S), rgb.view(P, Nb * S, 3)
+    want = O.scene_composite(sig, rgb, z)
+    got = amd.ops.scene_composite(sig.to(dev), rgb.to(dev), z.to(dev))
+    assert maxdiff(got[0], want[0]) < TOL_RGB and maxdiff(got[2], want[2]) < TOL_ACC
+    assert maxdiff(got[1], want[1]) < TOL_DEPTH_MAX
+    if Nb > 1:      # two objects sharing every depth exactly: the reference keeps the later sample of each pair and drops the other
+        z2 = z.clone().view(P, Nb, S); z2[:, 1] = z2[:, 0]; z2 = z2.view(P, Nb * S)
+        want2 = O.scene_composite(sig, rgb, z2)
+        got2 = amd.ops.scene_composite(sig.to(dev), rgb.to(dev), z2.to(dev))
+        assert maxdiff(got2[0], want2[0]) < TOL_RGB and maxdiff(got2[1], want2[1]) < TOL_DEPTH_MAX and maxdiff(got2[2], want2[2]) < TOL_ACC
+
+
+def test_scene_composite_limits(amd, dev):
+    e = amd.ops.scene_composite(torch.zeros(0, 128, device=dev), torch.zeros(0, 128, 3, device=dev), torch.zeros(0, 128, device=dev))
+    assert e[0].shape == (0, 3)
+    with pytest.raises(amd.SnrError):
+        amd.ops.scene_composite(torch.zeros(2, 2000, device=dev), torch.zeros(2, 2000, 3, device=dev), torch.zeros(2, 2000, device=dev))
+    with pytest.raises(amd.SnrError):
+        amd.ops.scene_composite(torch.zeros(2, 8, device=dev), torch.zeros(2, 8, 3, device=dev), torch.zeros(2, 9, device=dev))
+
+
 # ------------------------------------------------------------------ encode
 def _geom_family_a(g, dev, S, shapenet, kitti=False, flip=False):
     ro, vd = O.pixel_rays(g["K"], g["cam_pose"], g["roi"], uv_steps=[int(g["im_sz"])] * 2)

@@ -283,6 +283,20 @@ def test_grad_bucket_and_lr_schedule(amd):
     assert float(c.shape_codes.weight.min()) == 1.0 and float(c.texture_codes.weight.abs().max()) == 0.0
 
 
+def test_scene_ray_table_matches_oracle(amd, golden):
+    """Host side of vis_scene (scripts/demo.py:437-523): per-object rois, rays, box entry/exit depths, valid-pixel mask."""
+    g = golden("scene")
+    H, W = int(g["H"]), int(g["W"])
+    tab, valid, diags = amd.scene.scene_rays(g["obj_poses"], g["obj_wlh"], g["K"], H, W)
+    o_tab, o_valid, o_diags = O.scene_rays(g["obj_poses"], g["obj_wlh"], g["K"], H, W)
+    assert torch.equal(valid, g["valid"].bool()) and torch.equal(tab, o_tab) and torch.equal(diags, o_diags)
+    tab2, valid2, _ = amd.scene.scene_rays(g["obj_poses"], g["obj_wlh"], g["K"], H, W, manipulation=(0.5, 0.0, 2.0), rend_aabb=False)
+    o2 = O.scene_rays(g["obj_poses"], g["obj_wlh"], g["K"], H, W, manipulation=(0.5, 0.0, 2.0), rend_aabb=False)
+    assert torch.equal(tab2, o2[0]) and torch.equal(valid2, o2[1])
+    with pytest.raises(amd.SnrError):
+        amd.scene.vis_scene(None, "cpu", g["obj_poses"], g["obj_wlh"][:2], g["shapecodes"], g["texturecodes"], g["K"], H, W, 8)
+
+
 def test_reference_file_formats_round_trip(amd, tmp_path):
     """models.pth / codes+poses.pth with the reference's keys (src/trainer_unified_nuscenes.py:476-490, src/optimizer_nuscenes.py:1463-1476)."""
     m = amd.SUPNeRF(shape_blocks=3, texture_blocks=1)
