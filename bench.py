@@ -194,7 +194,16 @@ def main():
         rgb_h = torch.rand(Bh * N_RAYS, N_SAMPLES, 3, device=dev)
         t_cmp = timed(lambda: ops.composite_fwd(sig_h, rgb_h, z_h, ops.Z_PER_OBJECT, False, N_RAYS))
         cmp_bytes = P_h * 16 + Bh * N_RAYS * 20
+        # scene composite (vis_scene): 131072 pixels x 3 objects x 64 samples, depth merge + composite
+        P_s, n_s = 131072, 3 * N_SAMPLES
+        z_s = (torch.rand(P_s, 3, 1, device=dev) * 20 + 2 + torch.sort(torch.rand(P_s, 3, N_SAMPLES, device=dev), dim=-1)[0] * 4).view(P_s, n_s)
+        sig_s, rgb_s = torch.rand(P_s, n_s, device=dev), torch.rand(P_s, n_s, 3, device=dev)
+        t_scn = timed(lambda: ops.scene_composite(sig_s, rgb_s, z_s, True))
+        scn_bytes = P_s * n_s * 20 + P_s * 20
+        del z_s, sig_s, rgb_s
         hbm = {"encode": {"GB_per_s": enc_bytes / t_enc / 1e9, "ms": t_enc * 1e3, "bytes": enc_bytes, "frac_of_8TBps": enc_bytes / t_enc / 8e12},
+               "scene_composite": {"GB_per_s": scn_bytes / t_scn / 1e9, "ms": t_scn * 1e3, "bytes": scn_bytes, "frac_of_8TBps": scn_bytes / t_scn / 8e12,
+                                   "shape": f"{P_s} pixels x 3 objects x {N_SAMPLES} samples"},
                "composite_fwd": {"GB_per_s": cmp_bytes / t_cmp / 1e9, "ms": t_cmp * 1e3, "bytes": cmp_bytes, "frac_of_8TBps": cmp_bytes / t_cmp / 8e12},
                "shape": f"{Bh} objects x {N_RAYS} rays x {N_SAMPLES} samples"}
         del sig_h, rgb_h
