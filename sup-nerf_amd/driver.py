@@ -131,7 +131,7 @@ def losses(rgb_rays, acc_trans_rays, rgb_tgt, occ_pixels, loss_occ_coef):
 
 
 def optimize_object(model, device, obj: Dict, hpams: dict, shapecode0, texturecode0, pose_noise=(0.05, 0.3), reg_iters=3,
-                    n_lidar=64, seed=0, log=None):
+                    n_lidar=64, seed=0, log=None, jitter=None):
     """Optimise codes and object pose of one object against its (synthetic) target.  Returns a metric tensor
     (num_opts, 4) = [psnr, depth_err, rot_err, trans_err] per iteration, and the final codes / pose."""
     opt = hpams["optimize"]
@@ -161,6 +161,8 @@ def optimize_object(model, device, obj: Dict, hpams: dict, shapecode0, textureco
     depth0 = None
     for it in range(opt["num_opts"]):
         optim.zero_grad()
+        if jitter is not None:                                   # (num_opts, 2, S): the two draws of this iteration (tests)
+            U.JITTER_OVERRIDE = jitter[it, 0]
         R = axis_angle_to_matrix(rot_vec[0])
         t = trans_vec[0].unsqueeze(-1)
         if not opt.get("opt_cam_pose", 0):                       # object pose is optimised: invert to camera-in-object
@@ -173,6 +175,8 @@ def optimize_object(model, device, obj: Dict, hpams: dict, shapecode0, textureco
         loss, mse_fg = losses(rgb, acc, rgb_tgt, occ, hpams["loss_occ_coef"])
         loss.backward()
         with torch.no_grad():
+            if jitter is not None:
+                U.JITTER_OVERRIDE = jitter[it, 1]
             _, d_vec, _, _, _ = U.render_rays_specified(model, dev, img, mask, cam2opt.detach(), obj_diag, K, roi, x_vec, y_vec, S,
                                                         shapecode, texturecode, hpams["shapenet_obj_cood"], hpams["sym_aug"])
             if depth0 is None:
@@ -190,7 +194,117 @@ def optimize_object(model, device, obj: Dict, hpams: dict, shapecode0, textureco
             optim = make_optimizer(shapecode, texturecode, rot_vec, trans_vec, lr)
         if log is not None:
             log(it, float(loss), metrics[it])
+    if jitter is not None:
+        U.JITTER_OVERRIDE = None
     return metrics, shapecode.detach(), texturecode.detach(), cam2opt.detach()
+
+
+# ------------------------------------------------------------------ many objects per launch (BASELINE config 3)
+def _rays_batch(K, c2w, px, py):
+    """Batched twin of utils._pixel_dirs: K (B,3,3), c2w (B,3,4), pixel coordinates px, py (B,n) -> rays_o, viewdir (B*n,3)."""
+    cx, cy, fx, fy = K[:, 0, 2:3], K[:, 1, 2:3], K[:, 0, 0:1], K[:, 1, 1:2]
+    cam = torch.stack([(px - cx) / fx, (py - cy) / fy, torch.ones_like(px)], -1)                  # (B,n,3)
+    world = (cam[:, :, None, :] * c2w[:, None, :3, :3]).sum(-1)
+    unit = world / torch.norm(world, dim=-1, keepdim=True)
+    origin = c2w[:, None, :3, 3].expand(world.shape)
+    return origin.reshape(-1, 3), unit.reshape(-1, 3)
+
+
+def optimize_objects_batched(model, device, objs: List[Dict], hpams: dict, shapecodes0, texturecodes0, seeds: Sequence[int],
+                             pose_noise=(0.05, 0.3), reg_iters=3, n_lidar=64, jitter=None):
+    """The iteration of ``optimize_object`` for B objects at once: ONE fused forward, one backward and one 64-pixel
+    depth render per iteration for all of them (per-object codes, poses, depth tables and targets; the loss is the sum
+    of the per-object losses, so every object sees exactly its own gradient), AdamW over the stacked leaves, metrics
+    kept on the device until the end -- no host round trip inside the loop.  Jitter: ``jitter`` (num_opts, 2, B, S) or,
+    by default, drawn up front from one CPU generator per object (seeded like the per-object loop seeds its RandomState).
+    Returns metrics (B, num_opts, 4), shape codes, texture codes, poses (B,3,4)."""
+    opt = hpams["optimize"]
+    S, im_sz, T = hpams["n_samples"], hpams["render_im_sz"], opt["num_opts"]
+    dev = torch.device(device)
+    B, n = len(objs), im_sz * im_sz
+    if hpams.get("sym_aug", 0):
+        raise U.SnrError("optimize_objects_batched: sym_aug draws one python coin per object and iteration; use optimize_object")
+    rot0, tr0, gtR, gtT, px, py, lx, ly, tgt, occ = [], [], [], [], [], [], [], [], [], []
+    for ob, seed in zip(objs, seeds):
+        rs = np.random.RandomState(seed)
+        R_gt = ob["cam_pose"][:, :3].T
+        t_gt = -R_gt @ ob["cam_pose"][:, 3:]
+        rot0.append(matrix_to_axis_angle(R_gt[None]) + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[0])
+        tr0.append(t_gt.T + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[1])
+        gtR.append(R_gt); gtT.append(t_gt)
+        ys, xs = np.where(ob["mask"][:, :, 0].numpy() > 0)
+        pick = rs.permutation(len(ys))[:n_lidar]
+        x0, y0, x1, y1 = [int(v) for v in ob["roi"]]
+        lx.append(torch.from_numpy((xs[pick] + x0).astype(np.float32))); ly.append(torch.from_numpy((ys[pick] + y0).astype(np.float32)))
+        gx, gy = torch.linspace(x0, x1 - 1, im_sz), torch.linspace(y0, y1 - 1, im_sz)
+        px.append(gx[None, :].expand(im_sz, im_sz).reshape(-1)); py.append(gy[:, None].expand(im_sz, im_sz).reshape(-1))
+        im, mk = U._resize(ob["img"], ob["mask"], im_sz)
+        tgt.append(im.reshape(-1, 3)); occ.append(mk.reshape(-1, 1))
+    n_lidar = min(len(v) for v in lx)            # one launch needs the same count for every object: the smallest foreground decides
+    if n_lidar == 0:
+        raise U.SnrError("optimize_objects_batched: an object has no foreground pixel")
+    lx, ly = [v[:n_lidar] for v in lx], [v[:n_lidar] for v in ly]
+    st = lambda xs_: torch.stack(xs_).to(dev)
+    K = st([ob["K"] for ob in objs]); diag = torch.tensor([float(ob["obj_diag"]) for ob in objs], device=dev)
+    px, py, lx, ly, tgt, occ, gtR, gtT = st(px), st(py), st(lx), st(ly), st(tgt), st(occ), st(gtR), st(gtT)
+    rot_vec = torch.cat(rot0).to(dev).requires_grad_(); trans_vec = torch.cat(tr0).to(dev).requires_grad_()
+    shapecode = shapecodes0.detach().clone().to(dev).requires_grad_(); texturecode = texturecodes0.detach().clone().to(dev).requires_grad_()
+    if jitter is None:
+        gens = [torch.Generator().manual_seed(int(s_)) for s_ in seeds]
+        jitter = torch.stack([torch.rand(T, 2, S, generator=g) for g in gens], dim=2)
+    jitter = jitter.to(dev)
+    lr = {k: opt[k] for k in ("lr_shape", "lr_texture", "lr_pose")}
+    optim = make_optimizer(shapecode, texturecode, rot_vec, trans_vec, lr)
+    frame = U._frame(False, False, hpams["shapenet_obj_cood"])
+    sb, tb = getattr(model, "shape_blocks", 0), getattr(model, "texture_blocks", 0)
+    a = torch.abs(occ); denom = a.sum(dim=(1, 2)) + 1e-9; fg = occ.clamp_min(0); fg_denom = fg.sum(dim=(1, 2)) + 1e-9
+    metrics = torch.zeros(T, B, 4, device=dev)
+    depth0 = None
+    half = diag / 2
+    idx = torch.arange(S, device=dev, dtype=torch.float32)[None, :]
+    for it in range(T):
+        optim.zero_grad()
+        R = axis_angle_to_matrix(rot_vec)
+        t = trans_vec.unsqueeze(-1)
+        if not opt.get("opt_cam_pose", 0):
+            Rc = R.transpose(-2, -1)
+            cam2opt = torch.cat([Rc, -Rc @ t], -1)
+        else:
+            cam2opt = torch.cat([R, t], -1)
+        dist = cam2opt[:, :, 3].detach().norm(dim=-1)
+        near, far = (dist - half)[:, None], (dist + half)[:, None]
+
+        def render(pxx, pyy, jit, rays_per_obj):
+            rays_o, viewdir = _rays_batch(K, cam2opt, pxx, pyy)
+            hw = (far - near) / (2 * S)                          # (B,S) twin of utils._shared_depths incl. its two-sided linspace
+            start, end = near + hw, far - hw
+            step = (end - start) / max(S - 1, 1)
+            z = torch.where(idx < S // 2, start + step * idx, end - step * (S - 1 - idx)) + jit * hw
+            cfg = U.ops.RenderCfg(S, U.ops.Z_PER_OBJECT, rays_per_obj, sb, tb, frame=frame, precision=None)
+            return model.fused_render(rays_o, viewdir, z.contiguous(), diag, None, shapecode, texturecode, cfg)
+        rgb, depth, acc = render(px, py, jitter[it, 0], n)
+        rgb, acc = rgb.view(B, n, 3), acc.view(B, n, 1)
+        sq = (rgb - tgt) ** 2
+        loss_rgb = (sq * a).sum(dim=(1, 2)) / denom
+        loss_occ = (torch.exp(-occ * (0.5 - acc)) * a).sum(dim=(1, 2)) / denom
+        (loss_rgb + hpams["loss_occ_coef"] * loss_occ).sum().backward()
+        with torch.no_grad():
+            mse_fg = (sq.detach() * fg).sum(dim=(1, 2)) / fg_denom
+            d_vec = render(lx, ly, jitter[it, 1], n_lidar)[1].view(B, n_lidar)
+            if depth0 is None:
+                depth0 = d_vec.clone()
+            c = cam2opt.detach()
+            pred_R = c[:, :, :3].transpose(-2, -1) if not opt.get("opt_cam_pose", 0) else c[:, :, :3]
+            pred_t = -pred_R @ c[:, :, 3:] if not opt.get("opt_cam_pose", 0) else c[:, :, 3:]
+            metrics[it] = torch.stack([-10 * torch.log10(mse_fg), (d_vec - depth0).abs().mean(dim=1), rot_dist(pred_R, gtR),
+                                       (pred_t - gtT).flatten(1).norm(dim=1)], dim=1)
+        if it > reg_iters:
+            optim.step()
+        if (it + 1) % opt["lr_half_interval"] == 0:
+            halvings = (it + 1) // opt["lr_half_interval"]
+            lr = {k: v * 2 ** (-halvings) for k, v in lr.items()}
+            optim = make_optimizer(shapecode, texturecode, rot_vec, trans_vec, lr)
+    return metrics.permute(1, 0, 2).contiguous(), shapecode.detach(), texturecode.detach(), cam2opt.detach()
 
 
 def make_objects(ids: Sequence[int], im_sz: int) -> List[Dict]:
@@ -206,20 +320,30 @@ def make_objects(ids: Sequence[int], im_sz: int) -> List[Dict]:
 
 
 def optimize_objects(model, device, n_objects: int, hpams: Optional[dict] = None, rank: int = 0, world_size: int = 1, seed: int = 0,
-                     group=None):
-    """Shard ``n_objects`` synthetic objects over the ranks, optimise the local slice, all-gather the metric rows.
+                     group=None, batch: int = 64):
+    """Shard ``n_objects`` synthetic objects over the ranks, optimise the local slice ``batch`` objects per launch
+    (``batch=1``: the reference's one-object-at-a-time loop with its global random streams), all-gather the metric rows.
     Returns (n_objects, num_opts*4) on every rank."""
     hpams = hpams or load_hpams()
     mine = list(shard_slice(n_objects, world_size, rank))
     objs = make_objects(mine, hpams["render_im_sz"])
-    gen = torch.Generator().manual_seed(seed)
     rows = []
-    for ob in objs:
-        g = torch.Generator().manual_seed(seed * 7919 + ob["index"])
-        sc = torch.randn(1, 256, generator=g) * 0.3
-        tc = torch.randn(1, 256, generator=g) * 0.3
-        m, *_ = optimize_object(model, device, ob, hpams, sc, tc, seed=seed * 7919 + ob["index"])
-        rows.append(m.reshape(-1))
+
+    def start_codes(index):
+        g = torch.Generator().manual_seed(seed * 7919 + index)
+        return torch.randn(1, 256, generator=g) * 0.3, torch.randn(1, 256, generator=g) * 0.3
+    if batch <= 1 or hpams.get("sym_aug", 0) or not U._is_native(model):
+        for ob in objs:
+            sc, tc = start_codes(ob["index"])
+            m, *_ = optimize_object(model, device, ob, hpams, sc, tc, seed=seed * 7919 + ob["index"])
+            rows.append(m.reshape(-1))
+    else:
+        for i in range(0, len(objs), batch):
+            part = objs[i:i + batch]
+            codes = [start_codes(ob["index"]) for ob in part]
+            m, *_ = optimize_objects_batched(model, device, part, hpams, torch.cat([c[0] for c in codes]), torch.cat([c[1] for c in codes]),
+                                             [seed * 7919 + ob["index"] for ob in part])
+            rows += list(m.reshape(len(part), -1).cpu())
     n_cols = hpams["optimize"]["num_opts"] * 4
     dev = torch.device(device)
     local = torch.stack(rows).to(dev) if rows else torch.zeros(0, n_cols, device=dev)
