@@ -524,33 +524,38 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
 }
 
 // ------------------------------------------------------------------------------------------ backward
-// Sum 16 accumulator registers over the 32 points of the wave (butterfly reduce-scatter, 16 shuffles) and store
-// the 32 feature totals of this tile.  dst points at the tile's 32 features.
-__device__ __forceinline__ void reduce_tile_store(const f32x16& acc, float* __restrict__ dst, int lane) {
-    const int p = lane & 31, h = lane >> 5;
-    float a8[8], a4[4], a2[2], a1;
-    {
-        const bool up = p & 16;
+// Latent-term gradient of one layer: sum every feature of the 8 finished accumulator tiles over the wave's 32 points.
+// Done through a wave-private LDS scratch, half a tile at a time: lane (p,h) writes its 8 values of the half tile as two
+// ds_write_b128 into row p (16 features + 4 pad floats), then lane (f, q) adds the 8 rows of point group q for feature f,
+// the four groups meet through two permlane swaps at the very end, and the 256 sums are parked in LDS (`out`) until the kernel's
+// last phase stores them -- so no global store is queued between the hand-counted DMA waits of the layer chain.
+// (The previous version, a register butterfly of 16 ds_bpermute per tile in the middle of the MFMA pipeline, cost 35-45 k
+// cycles per latent layer = 40 % of the backward kernel.)
+constexpr int RED_STRIDE = 20;      // floats per scratch row: 16 features + pad (16-byte aligned rows, conflict-free column reads)
+__device__ __forceinline__ void reduce_tiles_lds(const f32x16 (&acc)[8], float* __restrict__ out /*LDS, 256*/, float* scratch /*LDS, 32*RED_STRIDE*/,
+                                                 int lane) {
+    const int p = lane & 31, h = lane >> 5, f = lane & 15, q = lane >> 4;
+    float s[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a8[i] = (up ? acc[i + 8] : acc[i]) + __shfl_xor(up ? acc[i] : acc[i + 8], 16, 64);
-    }
-    {
-        const bool up = p & 8;
+    for (int k = 0; k < 16; ++k) {            // half tile k: tile k>>1, registers 8*(k&1) .. +7
+        const int t = k >> 1, r0 = 8 * (k & 1);
+        f32x4 v0 = {acc[t][r0], acc[t][r0 + 1], acc[t][r0 + 2], acc[t][r0 + 3]};
+        f32x4 v1 = {acc[t][r0 + 4], acc[t][r0 + 5], acc[t][r0 + 6], acc[t][r0 + 7]};
+        *reinterpret_cast<f32x4*>(scratch + p * RED_STRIDE + 4 * h) = v0;
+        *reinterpret_cast<f32x4*>(scratch + p * RED_STRIDE + 8 + 4 * h) = v1;
+        __builtin_amdgcn_wave_barrier();
+        float a = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a4[i] = (up ? a8[i + 4] : a8[i]) + __shfl_xor(up ? a8[i] : a8[i + 4], 8, 64);
+        for (int i = 0; i < 8; ++i) a += scratch[(8 * q + i) * RED_STRIDE + f];
+        s[k] = a;
+        __builtin_amdgcn_wave_barrier();
     }
-    {
-        const bool up = p & 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a2[i] = (up ? a4[i + 2] : a4[i]) + __shfl_xor(up ? a4[i] : a4[i + 2], 4, 64);
+    for (int k = 0; k < 16; ++k) s[k] = sum_halves(sum_row_pairs(s[k]));       // the four point groups meet on the VALU
+    if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) out[16 * k + f] = s[k];
     }
-    {
-        const bool up = p & 2;
-        a1 = (up ? a2[1] : a2[0]) + __shfl_xor(up ? a2[0] : a2[1], 2, 64);
-    }
-    a1 += __shfl_xor(a1, 1, 64);
-    const int r = (p >> 1) & 15;                 // 8 b4 + 4 b3 + 2 b2 + b1
-    if ((p & 1) == 0) dst[8 * (r >> 2) + 4 * h + (r & 3)] = a1;
 }
 
 // What happens to a finished gradient tile (wrt the input of the layer above = output of layer l [+ latent]):
@@ -559,11 +564,10 @@ struct BwdEpi {
     uint32_t m[4];        // ReLU bits of layer l (all ones when it has no activation)
     const float* wsig;    // LDS: density-head weights below enc_shape (a block of zeros otherwise)
     float dpre;           // d loss / d (pre-softplus density) of this lane's point
-    float* dz;            // global: this wave tile's partial latent gradient (256 floats), or null
+    float* dzl;           // LDS: where this wave parks the layer's latent-term gradient (256 floats), or null
 };
 template <int T, int HALF, int JJ>
 __device__ __forceinline__ void bwd_quarter(const f32x16& acc, XOp& out, const BwdEpi& c, const f32x4& wv, int lane) {
-    if (HALF == 0 && JJ == 0 && c.dz) reduce_tile_store(acc, c.dz + 32 * T, lane);
     const int j = 2 * HALF + JJ;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -591,6 +595,7 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
     constexpr int NTH = NT / 2;
     constexpr int SPC = (NT == 8) ? 2 : 8;                  // steps per chunk (NT == 2: enc_xyz^T, 8 steps of 4 KiB)
     const int step_bytes = (NT + (ninth ? 1 : 0)) * 2 * 1024;
+    if (c.dzl) reduce_tiles_lds(accP, c.dzl, reinterpret_cast<float*>(lds + OFF_XDIR) + (threadIdx.x >> 6) * 1024, lane);
     acc_zero<NT, 8>(accC);
     bwd_half_tile<0, 0>(accP[0], x[0], c, h, lane);
     Frags<NTH> fa, fb;
@@ -628,6 +633,12 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
 #undef SNR_BSTEP
 }
 
+#ifdef SNR_STAMPS
+#define SNR_BSTAMP(i) do { if (io.d_t && lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    reinterpret_cast<unsigned long long*>(io.d_t)[tile32 * 16 + (i)] = t_; } } while (0)
+#else
+#define SNR_BSTAMP(i) do {} while (0)
+#endif
 template <int MODE>
 __global__ void __launch_bounds__(256, 1)
 bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom g) {
@@ -642,6 +653,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     const int n_relu = n_relu_layers(sb, tb);
     const int li_encshape = sb + 1, li_view = sb + 2, li_last = sb + tb + 2;
     float* vec = reinterpret_cast<float*>(lds + OFF_VEC);
+    SNR_BSTAMP(0);
 
     // ---- everything that needs an ordinary global load happens before the DMA ring starts
     vec[VEC_SIGW + tid] = io.packed[L.sigma_w + tid];
@@ -701,6 +713,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     }
     const float dpre = gs * (1.f - expf(-io.sigmas[gp]));
     __syncthreads();
+    SNR_BSTAMP(1);
 
     Ring ring;
     const int total_chunks = 4 + 8 * tb + 8 + 8 * (sb + 1) + 2;
@@ -738,6 +751,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     f32x16 accA[8], accB[8], acc9;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc9[r] = 0.f;
+    SNR_BSTAMP(2);
     // ---- rgb.0^T : K = 128 (8 steps) -> accA
     acc_zero<8, 8>(accA);
     {
@@ -755,22 +769,33 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
         c.wsig = (l == li_encshape) ? vec + VEC_SIGW : vec + VEC_ZERO;
         c.dpre = (l == li_encshape) ? dpre : 0.f;
         const int la = latent_after(l, sb, tb);
-        c.dz = (la >= 0 && io.partial) ? io.partial + (tile32 * L.n_lat + la) * 256 : nullptr;
+        c.dzl = (la >= 0 && io.partial) ? reinterpret_cast<float*>(lds + OFF_LAT) + (wave * MAX_LAT + la) * 256 : nullptr;
         return c;
     };
     int li = li_last;
+    SNR_BSTAMP(3);
 #pragma unroll 1
     for (; li - 1 >= 1; li -= 2) {
         layer_bwd<8>(accA, accB, acc9, x, ring, lds, epi_of(li), li == li_view, tid, lane);
+        SNR_BSTAMP(4 + li_last - li);
         layer_bwd<8>(accB, accA, acc9, x, ring, lds, epi_of(li - 1), li - 1 == li_view, tid, lane);
+        SNR_BSTAMP(5 + li_last - li);
     }
     const bool odd_tail = (li == 1);
     if (odd_tail) layer_bwd<8>(accA, accB, acc9, x, ring, lds, epi_of(1), 1 == li_view, tid, lane);
+    SNR_BSTAMP(11);
     // ---- enc_xyz^T : 256 -> 64 positional-encoding features (two tiles, fp32)
     if (odd_tail) layer_bwd<2>(accB, accA, acc9, x, ring, lds, epi_of(0), false, tid, lane);
     else          layer_bwd<2>(accA, accB, acc9, x, ring, lds, epi_of(0), false, tid, lane);
 
-    // ---- positional-encoding backward through the scratch rows (the ring is idle now)
+    SNR_BSTAMP(12);
+    // ---- the parked latent-term gradients of this wave tile -> global partials (the ring is idle now)
+    if (io.partial) {
+        const float* dzl = reinterpret_cast<const float*>(lds + OFF_LAT) + wave * MAX_LAT * 256;
+        for (int la = 0; la < L.n_lat; ++la)
+            *reinterpret_cast<f32x4*>(io.partial + (tile32 * L.n_lat + la) * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(dzl + la * 256 + lane * 4);
+    }
+    // ---- positional-encoding backward through the scratch rows
     __syncthreads();
     float* sc = reinterpret_cast<float*>(lds + OFF_PE) + (wave * 32 + p) * PE_ROWF;
 #pragma unroll
@@ -801,6 +826,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     if (h == 0) { hx += sc[0]; hy += sc[1]; hz += sc[2]; }
     gx += __shfl_xor(gx, 32, 64); gy += __shfl_xor(gy, 32, 64); gz += __shfl_xor(gz, 32, 64);
     hx += __shfl_xor(hx, 32, 64); hy += __shfl_xor(hy, 32, 64); hz += __shfl_xor(hz, 32, 64);
+    SNR_BSTAMP(13);
 
     if (MODE == 0) {
         if (live && h == 0) {
@@ -833,7 +859,9 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
 #pragma unroll
             for (int i = 0; i < 6; ++i) c[i] = 0.f;
         }
+#ifndef SNR_STAMPS
         if (io.d_t && live && h == 0) io.d_t[gp] = dt;
+#endif
         if (io.d_rays_o || io.d_rays_d) {
             const int S = g.S;
             const int G = S < 32 ? S : 32;
@@ -868,6 +896,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
             }
         }
     }
+    SNR_BSTAMP(14);
 }
 
 // ------------------------------------------------------------------------------------------ packing

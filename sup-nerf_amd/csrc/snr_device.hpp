@@ -31,6 +31,21 @@ __device__ __forceinline__ float wave_scan_mul(float v, int lane) {
     return v;
 }
 
+// Cross-row sums on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap), no LDS round trip like ds_bpermute:
+//   sum_row_pairs : lane i <- v[i] + v[i ^ 16]   (rows of 16 lanes: 0+1, 2+3)
+//   sum_halves    : lane i <- v[i] + v[i ^ 32]
+// Through inline asm: __builtin_amdgcn_permlane{16,32}_swap returned the first output twice with this compiler.
+__device__ __forceinline__ float sum_row_pairs(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float sum_halves(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 // inclusive suffix sum over the 64 lanes (lane k gets sum_{j>=k} v_j)
 __device__ __forceinline__ float wave_suffix_sum(float v, int lane) {
 #pragma unroll

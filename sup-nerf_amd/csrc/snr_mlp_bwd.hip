@@ -414,7 +414,9 @@ int snr_render_bwd(const snr_render_args* a, const float* sigmas, const float* r
     if (a->n_rays == 0) return SNR_OK;
     if (!sigmas || !rgbs || !relu_masks) return SNR_E_ARG;
     if (a->n_samples > 128 || (128 % a->n_samples) != 0) return SNR_E_UNSUPPORTED;
+#ifndef SNR_STAMPS      /* the diagnostic build borrows d_t as its stamp buffer */
     if (d_t && a->z_mode != SNR_Z_PER_RAY) return SNR_E_UNSUPPORTED;
+#endif
     const int sb = a->shape_blocks, tb = a->texture_blocks;
     const long long P = a->n_rays * a->n_samples;
     const long long ppo = a->rays_per_obj * a->n_samples;

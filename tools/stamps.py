@@ -44,3 +44,35 @@ for i, n in enumerate(names):
     print(f"  {n:14s} {m:10.0f}  (+{m - prev:8.0f})")
     prev = m
 print("first start -> last end (cycles):", int(t[:, 14].max() - t[:, 0].min()), " waves:", len(t))
+
+# ---------------------------------------------------------------- backward timeline (stamps land in the d_t buffer)
+sig = torch.empty(N * S, device=dev); rgbs = torch.empty(N * S, 3, device=dev)
+masks = torch.empty(int(good.snr_mask_bytes(N * S, 3, 1)), dtype=torch.uint8, device=dev)
+rc = good.snr_render_fwd(C.byref(a), rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), sig.data_ptr(), rgbs.data_ptr(), masks.data_ptr(),
+                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+assert rc == 0, rc
+stamps.snr_render_bwd.restype = C.c_int
+stamps.snr_render_bwd.argtypes = _lib._SIGS["snr_render_bwd"][1]
+stamps.snr_render_bwd_ws_bytes.restype = C.c_size_t
+stamps.snr_render_bwd_ws_bytes.argtypes = _lib._SIGS["snr_render_bwd_ws_bytes"][1]
+ws_bytes = stamps.snr_render_bwd_ws_bytes(C.byref(a))
+ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+d_rgb = torch.rand(N, 3, device=dev); d_depth = torch.rand(N, device=dev); d_acc = torch.rand(N, device=dev)
+d_lat = torch.empty_like(lat); d_o = torch.zeros(N, 3, device=dev); d_d = torch.zeros(N, 3, device=dev)
+dbg2 = torch.zeros(N * S, device=dev)
+for _ in range(3):
+    rc = stamps.snr_render_bwd(C.byref(a), sig.data_ptr(), rgbs.data_ptr(), masks.data_ptr(), d_rgb.data_ptr(), d_depth.data_ptr(), d_acc.data_ptr(),
+                               d_lat.data_ptr(), d_o.data_ptr(), d_d.data_ptr(), dbg2.data_ptr(), ws.data_ptr(), ws_bytes,
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+torch.cuda.synchronize()
+tb = dbg2.cpu().numpy().view(np.uint64).reshape(-1, 16)[: N * S // 32].astype(np.int64)
+bn = ["start", "composite bwd", "colour head", "rgb0^T"] + [f"layer {6 - i}^T done" for i in range(6)] + ["", "(layers done)", "enc_xyz^T", "PE bwd", "end"]
+db = tb - tb[:, :1]
+print("backward, cycles from kernel start (median over %d wave tiles):" % len(tb))
+prev = 0
+for i, nme in enumerate(bn):
+    if not nme or not tb[:, i].any(): continue
+    m = float(np.median(db[:, i]))
+    print(f"  {nme:16s} {m:10.0f}  (+{m - prev:8.0f})")
+    prev = m
