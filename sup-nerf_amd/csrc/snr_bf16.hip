@@ -457,7 +457,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     SNR_STAMP(12);
 
     // density head (enc_shape's output dotted with w_sigma inside the epilogues)
-    const float pre = sig_dot + __shfl_xor(sig_dot, 32, 64) + vec[VEC_MISC + 0];
+    const float pre = sum_halves(sig_dot) + vec[VEC_MISC + 0];
     const float o_sigma = pre > 20.f ? pre : log1pf(expf(pre));
 
     // ---- colour head: ReLU(rgb.0) . W2 on the VALU
@@ -484,9 +484,9 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
             }
         if (MASKS) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mk[0], mk[1], 0u, 0u);
     }
-    const float cr = pr + __shfl_xor(pr, 32, 64) + vec[VEC_MISC + 4];
-    const float cg = pg + __shfl_xor(pg, 32, 64) + vec[VEC_MISC + 5];
-    const float cb = pb + __shfl_xor(pb, 32, 64) + vec[VEC_MISC + 6];
+    const float cr = sum_halves(pr) + vec[VEC_MISC + 4];
+    const float cg = sum_halves(pg) + vec[VEC_MISC + 5];
+    const float cb = sum_halves(pb) + vec[VEC_MISC + 6];
 
     SNR_STAMP(13);
 #ifndef SNR_STAMPS
@@ -824,8 +824,8 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
         hx += a == 0 ? v : 0.f; hy += a == 1 ? v : 0.f; hz += a == 2 ? v : 0.f;
     }
     if (h == 0) { hx += sc[0]; hy += sc[1]; hz += sc[2]; }
-    gx += __shfl_xor(gx, 32, 64); gy += __shfl_xor(gy, 32, 64); gz += __shfl_xor(gz, 32, 64);
-    hx += __shfl_xor(hx, 32, 64); hy += __shfl_xor(hy, 32, 64); hz += __shfl_xor(hz, 32, 64);
+    gx = sum_halves(gx); gy = sum_halves(gy); gz = sum_halves(gz);
+    hx = sum_halves(hx); hy = sum_halves(hy); hz = sum_halves(hz);
     SNR_BSTAMP(13);
 
     if (MODE == 0) {
@@ -866,8 +866,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
             const int S = g.S;
             const int G = S < 32 ? S : 32;
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
-                for (int off = 1; off < G; off <<= 1) c[i] += __shfl_xor(c[i], off, 64);
+            for (int i = 0; i < 6; ++i) c[i] = group_sum(c[i], G);
             if (S <= 32) {
                 if (live && h == 0 && (p % S) == 0) {
                     if (io.d_rays_o) { io.d_rays_o[ray * 3] = c[0]; io.d_rays_o[ray * 3 + 1] = c[1]; io.d_rays_o[ray * 3 + 2] = c[2]; }

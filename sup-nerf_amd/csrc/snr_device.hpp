@@ -14,23 +14,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float LAST_DELTA = 1e10f;   // src/utils.py:209
 constexpr float TRANS_EPS = 1e-10f;   // src/utils.py:211
 
-// ------------------------------------------------------------------ wave primitives
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// inclusive product scan over the 64 lanes
-__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        float u = __shfl_up(v, off, 64);
-        if (lane >= off) v *= u;
-    }
-    return v;
-}
-
 // Cross-row sums on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap), no LDS round trip like ds_bpermute:
 //   sum_row_pairs : lane i <- v[i] + v[i ^ 16]   (rows of 16 lanes: 0+1, 2+3)
 //   sum_halves    : lane i <- v[i] + v[i ^ 32]
@@ -44,6 +27,38 @@ __device__ __forceinline__ float sum_halves(float v) {
     float a = v, b = v;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
+}
+
+// Sum over the 16 lanes of a DPP row (every lane gets the row total): four v_add_f32 with row_ror 8, 4, 2, 1 -- VALU only.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum(float v) {
+    v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
+    return v;
+}
+// Sum over aligned groups of G = 2..32 lanes (G a power of two), total in every lane of the group.
+__device__ __forceinline__ float group_sum(float v, int G) {
+    if (G == 32) return sum_row_pairs(row_sum(v));
+    if (G == 16) return row_sum(v);
+    for (int off = 1; off < G; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ wave primitives
+__device__ __forceinline__ float wave_sum(float v) {
+    return sum_halves(sum_row_pairs(row_sum(v)));           // 6 VALU ops instead of 6 ds_bpermute round trips
+}
+
+// inclusive product scan over the 64 lanes
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        float u = __shfl_up(v, off, 64);
+        if (lane >= off) v *= u;
+    }
+    return v;
 }
 
 // inclusive suffix sum over the 64 lanes (lane k gets sum_{j>=k} v_j)

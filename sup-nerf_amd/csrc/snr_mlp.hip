@@ -124,7 +124,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) part = fmaf(wv[e], in[t][4 * j + e], part);
                 }
-            const float pre = part + __shfl_xor(part, 32, 64) + io.packed[L.sigma_b];
+            const float pre = sum_halves(part) + io.packed[L.sigma_b];
             o_sigma = pre > 20.f ? pre : log1pf(expf(pre));
         }
     }
@@ -160,9 +160,9 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
                 }
             }
         const float* b2 = io.packed + L.rgb2_b;
-        o_r = pr + __shfl_xor(pr, 32, 64) + b2[0];
-        o_g = pg + __shfl_xor(pg, 32, 64) + b2[1];
-        o_b = pb + __shfl_xor(pb, 32, 64) + b2[2];
+        o_r = sum_halves(pr) + b2[0];
+        o_g = sum_halves(pg) + b2[1];
+        o_b = sum_halves(pb) + b2[2];
     }
 }
 

@@ -264,8 +264,8 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
         hx += a == 0 ? v : 0.f; hy += a == 1 ? v : 0.f; hz += a == 2 ? v : 0.f;
     }
     if (h == 0) { gx += sc[0]; gy += sc[1]; gz += sc[2]; hx += sc[64]; hy += sc[65]; hz += sc[66]; }
-    gx += __shfl_xor(gx, 32, 64); gy += __shfl_xor(gy, 32, 64); gz += __shfl_xor(gz, 32, 64);
-    hx += __shfl_xor(hx, 32, 64); hy += __shfl_xor(hy, 32, 64); hz += __shfl_xor(hz, 32, 64);
+    gx = sum_halves(gx); gy = sum_halves(gy); gz = sum_halves(gz);
+    hx = sum_halves(hx); hy = sum_halves(hy); hz = sum_halves(hz);
 
     if (MODE == 0) {
         if (live && h == 0) {
@@ -307,8 +307,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
             const int S = g.S;
             const int G = S < 32 ? S : 32;      // lanes of this wave that share a ray (S divides 128)
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
-                for (int off = 1; off < G; off <<= 1) c[i] += __shfl_xor(c[i], off, 64);
+            for (int i = 0; i < 6; ++i) c[i] = group_sum(c[i], G);
             if (S <= 32) {
                 if (live && h == 0 && (p % S) == 0) {
                     if (io.d_rays_o) { io.d_rays_o[ray * 3] = c[0]; io.d_rays_o[ray * 3 + 1] = c[1]; io.d_rays_o[ray * 3 + 2] = c[2]; }
