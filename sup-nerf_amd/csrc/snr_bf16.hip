@@ -372,7 +372,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         for (int i = 0; i < 15; ++i) {
             const int q = 15 * h + i;
             float sn, cs;
-            sincosf(ldexpf(pick3(px, py, pz, q % 3), q / 3), &sn, &cs);
+            pe_sincos(ldexpf(pick3(px, py, pz, q % 3), q / 3), &sn, &cs);
             sc[3 + q] = sn; sc[3 + 3 * XYZ_FREQ + q] = cs;
         }
         if (h == 0) { sc[0] = px; sc[1] = py; sc[2] = pz; sc[63] = 0.f; }
@@ -384,7 +384,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         for (int i = 0; i < 6; ++i) {
             const int q = 6 * h + i;
             float sn, cs;
-            sincosf(ldexpf(pick3(dx, dy, dz, q % 3), q / 3), &sn, &cs);
+            pe_sincos(ldexpf(pick3(dx, dy, dz, q % 3), q / 3), &sn, &cs);
             sc[3 + q] = sn; sc[3 + 3 * DIR_FREQ + q] = cs;
         }
         if (h == 0) {
@@ -808,7 +808,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     for (int i = 0; i < 15; ++i) {
         const int q = 15 * h + i, a = q % 3, f = q / 3;
         float sn, cs;
-        sincosf(ldexpf(pick3(px_, py_, pz_, a), f), &sn, &cs);
+        pe_sincos(ldexpf(pick3(px_, py_, pz_, a), f), &sn, &cs);
         const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * XYZ_FREQ + q] * sn, f);
         gx += a == 0 ? v : 0.f; gy += a == 1 ? v : 0.f; gz += a == 2 ? v : 0.f;
     }
@@ -819,7 +819,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     for (int i = 0; i < 6; ++i) {
         const int q = 6 * h + i, a = q % 3, f = q / 3;
         float sn, cs;
-        sincosf(ldexpf(pick3(dx, dy, dz, a), f), &sn, &cs);
+        pe_sincos(ldexpf(pick3(dx, dy, dz, a), f), &sn, &cs);
         const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * DIR_FREQ + q] * sn, f);
         hx += a == 0 ? v : 0.f; hy += a == 1 ? v : 0.f; hz += a == 2 ? v : 0.f;
     }

@@ -51,14 +51,14 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         for (int i = 0; i < 15; ++i) {
             const int q = 15 * h + i;
             float sn, cs;
-            sincosf(ldexpf(pick3(x, y, z, q % 3), q / 3), &sn, &cs);
+            pe_sincos(ldexpf(pick3(x, y, z, q % 3), q / 3), &sn, &cs);
             sc[3 + q] = sn; sc[3 + 3 * XYZ_FREQ + q] = cs;
         }
 #pragma unroll 1
         for (int i = 0; i < 6; ++i) {
             const int q = 6 * h + i;
             float sn, cs;
-            sincosf(ldexpf(pick3(dx, dy, dz, q % 3), q / 3), &sn, &cs);
+            pe_sincos(ldexpf(pick3(dx, dy, dz, q % 3), q / 3), &sn, &cs);
             sc[64 + 3 + q] = sn; sc[64 + 3 + 3 * DIR_FREQ + q] = cs;
         }
         if (h == 0) {

@@ -251,7 +251,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     for (int i = 0; i < 15; ++i) {
         const int q = 15 * h + i, a = q % 3, f = q / 3;
         float sn, cs;
-        sincosf(ldexpf(pick3(x, y, z, a), f), &sn, &cs);
+        pe_sincos(ldexpf(pick3(x, y, z, a), f), &sn, &cs);
         const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * XYZ_FREQ + q] * sn, f);
         gx += a == 0 ? v : 0.f; gy += a == 1 ? v : 0.f; gz += a == 2 ? v : 0.f;
     }
@@ -259,7 +259,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     for (int i = 0; i < 6; ++i) {
         const int q = 6 * h + i, a = q % 3, f = q / 3;
         float sn, cs;
-        sincosf(ldexpf(pick3(dx, dy, dz, a), f), &sn, &cs);
+        pe_sincos(ldexpf(pick3(dx, dy, dz, a), f), &sn, &cs);
         const float v = ldexpf(sc[64 + 3 + q] * cs - sc[64 + 3 + 3 * DIR_FREQ + q] * sn, f);
         hx += a == 0 ? v : 0.f; hy += a == 1 ? v : 0.f; hz += a == 2 ? v : 0.f;
     }
