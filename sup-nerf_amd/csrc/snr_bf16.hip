@@ -217,10 +217,14 @@ __device__ __forceinline__ void fwd_quarter(const f32x16& acc, XOp& out, const F
     for (int e = 0; e < 4; ++e) {
         const int r = 4 * j + e;
         const float a = acc[r] + v.b[e];
-        if (MASKS) mask[T >> 1] |= (a > 0.f ? 1u : 0u) << ((T & 1) * 16 + r);      // only stored for ReLU layers
+        // ReLU bits (only stored for ReLU layers), one VALU op per value and no VCC: v_alignbit shifts the word left and
+        // takes in the sign bit of a; the 32 values of a word arrive in register order (tile 2w r0..15, tile 2w+1 r0..15), so
+        // store_mask recovers bit (T&1)*16 + r = "a > 0" as ~bitreverse(word).  (a == +0.0 counts as positive.)
+        if (MASKS) mask[T >> 1] = __builtin_amdgcn_alignbit(mask[T >> 1], __builtin_bit_cast(uint32_t, a), 31);
         split_store(__builtin_amdgcn_fmed3f(a, c.floor, __builtin_inff()) + v.z[e], out, r & 7);   // max(a, floor) in one op
     }
     if (JJ == 1) pin(out);
+    if (MASKS) asm volatile("" : "+v"(mask[T >> 1]));      // keep the bit capture here (LLVM otherwise recomputes it at the layer's end)
 }
 template <int T, int HALF, bool MASKS>
 __device__ __forceinline__ void fwd_half_tile(const f32x16& acc, XOp& out, const FwdEpi& c, int h, uint32_t (&mask)[4]) {
@@ -430,7 +434,8 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     };
     auto store_mask = [&](int l) {   // ReLU bits of layer l (complete once the next layer has consumed all its tiles)
         if (MASKS && l != li_encshape)
-            io.masks[(tile32 * n_relu + relu_slot(l, sb)) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
+            io.masks[(tile32 * n_relu + relu_slot(l, sb)) * 64 + lane] =
+                make_uint4(~__builtin_bitreverse32(mask[0]), ~__builtin_bitreverse32(mask[1]), ~__builtin_bitreverse32(mask[2]), ~__builtin_bitreverse32(mask[3]));
     };
     int li = 1;
 #pragma unroll 1

@@ -45,6 +45,19 @@ for i, n in enumerate(names):
     prev = m
 print("first start -> last end (cycles):", int(t[:, 14].max() - t[:, 0].min()), " waves:", len(t))
 
+# ---------------------------------------------------------------- forward that also saves the ReLU bits (the optimiser's forward)
+masks_dbg = torch.empty(int(good.snr_mask_bytes(N * S, 3, 1)), dtype=torch.uint8, device=dev)
+rgbs_dbg = torch.empty(N * S, 3, device=dev)
+dbg.zero_()
+for _ in range(3):
+    rc = stamps.snr_render_fwd(C.byref(a), rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), dbg.data_ptr(), rgbs_dbg.data_ptr(), masks_dbg.data_ptr(),
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+torch.cuda.synchronize()
+t2 = dbg.cpu().numpy().view(np.uint64).reshape(-1, 16)[: N * S // 32].astype(np.int64)
+d2 = t2 - t2[:, :1]
+print("forward WITH ReLU-bit capture:", "  ".join(f"{n or i}:{int(np.median(d2[:, i]))}" for i, n in enumerate(names) if n))
+
 # ---------------------------------------------------------------- backward timeline (stamps land in the d_t buffer)
 sig = torch.empty(N * S, device=dev); rgbs = torch.empty(N * S, 3, device=dev)
 masks = torch.empty(int(good.snr_mask_bytes(N * S, 3, 1)), dtype=torch.uint8, device=dev)
