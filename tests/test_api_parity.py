@@ -253,6 +253,37 @@ def test_gradients_family_b(amd, dev, model, golden, jitter):
     assert close_grad(pose.grad, g["d_cam_pose"], rel=5e-4)
 
 
+@pytest.mark.parametrize("S", [4, 8, 16, 32, 128])
+def test_fused_render_gradients_other_sample_counts(amd, dev, model, oracle_params, S):
+    """The per-ray gradient sums take a different path for every samples-per-ray count that divides 128 (lanes per ray:
+    shuffles below 16, one DPP row at 16, row pairs at 32, LDS across waves above): forward and backward against the
+    oracle's autograd, family B (per-ray metric depths, white background)."""
+    ops = amd.ops
+    gen = torch.Generator().manual_seed(S)
+    N = 24
+    ro = (torch.randn(N, 3, generator=gen) * 0.05 + torch.tensor([0.0, -2.2, 0.2])).requires_grad_()
+    vd = torch.nn.functional.normalize(torch.randn(N, 3, generator=gen) * 0.1 + torch.tensor([0.0, 1.0, 0.0]), dim=-1).requires_grad_()
+    t = (torch.sort(torch.rand(N, S, generator=gen), dim=-1)[0] * 1.5 + 1.4).requires_grad_()
+    sc = (torch.randn(1, 256, generator=gen) * 0.3).requires_grad_()
+    tc = (torch.randn(1, 256, generator=gen) * 0.3).requires_grad_()
+    wts = [torch.randn(N, 3, generator=gen), torch.randn(N, generator=gen) * 0.1, torch.randn(N, generator=gen)]
+    diag = 5.2
+    xyz = ro[:, None, :] + vd[:, None, :] * t[:, :, None]
+    z_metric = torch.norm(xyz - ro[:, None, :], dim=-1) * (diag / 2)
+    xyz_o, vd_o = O.object_frame_transforms(xyz, vd[:, None, :].repeat(1, S, 1), False, False, True)
+    sig, rgb = O.decoder_forward(oracle_params, xyz_o, vd_o, sc, tc)
+    ref = O.composite(sig, rgb, z_metric, white_bkgd=True)
+    sum((a * b).sum() for a, b in zip(ref, wts)).backward()
+    leaves = [x.detach().to(dev).requires_grad_() for x in (ro, vd, t, sc, tc)]
+    cfg = ops.RenderCfg(S, ops.Z_PER_RAY, N, 3, 1, frame=amd.utils._frame(False, False, True), white_bkgd=True, metric_z=True, precision=None)
+    out = model.fused_render(leaves[0], leaves[1], leaves[2], torch.ones(1, device=dev), torch.full((1,), diag / 2, device=dev),
+                             leaves[3], leaves[4], cfg)
+    sum((a * b.to(dev)).sum() for a, b in zip(out, wts)).backward()
+    assert md(out[0], ref[0]) < TOL_RGB and md(out[1], ref[1]) < TOL_DEPTH_MAX and md(out[2], ref[2]) < TOL_ACC
+    for got, want, rel in zip(leaves, (ro, vd, t, sc, tc), (3e-3, 3e-3, 3e-3, 2e-3, 2e-3)):   # few rays, few samples: nothing averages out, split-bf16 noise shows
+        assert close_grad(got.grad, want.grad, rel=rel), (S, float((got.grad.cpu() - want.grad).abs().max()), float(want.grad.abs().max()))
+
+
 def test_training_shapes_volume_rendering_batch(amd, dev, model, golden):
     """Decoder half of ParallelModel.forward (src/trainer_unified_nuscenes.py:120-129): batched codes, per-object z."""
     g = golden("train_step")
