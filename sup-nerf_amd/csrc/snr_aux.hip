@@ -198,8 +198,9 @@ __global__ void __launch_bounds__(256) encode_kernel(RayGeom g, float* __restric
         if (f < 3) v = sx[p][f];
         else {
             const int q = (f - 3) % (3 * XYZ_FREQ);
-            const float arg = ldexpf(sx[p][q % 3], q / 3);
-            v = (f < 3 + 3 * XYZ_FREQ) ? sinf(arg) : cosf(arg);
+            float sn, cs;
+            pe_sincos(ldexpf(sx[p][q % 3], q / 3), &sn, &cs);
+            v = (f < 3 + 3 * XYZ_FREQ) ? sn : cs;
         }
         pe_xyz[base * D_XYZ + i] = v;
     }
@@ -217,8 +218,9 @@ __global__ void encode_dir_kernel(RayGeom g, float* __restrict__ pe_dir) {
     if (f < 3) v = pick3(vx, vy, vz, f);
     else {
         const int q = (f - 3) % (3 * DIR_FREQ);
-        const float arg = ldexpf(pick3(vx, vy, vz, q % 3), q / 3);
-        v = (f < 3 + 3 * DIR_FREQ) ? sinf(arg) : cosf(arg);
+        float sn, cs;
+        pe_sincos(ldexpf(pick3(vx, vy, vz, q % 3), q / 3), &sn, &cs);
+        v = (f < 3 + 3 * DIR_FREQ) ? sn : cs;
     }
     pe_dir[i] = v;
 }
