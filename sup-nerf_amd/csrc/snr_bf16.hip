@@ -699,7 +699,17 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
             const float ur = io.d_rgb ? io.d_rgb[rr * 3] : 0.f, ug = io.d_rgb ? io.d_rgb[rr * 3 + 1] : 0.f,
                         ub = io.d_rgb ? io.d_rgb[rr * 3 + 2] : 0.f;
             const float ud = io.d_depth ? io.d_depth[rr] : 0.f, ua = io.d_acc ? io.d_acc[rr] : 0.f;
-            composite_ray_bwd<2>(S, lane, white, ur, ug, ub, ud, ua,
+            if (S <= 64) composite_ray_bwd<1>(S, lane, white, ur, ug, ub, ud, ua,
+                [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
+                    s_ = srow[k]; r_ = crow[3 * k]; g_ = crow[3 * k + 1]; b_ = crow[3 * k + 2];
+                    z_ = c0[k * COMP_STRIDE + 5];
+                    zn_ = (k < S - 1) ? c0[(k + 1) * COMP_STRIDE + 5] : 0.f;
+                },
+                [&](int k, float ds, float dcr, float dcg, float dcb, float dzz) {
+                    float* c = c0 + k * COMP_STRIDE;
+                    c[0] = ds; c[1] = dcr; c[2] = dcg; c[3] = dcb; c[4] = dzz;
+                });
+            else composite_ray_bwd<2>(S, lane, white, ur, ug, ub, ud, ua,
                 [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
                     s_ = srow[k]; r_ = crow[3 * k]; g_ = crow[3 * k + 1]; b_ = crow[3 * k + 2];
                     z_ = c0[k * COMP_STRIDE + 5];

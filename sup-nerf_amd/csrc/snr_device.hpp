@@ -51,24 +51,35 @@ __device__ __forceinline__ float wave_sum(float v) {
     return sum_halves(sum_row_pairs(row_sum(v)));           // 6 VALU ops instead of 6 ds_bpermute round trips
 }
 
-// inclusive product scan over the 64 lanes
-__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        float u = __shfl_up(v, off, 64);
-        if (lane >= off) v *= u;
-    }
+// DPP moves whose lanes without a source (shifted in from outside the row / wave, or rows masked out) keep `old`
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_or(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+// lane k <- lane k-1 across the whole wave (wave_shr:1), lane 0 <- fill
+__device__ __forceinline__ float wave_shift_up1(float v, float fill) { return dpp_or<0x138>(fill, v); }
+__device__ __forceinline__ float wave_lane(float v, int uniform_lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), uniform_lane));
+}
+
+// inclusive product scan over the 64 lanes: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8), then the row totals
+// travel with row_bcast:15 (into rows 1 and 3) and row_bcast:31 (into rows 2 and 3) -- six VALU ops, no ds_bpermute
+__device__ __forceinline__ float wave_scan_mul(float v, int /*lane*/) {
+    v *= dpp_or<0x111>(1.f, v); v *= dpp_or<0x112>(1.f, v); v *= dpp_or<0x114>(1.f, v); v *= dpp_or<0x118>(1.f, v);
+    v *= dpp_or<0x142, 0xa>(1.f, v);
+    v *= dpp_or<0x143, 0xc>(1.f, v);
+    return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v) {
+    v += dpp_or<0x111>(0.f, v); v += dpp_or<0x112>(0.f, v); v += dpp_or<0x114>(0.f, v); v += dpp_or<0x118>(0.f, v);
+    v += dpp_or<0x142, 0xa>(0.f, v);
+    v += dpp_or<0x143, 0xc>(0.f, v);
     return v;
 }
 
-// inclusive suffix sum over the 64 lanes (lane k gets sum_{j>=k} v_j)
+// inclusive suffix sum over the 64 lanes (lane k gets sum_{j>=k} v_j): the prefix scan on the reversed wave
 __device__ __forceinline__ float wave_suffix_sum(float v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        float u = __shfl_down(v, off, 64);
-        if (lane + off < 64) v += u;
-    }
-    return v;
+    return __shfl(wave_scan_add(__shfl(v, 63 - lane, 64)), 63 - lane, 64);
 }
 
 // ------------------------------------------------------------------ positional-encoding sin / cos
@@ -180,18 +191,17 @@ __device__ __forceinline__ RayOut composite_ray_fwd(int S, int lane, bool white,
         const float alpha = 1.f - expf(-fmaxf(sig, 0.f) * delta);
         const float T = valid ? (1.f - alpha) + TRANS_EPS : 1.f;
         const float incl = wave_scan_mul(T, lane);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.f;
+        const float excl = wave_shift_up1(incl, 1.f);
         const float A = carry * excl;
         const float w = valid ? alpha * A : 0.f;
         sr += w * cr; sg += w * cg; sb += w * cb; sd += w * z; sw += w;
         if (k == S - 1) acc = A;
-        carry *= __shfl(incl, 63, 64);
+        carry *= wave_lane(incl, 63);
     }
     RayOut o;
     o.r = wave_sum(sr); o.g = wave_sum(sg); o.b = wave_sum(sb); o.depth = wave_sum(sd);
     const float wsum = wave_sum(sw);
-    o.acc = __shfl(acc, (S - 1) & 63, 64);
+    o.acc = wave_lane(acc, (S - 1) & 63);
     if (white) { const float bg = 1.f - wsum; o.r += bg; o.g += bg; o.b += bg; }
     return o;
 }
@@ -217,15 +227,14 @@ __device__ __forceinline__ void composite_ray_bwd(int S, int lane, bool white, f
         const float alpha = 1.f - e[c];
         T[c] = valid ? (1.f - alpha) + TRANS_EPS : 1.f;
         const float incl = wave_scan_mul(T[c], lane);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.f;
+        const float excl = wave_shift_up1(incl, 1.f);
         A[c] = carry * excl;
         w[c] = valid ? alpha * A[c] : 0.f;
         dw[c] = valid ? (g_r * cr[c] + g_g * cg[c] + g_b * cb[c] + g_depth * z[c] - g_white) : 0.f;
         if (k == S - 1) acc_last = A[c];
-        carry *= __shfl(incl, 63, 64);
+        carry *= wave_lane(incl, 63);
     }
-    acc_last = __shfl(acc_last, (S - 1) & 63, 64);
+    acc_last = wave_lane(acc_last, (S - 1) & 63);
     // reverse pass: R_k = sum_{j>k} dw_j w_j  (+ g_acc * A_{S-1} for k < S-1)
     float tail = 0.f;           // sum over later chunks
     float dd[NCH];
@@ -236,7 +245,7 @@ __device__ __forceinline__ void composite_ray_bwd(int S, int lane, bool white, f
         const float p = dw[c] * w[c];
         const float incl = wave_suffix_sum(p, lane);
         const float R = (incl - p) + tail + ((k < S - 1) ? g_acc * acc_last : 0.f);
-        tail += __shfl(incl, 0, 64);
+        tail += wave_lane(incl, 0);
         const float dT = R / T[c];
         const float dalpha = dw[c] * A[c] - dT;
         const float s = fmaxf(sig[c], 0.f);
@@ -250,9 +259,8 @@ __device__ __forceinline__ void composite_ray_bwd(int S, int lane, bool white, f
         const int k = c * 64 + lane;
         const bool valid = k < S;
         // d_z_k = w_k g_depth + d_delta_{k-1} - d_delta_k
-        float prev = __shfl_up(dd[c], 1, 64);
-        const float prev_chunk_last = (c > 0) ? __shfl(dd[c > 0 ? c - 1 : 0], 63, 64) : 0.f;   // all lanes take part
-        if (lane == 0) prev = prev_chunk_last;
+        const float prev_chunk_last = (c > 0) ? wave_lane(dd[c > 0 ? c - 1 : 0], 63) : 0.f;
+        const float prev = wave_shift_up1(dd[c], prev_chunk_last);
         const float dz = w[c] * g_depth + prev - dd[c];
         if (valid) emit(k, sig[c], w[c] * g_r, w[c] * g_g, w[c] * g_b, dz);
     }
