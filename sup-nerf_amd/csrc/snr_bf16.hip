@@ -313,7 +313,7 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
 
 // ------------------------------------------------------------------------------------------ forward kernel
 #ifdef SNR_STAMPS
-#define SNR_STAMP(i) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+#define SNR_STAMP(i) do { if (lane == 0 && tile32 * 32 < io.n_points) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     reinterpret_cast<unsigned long long*>(io.sigmas)[tile32 * 16 + (i)] = t_; } } while (0)
 #else
 #define SNR_STAMP(i) do {} while (0)
@@ -432,8 +432,9 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         c.zl = la >= 0 ? latw + la * 256 : vec + VEC_ZERO;
         return c;
     };
+    const bool tile_live = tile32 * 32 < io.n_points;     // the last workgroup may own wave tiles past the end: they store nothing
     auto store_mask = [&](int l) {   // ReLU bits of layer l (complete once the next layer has consumed all its tiles)
-        if (MASKS && l != li_encshape)
+        if (MASKS && tile_live && l != li_encshape)
             io.masks[(tile32 * n_relu + relu_slot(l, sb)) * 64 + lane] =
                 make_uint4(~__builtin_bitreverse32(mask[0]), ~__builtin_bitreverse32(mask[1]), ~__builtin_bitreverse32(mask[2]), ~__builtin_bitreverse32(mask[3]));
     };
@@ -487,7 +488,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
                     pr = fmaf(wr[e], v, pr); pg = fmaf(wg[e], v, pg); pb = fmaf(wb[e], v, pb);
                 }
             }
-        if (MASKS) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mk[0], mk[1], 0u, 0u);
+        if (MASKS && tile_live) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mk[0], mk[1], 0u, 0u);
     }
     const float cr = sum_halves(pr) + vec[VEC_MISC + 4];
     const float cg = sum_halves(pg) + vec[VEC_MISC + 5];
@@ -639,7 +640,7 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
 }
 
 #ifdef SNR_STAMPS
-#define SNR_BSTAMP(i) do { if (io.d_t && lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+#define SNR_BSTAMP(i) do { if (io.d_t && lane == 0 && tile32 * 32 < io.n_points) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     reinterpret_cast<unsigned long long*>(io.d_t)[tile32 * 16 + (i)] = t_; } } while (0)
 #else
 #define SNR_BSTAMP(i) do {} while (0)
@@ -664,9 +665,10 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     vec[VEC_SIGW + tid] = io.packed[L.sigma_w + tid];
     vec[VEC_ZERO + tid] = 0.f;
     for (int i = tid; i < 384; i += 256) vec[VEC_RGBW + i] = io.packed[L.rgb2_w + i];
+    const bool tile_live = tile32 * 32 < io.n_points;         // wave tiles past the end (last workgroup) read and store nothing
     uint4 mk[MAX_LAYERS - 1];                                  // ReLU bits of every ReLU layer of this wave tile
 #pragma unroll
-    for (int s = 0; s < MAX_LAYERS - 1; ++s) mk[s] = (s < n_relu) ? io.masks[(tile32 * n_relu + s) * 64 + lane] : make_uint4(0, 0, 0, 0);
+    for (int s = 0; s < MAX_LAYERS - 1; ++s) mk[s] = (s < n_relu && tile_live) ? io.masks[(tile32 * n_relu + s) * 64 + lane] : make_uint4(0, 0, 0, 0);
     float px_, py_, pz_, dx, dy, dz, tval = 0.f, zc = 0.f;
     long long ray = 0;
     if (MODE == 0) {
@@ -805,7 +807,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
 
     SNR_BSTAMP(12);
     // ---- the parked latent-term gradients of this wave tile -> global partials (the ring is idle now)
-    if (io.partial) {
+    if (io.partial && tile_live) {
         const float* dzl = reinterpret_cast<const float*>(lds + OFF_LAT) + wave * MAX_LAT * 256;
         for (int la = 0; la < L.n_lat; ++la)
             *reinterpret_cast<f32x4*>(io.partial + (tile32 * L.n_lat + la) * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(dzl + la * 256 + lane * 4);

@@ -32,6 +32,8 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     const int p = lane & 31, h = lane >> 5;
     const int sb = io.sb, tb = io.tb;
     const int n_relu = n_relu_layers(sb, tb);
+    // a workgroup covers 4 wave tiles; the last one of a launch may own tiles past the end (buffers are sized for ceil(P/32) tiles)
+    const bool tile_live = tile32 * 32 < io.n_points;
     const float* bias = io.packed + L.bias;
     const float* lat = io.latent + (gp / io.points_per_obj) * (long long)L.n_lat * 256;
 
@@ -85,7 +87,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     {
         const int la = latent_after(0, sb, tb);
         epilogue<8, 8>(acc, in, true, la >= 0 ? lat + la * 256 : nullptr, h, mask);
-        if (io.masks) io.masks[(tile32 * n_relu + 0) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
+        if (io.masks && tile_live) io.masks[(tile32 * n_relu + 0) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
         if (io.act && live) dump_operand<8>(in, io.act + ((long long)0 * io.n_points + gp) * 256, h);
     }
 
@@ -109,7 +111,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         const bool relu = (li != li_encshape);
         const int la = latent_after(li, sb, tb);
         epilogue<8, 8>(acc, in, relu, la >= 0 ? lat + la * 256 : nullptr, h, mask);
-        if (relu && io.masks)
+        if (relu && io.masks && tile_live)
             io.masks[(tile32 * n_relu + relu_slot(li, sb)) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
         if (io.act && live) dump_operand<8>(in, io.act + ((long long)li * io.n_points + gp) * 256, h);
         if (li == li_encshape) {
@@ -140,7 +142,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     step<4, 8>(acc, in[6], pipe, lds, 128, tid);
     step<4, 8>(acc, in[7], pipe, lds, 0, tid);
     epilogue<4, 8>(acc, in, true, nullptr, h, mask);
-    if (io.masks) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mask[0], mask[1], 0u, 0u);
+    if (io.masks && tile_live) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mask[0], mask[1], 0u, 0u);
     if (io.act && live) dump_operand<4>(in, io.act + ((long long)(li_last + 1) * io.n_points + gp) * 256, h);
     {
         const float* w2 = io.packed + L.rgb2_w;

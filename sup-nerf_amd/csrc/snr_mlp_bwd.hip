@@ -99,6 +99,9 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     const int sb = io.sb, tb = io.tb;
     const int n_relu = n_relu_layers(sb, tb);
     const int li_encshape = sb + 1, li_view = sb + 2, li_last = sb + tb + 2;
+    // wave tiles past the end of the launch (last workgroup): read tile 0's ReLU bits (results are discarded), store nothing
+    const bool tile_live = tile32 * 32 < io.n_points;
+    const long long tile32m = tile_live ? tile32 : 0;
 
     // ---- start the transposed weight stream
     Pipe pipe;
@@ -175,7 +178,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
 
     // ---- colour head backward: g_h = W2^T d_rgb, masked by rgb.0's ReLU
     {
-        const uint4 mk = io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane];
+        const uint4 mk = io.masks[(tile32m * n_relu + (n_relu - 1)) * 64 + lane];
         const uint32_t m[2] = {mk.x, mk.y};
         const float* w2 = io.packed + L.rgb2_w;
 #pragma unroll
@@ -212,7 +215,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
         const bool is_view = (li == li_view);
         const bool relu = (li != li_encshape);
         // acc = gradient wrt the OUTPUT of layer li; enc_shape's output also feeds the density head
-        masked_to_operand<8>(acc, in, relu ? io.masks + (tile32 * n_relu + relu_slot(li, sb)) * 64 + lane : nullptr,
+        masked_to_operand<8>(acc, in, relu ? io.masks + (tile32m * n_relu + relu_slot(li, sb)) * 64 + lane : nullptr,
                              li == li_encshape ? io.packed + L.sigma_w : nullptr, dpre, h);
         if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)li * io.n_points + gp) * 256, h);
         acc_zero<9>(acc);
@@ -227,7 +230,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
         step<8, 9>(acc, in[7], pipe, lds, rows_after, tid, is_view);
         // acc = gradient wrt the INPUT of layer li = previous output + latent term
         const int la = latent_after(li - 1, sb, tb);
-        if (la >= 0 && io.partial) reduce_points_store(acc, io.partial + (tile32 * L.n_lat + la) * 256, lane);
+        if (la >= 0 && io.partial && tile_live) reduce_points_store(acc, io.partial + (tile32 * L.n_lat + la) * 256, lane);
         if (is_view) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) gdir[r] = acc[8][r];
@@ -235,7 +238,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     }
 
     // ---- enc_xyz^T : 256 -> 64 positional-encoding features
-    masked_to_operand<8>(acc, in, io.masks + (tile32 * n_relu + 0) * 64 + lane, nullptr, 0.f, h);
+    masked_to_operand<8>(acc, in, io.masks + (tile32m * n_relu + 0) * 64 + lane, nullptr, 0.f, h);
     if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)0 * io.n_points + gp) * 256, h);
     acc_zero<2>(acc);
     step<2, 9>(acc, in[0], pipe, lds, 64, tid);
