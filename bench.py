@@ -202,7 +202,7 @@ def main():
     # ---- the two HBM-bound stand-alone kernels (encode with PE output, composite) at 16 objects x 4096 x 64: achieved GB/s
     hbm = {}
     if rank == 0:
-        Bh = 16
+        Bh = 64
         ro_h, vd_h = rays_o.repeat(Bh, 1), viewdir.repeat(Bh, 1)
         z_h = z[None].repeat(Bh, 1).contiguous()
         div_h = div.repeat(Bh)
