@@ -272,11 +272,17 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
     load_frags<NTH, 0>(fa, w);
 // interleave request for one half-step region: after every MFMA one LDS read (while there are any) and two VALU ops, so the
 // fragment fetches for the next half-step and the previous layer's epilogue are spread under the MFMAs instead of in blocks
+#ifndef SNR_IL_DS
+#define SNR_IL_DS 0     /* measured: asking for an LDS read per group costs 2-4 %; the VALU request alone is best */
+#endif
+#ifndef SNR_IL_VALU
+#define SNR_IL_VALU 4
+#endif
 #define SNR_INTERLEAVE(N_MFMA)                                                           \
     _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA); ++g_) {                            \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                               \
+        if (SNR_IL_DS) __builtin_amdgcn_sched_group_barrier(0x100, SNR_IL_DS, 0);        \
+        if (SNR_IL_VALU) __builtin_amdgcn_sched_group_barrier(0x002, SNR_IL_VALU, 0);    \
     }
 #define SNR_FSTEP(S)                                                                                                   \
     {                                                                                                                  \

@@ -1,0 +1,48 @@
+"""A/B timing of library variants (tools/build_variant.sh): forward, forward with ReLU bits and backward of the fused render at
+4096 x 64, device-event times.  usage: python tools/ab_time.py NAME [NAME ...]   (NAME 'shipped' = the in-tree library)"""
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import supnerf_amd as A
+from supnerf_amd import _lib, ops, synthetic as SY, utils as U
+good = _lib.lib()
+dev = torch.device("cuda:0")
+model = A.CodeNeRF(3, 1); model.load_state_dict(SY.init_decoder_params()); model = model.to(dev)
+N, S = 4096, 64
+ob = SY.synthetic_object(100)
+g = torch.Generator().manual_seed(100)
+sc = (torch.randn(1, 256, generator=g) * 0.3).to(dev); tc = (torch.randn(1, 256, generator=g) * 0.3).to(dev)
+with torch.no_grad():
+    ro, vd = U.get_rays(ob["K"], ob["cam_pose"].to(dev), ob["roi"], uv_steps=[64, 64])
+    near, far = U._sphere_bounds(ob["cam_pose"], ob["obj_diag"])
+    z = U._shared_depths(near, far, S, dev, jitter=torch.rand(S, generator=g))
+    lat = model.latent_terms(sc, tc).contiguous()
+pk = model.packed_weights()
+div = torch.full((1,), float(ob["obj_diag"]), device=dev)
+ro, vd = ro.contiguous(), vd.contiguous()
+a = ops._render_args(ro, vd, z, div, None, lat, pk, U._frame(False, False, True), 1.0, ops.Z_SHARED, 0, N, S, 3, 1, 1)
+rgb = torch.empty(N, 3, device=dev); depth = torch.empty(N, device=dev); acc = torch.empty(N, device=dev)
+sig = torch.empty(N * S, device=dev); rgbs = torch.empty(N * S, 3, device=dev)
+masks = torch.empty(int(good.snr_mask_bytes(N * S, 3, 1)), dtype=torch.uint8, device=dev)
+d_rgb = torch.rand(N, 3, device=dev); d_depth = torch.rand(N, device=dev); d_acc = torch.rand(N, device=dev)
+d_lat = torch.empty_like(lat); d_o = torch.zeros(N, 3, device=dev); d_d = torch.zeros(N, 3, device=dev)
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+def timed(fn, n=30):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+for name in sys.argv[1:]:
+    lib = good if name == "shipped" else C.CDLL(os.path.join(ROOT, "tools", "_diag", f"libvariant_{name}.so"), mode=os.RTLD_NOW | os.RTLD_DEEPBIND)
+    for fn in ("snr_render_fwd", "snr_render_bwd", "snr_render_bwd_ws_bytes"):
+        getattr(lib, fn).restype, getattr(lib, fn).argtypes = _lib._SIGS[fn]
+    wsb = lib.snr_render_bwd_ws_bytes(C.byref(a)); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    f0 = lambda: lib.snr_render_fwd(C.byref(a), rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), None, None, None, st())
+    f1 = lambda: lib.snr_render_fwd(C.byref(a), rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), sig.data_ptr(), rgbs.data_ptr(), masks.data_ptr(), st())
+    b = lambda: lib.snr_render_bwd(C.byref(a), sig.data_ptr(), rgbs.data_ptr(), masks.data_ptr(), d_rgb.data_ptr(), d_depth.data_ptr(), d_acc.data_ptr(),
+                                   d_lat.data_ptr(), d_o.data_ptr(), d_d.data_ptr(), None, ws.data_ptr(), wsb, st())
+    assert f1() == 0 and b() == 0
+    print(f"{name:14s} fwd {timed(f0):.4f} ms   fwd+bits {timed(f1):.4f} ms   bwd {timed(b):.4f} ms", flush=True)
