@@ -481,6 +481,107 @@ def nerf_renderer_render_rays(model, img, mask_occ, cam_pose, obj_sz, K, roi, sh
     return rgb_r, depth_r, acc_r, rgb_tgt, occ
 
 
+def nerf_renderer_render_rays_specified(model, img, mask_occ, cam_pose, obj_sz, K, roi, x_vec, y_vec, shapecode, texturecode,
+                                        n_samples=64, white_bkgd=True, kitti2nusc=False, jitter=None):
+    """Family B at listed crop pixels.  Restates ``NeRFRenderer.render_rays_specified`` (src/renderer.py:169-201)."""
+    rays_o, viewdir = pixel_rays_at(K, cam_pose, np.asarray(x_vec) + int(roi[0]), np.asarray(y_vec) + int(roi[1]))
+    rgb_tgt, occ = img[y_vec, x_vec, :], mask_occ[y_vec, x_vec, :]
+    xyz, vd, z_vals, _hit = aabb_sampled_rays(rays_o, viewdir, obj_sz, n_samples, jitter)
+    xyz, vd = object_frame_transforms(xyz, vd, False, kitti2nusc, False)
+    sig, rgb = _decode(model, xyz, vd, shapecode, texturecode)
+    rgb_r, depth_r, acc_r = composite(sig, rgb, z_vals, white_bkgd=white_bkgd)
+    return rgb_r, depth_r, acc_r, rgb_tgt, occ
+
+
+def nerf_renderer_prepare_pixel_samples(img, mask_occ, cam_pose, obj_sz, K, roi, n_rays, n_samples=64, im_sz=None, ray_ids=None,
+                                        jitter=None):
+    """Pre-sampled family-B ray batch.  Restates ``NeRFRenderer.prepare_pixel_samples`` (src/renderer.py:203-236);
+    ``ray_ids`` = the first n_rays entries of its ``np.random.permutation`` draw."""
+    if im_sz is None:
+        rays_o, viewdir = pixel_rays(K, cam_pose, roi)
+    else:
+        rays_o, viewdir = pixel_rays(K, cam_pose, roi, uv_steps=[im_sz, im_sz])
+        img, mask_occ = resize_targets(img, mask_occ, im_sz)
+    rays_o, viewdir = rays_o[ray_ids], viewdir[ray_ids]
+    rgb_tgt, occ = img.reshape(-1, 3)[ray_ids], mask_occ.reshape(-1, 1)[ray_ids]
+    xyz, vd, z_vals, _hit = aabb_sampled_rays(rays_o, viewdir, obj_sz, n_samples, jitter)
+    return xyz, vd, z_vals, rgb_tgt, occ
+
+
+def nerf_renderer_render_full_img(model, cam_pose, obj_sz, K, roi, shapecode, texturecode, n_samples=64, white_bkgd=True,
+                                  out_depth=False, kitti2nusc=False, jitter=None):
+    """Family B, every pixel of the roi, decoder called in slabs of max(roi_w, roi_h) rays.
+    Restates ``NeRFRenderer.render_full_img`` (src/renderer.py:238-294)."""
+    rays_o, viewdir = pixel_rays(K, cam_pose, roi)
+    xyz, vd, z_vals, _hit = aabb_sampled_rays(rays_o, viewdir, obj_sz, n_samples, jitter)
+    xyz, vd = object_frame_transforms(xyz, vd, False, kitti2nusc, False)
+    h, w = int(roi[3] - roi[1]), int(roi[2] - roi[0])
+    step = max(h, w)
+    parts = []
+    for i in range(0, xyz.shape[0], step):
+        sig, rgb = _decode(model, xyz[i:i + step], vd[i:i + step], shapecode, texturecode)
+        parts.append(composite(sig, rgb, z_vals[i:i + step], white_bkgd=white_bkgd))
+    rgb_r = torch.cat([p_[0] for p_ in parts]).reshape(h, w, 3)
+    if out_depth:
+        return rgb_r, torch.cat([p_[1] for p_ in parts]).reshape(h, w)
+    return rgb_r
+
+
+def turntable_poses(radius=40.0, tilt=np.pi / 6, pan_num=8):
+    """The camera-in-object poses (3,4) of ``render_virtual_imgs`` (src/utils.py:633-650 == src/renderer.py:309-326)."""
+    cam_init = np.asarray([[0, 0, 1, -radius], [-1, 0, 0, 0], [0, -1, 0, 0], [0, 0, 0, 1]]).astype(np.float32)
+    cam_tilt = np.asarray([[np.cos(tilt), 0, np.sin(tilt), 0], [0, 1, 0, 0], [-np.sin(tilt), 0, np.cos(tilt), 0],
+                           [0, 0, 0, 1]]).astype(np.float32) @ cam_init
+    out = []
+    for pan in np.linspace(0, 2 * np.pi, pan_num, endpoint=False):
+        pose = np.asarray([[np.cos(pan), -np.sin(pan), 0, 0], [np.sin(pan), np.cos(pan), 0, 0], [0, 0, 1, 0],
+                           [0, 0, 0, 1]]).astype(np.float32) @ cam_tilt
+        out.append(torch.from_numpy(pose[:3, :]))
+    return out
+
+
+def virtual_roi(K, img_sz):
+    x0, y0 = K[0, 2] - img_sz / 2, K[1, 2] - img_sz / 2
+    return np.asarray([x0, y0, x0 + img_sz, y0 + img_sz]).astype(np.int64)
+
+
+def render_virtual_imgs(model, obj_sz, K, n_samples, shapecode, texturecode, shapenet_obj_cood, radius=40., tilt=np.pi / 6,
+                        pan_num=8, img_sz=128, kitti2nusc=False, jitters=None):
+    """Family A turntable views WITHOUT the axis arrows the reference draws with cv2 (src/utils.py:619-672)."""
+    roi = virtual_roi(K, img_sz)
+    return [render_full_img(model, pose, obj_sz, K, roi, n_samples, shapecode, texturecode, shapenet_obj_cood, kitti2nusc=kitti2nusc,
+                            jitter=None if jitters is None else jitters[i]) for i, pose in enumerate(turntable_poses(radius, tilt, pan_num))]
+
+
+def nerf_renderer_render_virtual_imgs(model, obj_sz, K, shapecode, texturecode, n_samples=64, white_bkgd=True, radius=40.,
+                                      tilt=np.pi / 6, pan_num=8, img_sz=128, kitti2nusc=False, jitters=None):
+    """Family B turntable views without the cv2 arrows (src/renderer.py:296-352)."""
+    roi = virtual_roi(K, img_sz)
+    return [nerf_renderer_render_full_img(model, pose, obj_sz, K, roi, shapecode, texturecode, n_samples, white_bkgd,
+                                          kitti2nusc=kitti2nusc, jitter=None if jitters is None else jitters[i])
+            for i, pose in enumerate(turntable_poses(radius, tilt, pan_num))]
+
+
+def srn_rays(H, W, focal, c2w):
+    """``get_rays_srn`` (src/utils.py:94-104): ShapeNet-SRN camera convention (y up, looking down -z)."""
+    xs, ys = torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H)
+    px, py = xs[None, :].expand(H, W), ys[:, None].expand(H, W)
+    cam = torch.stack([(px - W * .5) / focal, -(py - H * .5) / focal, -torch.ones_like(px)], -1)
+    world = (cam[..., None, :] * c2w[:3, :3]).sum(-1)
+    unit = world / torch.norm(world, dim=-1, keepdim=True)
+    return c2w[:3, -1].expand(world.shape).reshape(-1, 3), unit.reshape(-1, 3)
+
+
+def volume_rendering_legacy(sigmas, rgbs, z_vals):
+    """``volume_rendering`` (src/utils.py:187-199): two outputs and NO relu on the densities."""
+    deltas = torch.cat([z_vals[1:] - z_vals[:-1], torch.ones_like(z_vals[:1]) * LAST_DELTA])
+    alphas = 1 - torch.exp(-sigmas.squeeze(-1) * deltas)
+    trans = 1 - alphas + TRANS_EPS
+    acc = torch.cumprod(torch.cat([torch.ones_like(trans[..., :1]), trans], -1), -1)[..., :-1]
+    w = alphas * acc
+    return torch.sum(w.unsqueeze(-1) * rgbs, -2), torch.sum(w * z_vals, -1)
+
+
 def render_rays_v3(model, img, mask_occ, cam_pose, obj_wlh, K, roi, n_samples, shapecode, texturecode,
                    shapenet_obj_cood, sym_flip=False, kitti2nusc=False, im_sz=64, ray_ids=None,
                    adjust_scale=1.0, jitter=None):

@@ -26,7 +26,7 @@ def _unit_depths(near, far, n_samples, jitter=None):
     step = 1.0 / n_samples
     t = torch.linspace(0, 1 - step, n_samples, device=near.device)[None, :].repeat(near.shape[0], 1)
     if jitter is None:
-        jitter = U.JITTER_OVERRIDE
+        jitter = U._jitter_override()
     t = t + (torch.rand_like(t) if jitter is None else jitter.to(t.device)) * step
     return near * (1 - t) + far * t
 

@@ -83,8 +83,16 @@ def _linspace(start, end, steps, device):
     return torch.where(i < steps // 2, lo, hi)
 
 
-# test hook: a tensor here replaces the next jitter draws (parity tests inject the reference's numbers)
+# test hook: a tensor here replaces every following jitter draw, a list is consumed one tensor per draw (parity tests inject
+# the reference's numbers)
 JITTER_OVERRIDE = None
+
+
+def _jitter_override():
+    global JITTER_OVERRIDE
+    if isinstance(JITTER_OVERRIDE, list):
+        return JITTER_OVERRIDE.pop(0) if JITTER_OVERRIDE else None
+    return JITTER_OVERRIDE
 
 
 def _shared_depths(near, far, n_samples, device, z_fixed=False, jitter=None):
@@ -95,7 +103,9 @@ def _shared_depths(near, far, n_samples, device, z_fixed=False, jitter=None):
     half = (far - near) / (2 * n_samples)
     z = _linspace(near + half, far - half, n_samples, device)
     if jitter is None:
-        jitter = JITTER_OVERRIDE if JITTER_OVERRIDE is not None else torch.rand(n_samples)
+        jitter = _jitter_override()
+        if jitter is None:
+            jitter = torch.rand(n_samples)
     return z + jitter.to(device) * (far - near) / (2 * n_samples)
 
 

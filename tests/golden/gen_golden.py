@@ -40,6 +40,7 @@ from oracle import supnerf_oracle as O  # noqa: E402
 # ---------------------------------------------------------------- reference import
 def import_reference():
     cv2 = types.ModuleType("cv2")
+    cv2.arrowedLine = lambda img, *a, **k: img        # render_virtual_imgs draws axis arrows on a finished image: left out
     tv = types.ModuleType("torchvision")
     tvt = types.ModuleType("torchvision.transforms")
 
@@ -235,6 +236,108 @@ def scene_fixture(RU, RR, model, params):
          valid=valid, canvas=canvas, image=img8, **inter)
 
 
+def twins_fixture(RU, RR, model, params):
+    """(viii) the rest of the render API: NeRFRenderer's other methods (src/renderer.py:169-352), both render_virtual_imgs
+    (axis arrows left out through the inert cv2 stand-in), and the small utilities next to the path."""
+    ob = O.synthetic_object(7)
+    img, mask = O.synthetic_targets(7, 12)
+    g = torch.Generator().manual_seed(303)
+    sc, tc = torch.randn(1, 256, generator=g) * 0.3, torch.randn(1, 256, generator=g) * 0.3
+    K, pose, wlh, roi = ob["K"], ob["cam_pose"], ob["wlh"], ob["roi"]
+    rend = RR.NeRFRenderer(n_samples=32, white_bkgd=True)
+    out = {}
+    # render_rays_specified
+    x_vec, y_vec = np.array([1, 5, 7, 3, 10, 0, 6, 9, 2, 11, 4, 8]), np.array([2, 2, 9, 5, 1, 11, 6, 3, 8, 10, 0, 7])
+    torch.manual_seed(5)
+    with torch.no_grad(), RandTap() as tap:
+        ref = rend.render_rays_specified(model, "cpu", img, mask, pose, wlh, K, roi, x_vec, y_vec, sc, tc)
+    with torch.no_grad():
+        ora = O.nerf_renderer_render_rays_specified(params, img, mask, pose, wlh, K, roi, x_vec, y_vec, sc, tc, n_samples=32, jitter=tap.draws[0])
+    for a, b, n in zip(ora, ref, ("rgb", "depth", "acc", "tgt", "occ")):
+        assert_same("B specified " + n, a, b)
+    out.update(spec_x=x_vec, spec_y=y_vec, spec_jitter=tap.draws[0], spec_rgb=ref[0], spec_depth=ref[1], spec_acc=ref[2], spec_tgt=ref[3], spec_occ=ref[4])
+    # prepare_pixel_samples
+    np.random.seed(77); torch.manual_seed(6)
+    with RandTap() as tap:
+        ref = rend.prepare_pixel_samples(img, mask, pose, wlh, K, roi, 40, im_sz=8)
+    np.random.seed(77)
+    ids = np.random.permutation(64)[:40]
+    ora = O.nerf_renderer_prepare_pixel_samples(img, mask, pose, wlh, K, roi, 40, n_samples=32, im_sz=8, ray_ids=ids, jitter=tap.draws[0])
+    for a, b, n in zip(ora, ref, ("xyz", "viewdir", "z", "tgt", "occ")):
+        assert_same("B pixel samples " + n, a, b)
+    out.update(pps_ids=ids, pps_jitter=tap.draws[0], pps_xyz=ref[0], pps_viewdir=ref[1], pps_z=ref[2], pps_tgt=ref[3], pps_occ=ref[4])
+    # render_full_img over a small roi
+    cx, cy = int((roi[0] + roi[2]) // 2), int((roi[1] + roi[3]) // 2)
+    small = torch.tensor([cx - 6, cy - 4, cx + 6, cy + 5], dtype=torch.int32)
+    torch.manual_seed(7)
+    with torch.no_grad(), RandTap() as tap:
+        ref = rend.render_full_img(model, "cpu", pose, wlh, K, small, sc, tc, out_depth=True)
+    with torch.no_grad():
+        ora = O.nerf_renderer_render_full_img(params, pose, wlh, K, small, sc, tc, n_samples=32, out_depth=True, jitter=tap.draws[0])
+    assert_same("B full img", ora[0], ref[0]); assert_same("B full depth", ora[1], ref[1])
+    out.update(full_roi=small, full_jitter=tap.draws[0], full_img=ref[0], full_depth=ref[1])
+    # turntables (2 views, 12 px): class B and function A
+    torch.manual_seed(8)
+    with torch.no_grad(), RandTap() as tap:
+        ref = rend.render_virtual_imgs(model, "cpu", wlh, K, sc, tc, radius=12., pan_num=2, img_sz=12)
+    with torch.no_grad():
+        ora = O.nerf_renderer_render_virtual_imgs(params, wlh, K, sc, tc, n_samples=32, radius=12., pan_num=2, img_sz=12, jitters=tap.draws)
+    for i in range(2):
+        assert_same("B virtual %d" % i, ora[i], ref[i])
+    out.update(virt_b_jitter=torch.stack(tap.draws), virt_b=torch.stack(ref))
+    # (utils.render_virtual_imgs itself cannot run here: it calls the removed alias np.int, src/utils.py:628 -- an ordinary error of
+    #  the reference under numpy 2; its views are render_full_img at the same turntable poses, both of which are pinned above)
+    # utilities
+    ro, vd = RU.get_rays(K, pose, small)
+    torch.manual_seed(10)
+    with RandTap() as tap:
+        xyz, vdd, z = RU.sample_from_rays(ro, vd, 7.5, 12.25, 9)
+    xf, _, zf = RU.sample_from_rays(ro, vd, 7.5, 12.25, 9, z_fixed=True)
+    assert_same("sample_from_rays z", O.shared_depth_samples(7.5, 12.25, 9, tap.draws[0]), z)
+    sig, col = torch.rand(5, 9, 1, generator=g) * 2, torch.rand(5, 9, 3, generator=g)     # (negative densities overflow there: no relu, last delta 1e10)
+    leg = RU.volume_rendering(sig, col, z)
+    for a, b in zip(O.volume_rendering_legacy(sig, col, z), leg):
+        assert_same("legacy composite", a, b)
+    c2w = torch.cat([torch.eye(3), torch.tensor([[0.1], [0.2], [1.3]])], 1)
+    so, sd = RU.get_rays_srn(6, 5, 40.0, c2w)
+    oo, od = O.srn_rays(6, 5, 40.0, c2w)
+    assert_same("srn o", oo, so); assert_same("srn d", od, sd)
+    o_np, d_np = (ro.numpy() / 2.6), vd.numpy()
+    bmax = np.asarray([0.9, 0.4, 0.33]).reshape(1, 3).repeat(ro.shape[0], axis=0)
+    z_in, z_out, hit = RU.ray_box_intersection(o_np, d_np, aabb_min=-bmax, aabb_max=bmax)
+    out.update(util_rays_o=ro, util_rays_d=vd, util_jitter=tap.draws[0], util_xyz=xyz, util_viewdir=vdd, util_z=z, util_z_fixed=zf, util_xyz_fixed=xf,
+               legacy_sig=sig, legacy_rgb=col, legacy_out_rgb=leg[0], legacy_out_depth=leg[1], srn_c2w=c2w, srn_o=so, srn_d=sd,
+               box_o=o_np, box_d=d_np, box_max=bmax, box_z_in=z_in, box_z_out=z_out, box_hit=hit)
+    # the class's small methods
+    torch.manual_seed(11)
+    rays8 = torch.cat([ro / 2.6, vd, torch.full((ro.shape[0], 1), 3.0), torch.full((ro.shape[0], 1), 5.5)], -1)
+    with RandTap() as tap:
+        zc = rend.sample_from_ray(rays8)
+    assert_same("sample_from_ray", O.unit_interval_samples(rays8[:, 6:7], rays8[:, 7:8], 32, tap.draws[0]), zc)
+    torch.manual_seed(12)
+    with RandTap() as tap2:
+        pxyz, pvd, pz, phit = rend.prepare_sampled_rays(ro, vd, wlh)
+    oa = O.aabb_sampled_rays(ro, vd, wlh, 32, tap2.draws[0])
+    for a, b, n in zip(oa[:3], (pxyz, pvd, pz), ("xyz", "viewdir", "z")):
+        assert_same("prepare_sampled_rays " + n, a, b)
+    sgm, colr = torch.rand(ro.shape[0], 32, generator=g) * 2, torch.rand(ro.shape[0], 32, 3, generator=g)
+    vr = rend.volume_render(sgm, colr, pz)
+    zb = torch.sort(torch.rand(2, 6, 32, generator=g) * 3 + 4, dim=-1)[0]
+    sgb, colb = torch.rand(2, 6, 32, 1, generator=g), torch.rand(2, 6, 32, 3, generator=g)
+    # (black background: the white-background branch of this method sums the weights over the RAY axis, src/renderer.py:85-87,
+    #  and only broadcasts when n_rays == n_samples; no caller uses it)
+    vb = RR.NeRFRenderer(n_samples=32, white_bkgd=False).volume_render_batch(sgb, colb, zb)
+    vb = (vb[0], vb[1].squeeze(-1), vb[2])
+    for a, b in zip(O.composite(sgb, colb, zb, white_bkgd=False), vb):
+        assert_same("volume_render_batch", a, b)
+    for a, b in zip(O.composite(sgm, colr, pz, white_bkgd=True), vr):
+        assert_same("volume_render", a, b)
+    out.update(sfr_rays=rays8, sfr_jitter=tap.draws[0], sfr_z=zc, psr_jitter=tap2.draws[0], psr_xyz=pxyz, psr_viewdir=pvd, psr_z=pz, psr_hit=phit,
+               vr_sig=sgm, vr_rgb=colr, vr_out_rgb=vr[0], vr_out_depth=vr[1], vr_out_acc=vr[2],
+               vrb_sig=sgb, vrb_rgb=colb, vrb_z=zb, vrb_out_rgb=vb[0], vrb_out_depth=vb[1], vrb_out_acc=vb[2])
+    save("twins", img=img, mask_occ=mask, cam_pose=pose, wlh=wlh, K=K, roi=roi, shapecode=sc, texturecode=tc, **out)
+
+
 def main():
     torch.set_num_threads(8)
     codenerf, RU, RR = import_reference()
@@ -242,6 +345,9 @@ def main():
     model, params = make_model(codenerf)
     if "--scene-only" in sys.argv:
         scene_fixture(RU, RR, model, params)
+        return
+    if "--twins-only" in sys.argv:
+        twins_fixture(RU, RR, model, params)
         return
     digest = weights_digest(params)
     print("weights digest", digest)
@@ -554,6 +660,7 @@ def main():
     save("train_step", xyz=xyz, viewdir=vd, z_vals=z, shapecode=sc, texturecode=tc, tgt=tgt, loss=loss,
          rgb=out[0], depth=out[1], acc=out[2], d_shapecode=sc.grad, d_texturecode=tc.grad, **small, **sums, **rows)
     scene_fixture(RU, RR, model, params)
+    twins_fixture(RU, RR, model, params)
     print("all reference-vs-oracle checks passed; fixtures written to", HERE)
 
 

@@ -329,6 +329,57 @@ def test_training_step_weight_gradients(amd, dev, oracle_params, golden):
             assert close_grad(p.grad[0], g["dWrow0_" + key]), name
 
 
+def test_renderer_twins(amd, dev, model, oracle_params, golden, jitter):
+    """NeRFRenderer's other methods (src/renderer.py:27-115,169-352) and the small utilities of src/utils.py on the GPU against the
+    reference's outputs (fixture `twins`)."""
+    g = golden("twins")
+    img, mask, pose, K, roi, sc, tc = [g[k] for k in ("img", "mask_occ", "cam_pose", "K", "roi", "shapecode", "texturecode")]
+    wlh = g["wlh"].numpy()
+    rend = amd.NeRFRenderer(n_samples=32, white_bkgd=True)
+    sc_d, tc_d = sc.to(dev), tc.to(dev)
+    with torch.no_grad():
+        jitter(g["spec_jitter"])
+        out = rend.render_rays_specified(model, dev, img, mask, pose, wlh, K, roi, g["spec_x"].numpy(), g["spec_y"].numpy(), sc_d, tc_d)
+        check_render(out, g, ("spec_rgb", "spec_depth", "spec_acc", "spec_tgt", "spec_occ"))
+        assert md(out[3], g["spec_tgt"]) == 0 and md(out[4], g["spec_occ"]) == 0
+        jitter(g["full_jitter"])
+        full = rend.render_full_img(model, dev, pose, wlh, K, g["full_roi"], sc_d, tc_d, out_depth=True)
+        assert md(full[0], g["full_img"]) < TOL_RGB and md(full[1], g["full_depth"]) < TOL_DEPTH_MAX
+        jitter(list(g["virt_b_jitter"]))
+        views = rend.render_virtual_imgs(model, dev, wlh, K, sc_d, tc_d, radius=12., pan_num=2, img_sz=12)
+        assert md(torch.stack(views), g["virt_b"]) < TOL_RGB
+        # family-A turntable: the same two poses through utils.render_full_img (pinned by the render_full_img fixture) == render_virtual_imgs
+        jitter(list(g["virt_b_jitter"][:, 0, :]))
+        va = amd.utils.render_virtual_imgs(model, dev, wlh, K, 32, sc_d, tc_d, True, radius=12., pan_num=2, img_sz=12)
+        want = O.render_virtual_imgs(oracle_params, wlh, K, 32, sc, tc, True, radius=12., pan_num=2, img_sz=12,
+                                     jitters=list(g["virt_b_jitter"][:, 0, :]))
+        assert md(torch.stack(va), torch.stack(want)) < TOL_RGB
+    # GPU twin of prepare_pixel_samples (encode kernel)
+    np.random.seed(77)
+    jitter(g["pps_jitter"])
+    out = rend.prepare_pixel_samples(img.to(dev), mask.to(dev), pose.to(dev), wlh, K, roi, 40, im_sz=8)
+    for a, k in zip(out, ("pps_xyz", "pps_viewdir", "pps_z", "pps_tgt", "pps_occ")):
+        assert md(a, g[k]) < 5e-6, k
+    # the class's small methods and the function-form utilities
+    jitter(g["sfr_jitter"])
+    assert md(rend.sample_from_ray(g["sfr_rays"].to(dev)), g["sfr_z"]) < 1e-6
+    jitter(g["psr_jitter"])
+    pxyz, pvd, pz, phit = rend.prepare_sampled_rays(g["util_rays_o"].to(dev), g["util_rays_d"].to(dev), wlh)
+    # metric z ~20 m: 5e-6 is 2 ulp
+    assert md(pxyz, g["psr_xyz"]) < 2e-6 and md(pz, g["psr_z"]) < 5e-6 and torch.equal(phit.cpu(), g["psr_hit"].bool())
+    vr = rend.volume_render(g["vr_sig"].to(dev), g["vr_rgb"].to(dev), g["psr_z"].to(dev))
+    assert md(vr[0], g["vr_out_rgb"]) < TOL_RGB and md(vr[1], g["vr_out_depth"]) < TOL_DEPTH_MAX and md(vr[2], g["vr_out_acc"]) < TOL_ACC
+    vb = amd.NeRFRenderer(n_samples=32, white_bkgd=False).volume_render_batch(g["vrb_sig"].to(dev), g["vrb_rgb"].to(dev), g["vrb_z"].to(dev))
+    assert md(vb[0], g["vrb_out_rgb"]) < TOL_RGB and md(vb[1], g["vrb_out_depth"]) < TOL_DEPTH_MAX and md(vb[2], g["vrb_out_acc"]) < TOL_ACC
+    jitter(g["util_jitter"])
+    xyz, vdd, z = amd.utils.sample_from_rays(g["util_rays_o"].to(dev), g["util_rays_d"].to(dev), 7.5, 12.25, 9)
+    assert md(xyz, g["util_xyz"]) < 2e-6 and md(vdd, g["util_viewdir"]) == 0 and md(z, g["util_z"]) < 1e-6
+    xf, _, zf = amd.utils.sample_from_rays(g["util_rays_o"].to(dev), g["util_rays_d"].to(dev), 7.5, 12.25, 9, z_fixed=True)
+    assert md(xf, g["util_xyz_fixed"]) < 2e-6 and md(zf, g["util_z_fixed"]) < 1e-6
+    leg = amd.utils.volume_rendering(g["legacy_sig"].to(dev), g["legacy_rgb"].to(dev), g["util_z"].to(dev))
+    assert md(leg[0], g["legacy_out_rgb"]) < TOL_RGB and md(leg[1], g["legacy_out_depth"]) < TOL_DEPTH_MAX
+
+
 def test_vis_scene(amd, dev, model, golden):
     """Multi-object scene (scripts/demo.py:425-579) against the picture the reference's building blocks produce."""
     g = golden("scene")

@@ -297,6 +297,25 @@ def test_scene_ray_table_matches_oracle(amd, golden):
         amd.scene.vis_scene(None, "cpu", g["obj_poses"], g["obj_wlh"][:2], g["shapecodes"], g["texturecodes"], g["K"], H, W, 8)
 
 
+def test_small_utilities_match_reference(amd, golden):
+    """get_rays_srn (src/utils.py:94-104), the numpy slab test ray_box_intersection (:236-280): host functions, reference outputs."""
+    g = golden("twins")
+    so, sd = amd.utils.get_rays_srn(6, 5, 40.0, g["srn_c2w"])
+    assert torch.equal(so, g["srn_o"]) and torch.equal(sd, g["srn_d"])
+    z_in, z_out, hit = amd.utils.ray_box_intersection(g["box_o"].numpy(), g["box_d"].numpy(), aabb_min=-g["box_max"].numpy(), aabb_max=g["box_max"].numpy())
+    assert np.array_equal(hit, g["box_hit"].numpy().astype(bool)) and np.array_equal(z_in, g["box_z_in"].numpy()) and np.array_equal(z_out, g["box_z_out"].numpy())
+    # CPU twin of NeRFRenderer.prepare_pixel_samples (the datasets call it in CPU workers): plain torch, same random streams
+    rend = amd.NeRFRenderer(n_samples=32, white_bkgd=True)
+    np.random.seed(77)
+    amd.utils.JITTER_OVERRIDE = g["pps_jitter"]
+    try:
+        out = rend.prepare_pixel_samples(g["img"], g["mask_occ"], g["cam_pose"], g["wlh"].numpy(), g["K"], g["roi"], 40, im_sz=8)
+    finally:
+        amd.utils.JITTER_OVERRIDE = None
+    for a, k in zip(out, ("pps_xyz", "pps_viewdir", "pps_z", "pps_tgt", "pps_occ")):
+        assert float((a - g[k]).abs().max()) < 1e-6, k
+
+
 def test_reference_file_formats_round_trip(amd, tmp_path):
     """models.pth / codes+poses.pth with the reference's keys (src/trainer_unified_nuscenes.py:476-490, src/optimizer_nuscenes.py:1463-1476)."""
     m = amd.SUPNeRF(shape_blocks=3, texture_blocks=1)

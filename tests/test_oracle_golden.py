@@ -229,3 +229,37 @@ def test_scene_compositing(golden, oracle_params):
     ref2 = O.composite(torch.gather(g["b0_sigmas"], 1, order), torch.gather(g["b0_rgbs"], 1, order[:, :, None].repeat(1, 1, 3)),
                        torch.gather(z, 1, order), white_bkgd=True)
     same(ref2[0], g["b0_rgb"], 1e-6)
+
+
+def test_render_api_twins(golden, oracle_params):
+    """The rest of the render API (src/renderer.py:169-352, src/utils.py:94-104,154-199,236-280) against the reference's outputs."""
+    g = golden("twins")
+    img, mask, pose, wlh, K, roi, sc, tc = [g[k] for k in ("img", "mask_occ", "cam_pose", "wlh", "K", "roi", "shapecode", "texturecode")]
+    wlh = wlh.numpy()
+    with torch.no_grad():
+        out = O.nerf_renderer_render_rays_specified(oracle_params, img, mask, pose, wlh, K, roi, g["spec_x"].numpy(), g["spec_y"].numpy(), sc, tc,
+                                                    n_samples=32, jitter=g["spec_jitter"])
+        for a, k in zip(out, ("spec_rgb", "spec_depth", "spec_acc", "spec_tgt", "spec_occ")):
+            same(a, g[k])
+        out = O.nerf_renderer_prepare_pixel_samples(img, mask, pose, wlh, K, roi, 40, n_samples=32, im_sz=8, ray_ids=g["pps_ids"].numpy(), jitter=g["pps_jitter"])
+        for a, k in zip(out, ("pps_xyz", "pps_viewdir", "pps_z", "pps_tgt", "pps_occ")):
+            same(a, g[k])
+        full = O.nerf_renderer_render_full_img(oracle_params, pose, wlh, K, g["full_roi"], sc, tc, n_samples=32, out_depth=True, jitter=g["full_jitter"])
+        same(full[0], g["full_img"]); same(full[1], g["full_depth"])
+        views = O.nerf_renderer_render_virtual_imgs(oracle_params, wlh, K, sc, tc, n_samples=32, radius=12., pan_num=2, img_sz=12, jitters=list(g["virt_b_jitter"]))
+        same(torch.stack(views), g["virt_b"])
+    same(O.shared_depth_samples(7.5, 12.25, 9, g["util_jitter"]), g["util_z"])
+    same(torch.linspace(7.5, 12.25, 9), g["util_z_fixed"])                   # z_fixed: plain linspace(near, far)
+    leg = O.volume_rendering_legacy(g["legacy_sig"], g["legacy_rgb"], g["util_z"])
+    same(leg[0], g["legacy_out_rgb"]); same(leg[1], g["legacy_out_depth"])
+    so, sd = O.srn_rays(6, 5, 40.0, g["srn_c2w"])
+    same(so, g["srn_o"]); same(sd, g["srn_d"])
+    tn, tf, hit = O.slab_intersect(g["box_o"], g["box_d"], -g["box_max"], g["box_max"])
+    assert torch.equal(hit, g["box_hit"].bool()) and torch.equal(tn[hit], g["box_z_in"]) and torch.equal(tf[hit], g["box_z_out"])
+    same(O.unit_interval_samples(g["sfr_rays"][:, 6:7], g["sfr_rays"][:, 7:8], 32, g["sfr_jitter"]), g["sfr_z"])
+    psr = O.aabb_sampled_rays(g["util_rays_o"], g["util_rays_d"], wlh, 32, g["psr_jitter"])
+    same(psr[0], g["psr_xyz"]); same(psr[2], g["psr_z"]); assert torch.equal(psr[3], g["psr_hit"].bool())
+    vr = O.composite(g["vr_sig"], g["vr_rgb"], g["psr_z"], white_bkgd=True)
+    same(vr[0], g["vr_out_rgb"]); same(vr[1], g["vr_out_depth"]); same(vr[2], g["vr_out_acc"])
+    vb = O.composite(g["vrb_sig"], g["vrb_rgb"], g["vrb_z"], white_bkgd=False)
+    same(vb[0], g["vrb_out_rgb"]); same(vb[1], g["vrb_out_depth"]); same(vb[2], g["vrb_out_acc"])
