@@ -54,6 +54,10 @@ struct Ring {
     int view0;            // first of the 8 backward enc_viewdir^T chunks (36 KiB each); negative = none
     int use, fill;        // ring buffer holding chunk ci / receiving the next fetched chunk
     unsigned wave_lds;    // wave id * 1024 (SGPR): this wave's 1 KiB slice inside every 4 KiB DMA row
+    // spread issue (forward): the chunk whose 8 pieces are issued one or two at a time under the MFMAs of the current chunk
+    const char* pg;       // its global address + this wave's 8 KiB slice
+    unsigned pm0;         // M0 for its pieces: LDS address of the slice + 4096 (the pieces use immediate offsets -4096 .. +3072)
+    const char* last;     // address of the stream's last chunk (fetches past the end re-read it into a vacated buffer)
 };
 __device__ __forceinline__ int ring_bytes(const Ring& r, int i) { return (i >= r.view0 && i < r.view0 + 8) ? BF_CHUNK_VIEW : BF_CHUNK; }
 
@@ -124,6 +128,49 @@ __device__ __forceinline__ const char* ring_acquire(Ring& r, char* lds, int tid)
     return p;
 }
 
+// ---- spread issue.  A burst of 8 DMA instructions per wave keeps the wave (and, the four waves sharing the CU's address path,
+// the whole workgroup) out of the matrix pipe for ~500 cycles per chunk; one bare instruction between MFMAs costs ~20
+// (tools/_diag/mfma_order.hip).  Bare = no M0 save/restore and no address arithmetic between pieces: wave w copies the contiguous
+// 8 KiB slice w of the chunk, M0 points into the middle of its LDS image and the instruction's immediate offset, which moves the
+// global and the LDS address together, selects the KiB.  Nothing else in these kernels uses M0 (checked in the disassembly).
+template <int K>
+__device__ __forceinline__ void ring_piece(const Ring& r, unsigned voff) {
+#ifndef SNR_EXP_NODMA
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 :: "v"(voff), "s"(r.pg), "s"(r.pm0), "n"(1024 * K - 4096) : "memory");
+#endif
+}
+template <int K0, int N>
+__device__ __forceinline__ void ring_pieces(const Ring& r, unsigned voff) {
+    if constexpr (N > 0) { ring_piece<K0>(r, voff); ring_pieces<K0 + 1, N - 1>(r, voff); }
+}
+__device__ __forceinline__ void ring_start_spread(Ring& r, const char* stream, int total, char* lds, unsigned voff) {
+    r.ci = 0; r.total = total; r.view0 = -100; r.use = 0; r.fill = 2 % NBUF;
+    r.wave_lds = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 8192u);
+    r.last = stream + (size_t)(total - 1) * BF_CHUNK;
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds) + r.wave_lds + 4096u;
+    r.pg = stream + r.wave_lds;                r.pm0 = base;             ring_pieces<0, 8>(r, voff);
+    r.pg = stream + BF_CHUNK + r.wave_lds;     r.pm0 = base + WB_BYTES;  ring_pieces<0, 8>(r, voff);
+    r.next = stream + 2 * BF_CHUNK;
+}
+// Wait for chunk ci (the 8 youngest DMA instructions are chunk ci+1's), rendezvous, and make chunk ci+2 the pending one; the caller
+// issues its 8 pieces before the next acquire.  No branches: past the end of the stream the pending chunk is the last chunk again.
+__device__ __forceinline__ const char* ring_acquire_spread(Ring& r, char* lds) {
+#ifndef SNR_EXP_NOSYNC
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#endif
+    const char* nx = r.next < r.last ? r.next : r.last;
+    r.pg = nx + r.wave_lds;
+    r.pm0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds) + r.fill * WB_BYTES + r.wave_lds + 4096u;
+    r.next = nx + BF_CHUNK;
+    r.fill = (r.fill == NBUF - 1) ? 0 : r.fill + 1;
+    const char* p = lds + r.use * WB_BYTES;
+    r.use = (r.use == NBUF - 1) ? 0 : r.use + 1;
+    r.ci += 1;
+    return p;
+}
+
 // ------------------------------------------------------------------------------------------ matrix core
 // Layer image in the stream: [k16-step s][output tile t][plane hi/lo][lane][8 bf16]; a chunk = a few whole steps.
 // One step: acc[t] += W_t[:, 16s..16s+15] * x   for t < NT, three split products each.
@@ -187,8 +234,8 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[NA]) {
 // What happens to a finished accumulator tile of the PREVIOUS layer on its way to becoming operand step s of the
 // current layer (s = 2*tile + half: registers 8*half .. 8*half+7 of the tile).
 struct FwdEpi {
-    float floor;          // 0 for a ReLU layer, -inf for none:  v = max(v, floor)
-    const float* bias;    // LDS: bias of the layer that produced the accumulators
+    int floor;            // ReLU as an integer max on the bit pattern: 0 for a ReLU layer, INT_MIN for none
+    const float* bias;    // LDS: bias of the layer being accumulated (its accumulators start from it)
     const float* zl;      // LDS: latent term added after the activation (a block of zeros if none)
 };
 // pin an operand step where it is produced: without this LLVM sinks the whole epilogue down to its use in the next
@@ -200,12 +247,24 @@ __device__ __forceinline__ void pin(XOp& o) { asm volatile("" : "+v"(o.hi), "+v"
 // with one wave per SIMD the layer chain is bounded by instruction ISSUE (about six 4-cycle slots per 32-cycle MFMA).
 // bias and latent vectors of one quarter: fetched from LDS at the top of a step, consumed half a step or more later, so no
 // lgkmcnt wait sits between the MFMAs (an exposed LDS round trip there stalls the in-order wave AND the matrix pipe)
-struct EpiVec { f32x4 b, z; };
+struct EpiVec { f32x4 z; };
 template <int T, int HALF, int JJ>
 __device__ __forceinline__ void fwd_quarter_load(EpiVec& v, const FwdEpi& c, int h) {
     const int j = 2 * HALF + JJ;
-    v.b = *reinterpret_cast<const f32x4*>(c.bias + 32 * T + 8 * j + 4 * h);
     v.z = *reinterpret_cast<const f32x4*>(c.zl + 32 * T + 8 * j + 4 * h);
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// two values at a time: the latent add and the hi/lo split run on the packed-fp32 VALU ops (v_pk_add_f32), one issue slot per pair
+// (LLVM scalarises <2 x float> adds whose elements come from separate registers, hence the asm)
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ void split_store2(f32x2 y, XOp& o, int jp) {
+    const bf16x2 hp = __builtin_convertvector(y, bf16x2);
+    const f32x2 lo = pk_sub(y, __builtin_convertvector(hp, f32x2));
+    const bf16x2 lp = __builtin_convertvector(lo, bf16x2);
+    o.hi[2 * jp] = hp[0]; o.hi[2 * jp + 1] = hp[1];
+    o.lo[2 * jp] = lp[0]; o.lo[2 * jp + 1] = lp[1];
 }
 template <int T, int HALF, int JJ, bool MASKS>
 __device__ __forceinline__ void fwd_quarter(const f32x16& acc, XOp& out, const FwdEpi& c, const EpiVec& v, uint32_t (&mask)[4]) {
@@ -214,14 +273,21 @@ __device__ __forceinline__ void fwd_quarter(const f32x16& acc, XOp& out, const F
 #endif
     const int j = 2 * HALF + JJ;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int r = 4 * j + e;
-        const float a = acc[r] + v.b[e];
+    for (int e2 = 0; e2 < 2; ++e2) {
+        const int r = 4 * j + 2 * e2;
+        const float a0 = acc[r], a1 = acc[r + 1];      // bias already inside (acc_bias).  Scalars on purpose: __builtin_bit_cast of
+                                                       // an ext-vector ELEMENT reads element 0 whatever the index (clang 19, ROCm 7.2)
         // ReLU bits (only stored for ReLU layers), one VALU op per value and no VCC: v_alignbit shifts the word left and
         // takes in the sign bit of a; the 32 values of a word arrive in register order (tile 2w r0..15, tile 2w+1 r0..15), so
         // store_mask recovers bit (T&1)*16 + r = "a > 0" as ~bitreverse(word).  (a == +0.0 counts as positive.)
-        if (MASKS) mask[T >> 1] = __builtin_amdgcn_alignbit(mask[T >> 1], __builtin_bit_cast(uint32_t, a), 31);
-        split_store(__builtin_amdgcn_fmed3f(a, c.floor, __builtin_inff()) + v.z[e], out, r & 7);   // max(a, floor) in one op
+        if (MASKS) {
+            mask[T >> 1] = __builtin_amdgcn_alignbit(mask[T >> 1], __builtin_bit_cast(uint32_t, a0), 31);
+            mask[T >> 1] = __builtin_amdgcn_alignbit(mask[T >> 1], __builtin_bit_cast(uint32_t, a1), 31);
+        }
+        f32x2 m = {__builtin_bit_cast(float, max(__builtin_bit_cast(int, a0), c.floor)),
+                   __builtin_bit_cast(float, max(__builtin_bit_cast(int, a1), c.floor))};         // v_max_i32: no canonicalisation, -0 -> 0
+        m = pk_add(m, f32x2{v.z[2 * e2], v.z[2 * e2 + 1]});
+        split_store2(m, out, (r & 7) >> 1);
     }
     if (JJ == 1) pin(out);
     if (MASKS) asm volatile("" : "+v"(mask[T >> 1]));      // keep the bit capture here (LLVM otherwise recomputes it at the layer's end)
@@ -235,23 +301,46 @@ __device__ __forceinline__ void fwd_half_tile(const f32x16& acc, XOp& out, const
     fwd_quarter<T, HALF, 1, MASKS>(acc, out, c, v1, mask);
 }
 
-// density head on finished enc_shape accumulators (+ its bias): this lane's share of w_sigma . y
-__device__ __forceinline__ float sigma_partial(const f32x16 (&acc)[8], const float* __restrict__ bias, const float* __restrict__ wsig, int h) {
+// density head on finished enc_shape accumulators (bias included): this lane's share of w_sigma . y
+__device__ __forceinline__ float sigma_partial(const f32x16 (&acc)[8], const float* __restrict__ wsig, int h) {
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 wv = *reinterpret_cast<const f32x4*>(wsig + 32 * t + 8 * j + 4 * h);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * t + 8 * j + 4 * h);
-            d0 = fmaf(wv[0], acc[t][4 * j + 0] + bv[0], d0); d1 = fmaf(wv[1], acc[t][4 * j + 1] + bv[1], d1);
-            d2 = fmaf(wv[2], acc[t][4 * j + 2] + bv[2], d2); d3 = fmaf(wv[3], acc[t][4 * j + 3] + bv[3], d3);
+            d0 = fmaf(wv[0], acc[t][4 * j + 0], d0); d1 = fmaf(wv[1], acc[t][4 * j + 1], d1);
+            d2 = fmaf(wv[2], acc[t][4 * j + 2], d2); d3 = fmaf(wv[3], acc[t][4 * j + 3], d3);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
     return (d0 + d1) + (d2 + d3);
 }
 
+// interleave request for one half-step region: after every MFMA one LDS read (while there are any) and a few VALU ops, so the
+// fragment fetches for the next half-step and the previous layer's epilogue are spread under the MFMAs instead of in blocks.
+// Measured (tools/ab_time.py, interleaved rounds): forward, ~20 epilogue ops per 12 MFMAs: read + 2 VALU per MFMA is best (-2 % against
+// 4 VALU and no read request); backward, ~34 ops per 12 MFMAs: 4 VALU and no read request.
+#ifndef SNR_IL_DS
+#define SNR_IL_DS 1
+#endif
+#ifndef SNR_IL_VALU
+#define SNR_IL_VALU 2
+#endif
+#ifndef SNR_ILB_DS
+#define SNR_ILB_DS 0
+#endif
+#ifndef SNR_ILB_VALU
+#define SNR_ILB_VALU 4
+#endif
+#define SNR_INTERLEAVE_(N_MFMA, DS, VALU)                                                \
+    _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA); ++g_) {                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
+        if (DS) __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);                      \
+        if (VALU) __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);                  \
+    }
+#define SNR_INTERLEAVE(N_MFMA) SNR_INTERLEAVE_(N_MFMA, SNR_IL_DS, SNR_IL_VALU)
+#define SNR_INTERLEAVE_B(N_MFMA) SNR_INTERLEAVE_(N_MFMA, SNR_ILB_DS, SNR_ILB_VALU)
 // One layer with 16 operand steps taken from accP (+ 2 direction steps for enc_viewdir), NT output tiles into accC.
 // Each step is two half-steps of NT/2 tiles.  The A fragments of a half-step are fetched from LDS while the previous
 // half-step's MFMAs run (two fragment buffers), the next chunk is acquired half a step before it is needed, and the
@@ -260,30 +349,19 @@ template <int NT, bool MASKS>
 __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], XOp (&x)[16], const char* xdir_lds, Ring& ring, char* lds,
                                           const FwdEpi& c, bool extra, uint32_t (&mask)[4], int tid, int lane) {
     const int h = lane >> 5;
+    const unsigned voff = lane * 16u + 4096u;         // DMA source offset of this lane inside the wave's slice (+ 4096, see ring_piece)
     constexpr int NTH = NT / 2;
     constexpr int SPC = (NT == 8) ? 2 : 4;            // steps per 32 KiB chunk
+    constexpr int PPH = 8 / (2 * SPC);                // DMA pieces per half-step: a chunk's 8 pieces over the 2*SPC half-steps up to the next acquire
     constexpr int STEP_BYTES = NT * 2 * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) mask[i] = 0u;
-    acc_zero<NT, 8>(accC);
+    acc_bias<NT, 8>(accC, c.bias, h);
     fwd_half_tile<0, 0, MASKS>(accP[0], x[0], c, h, mask);
     Frags<NTH> fa, fb;
-    const char* w = ring_acquire(ring, lds, tid) + lane * 16;
+    const char* w = ring_acquire_spread(ring, lds) + lane * 16;
     load_frags<NTH, 0>(fa, w);
-// interleave request for one half-step region: after every MFMA one LDS read (while there are any) and two VALU ops, so the
-// fragment fetches for the next half-step and the previous layer's epilogue are spread under the MFMAs instead of in blocks
-#ifndef SNR_IL_DS
-#define SNR_IL_DS 0     /* measured: asking for an LDS read per group costs 2-4 %; the VALU request alone is best */
-#endif
-#ifndef SNR_IL_VALU
-#define SNR_IL_VALU 4
-#endif
-#define SNR_INTERLEAVE(N_MFMA)                                                           \
-    _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA); ++g_) {                            \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
-        if (SNR_IL_DS) __builtin_amdgcn_sched_group_barrier(0x100, SNR_IL_DS, 0);        \
-        if (SNR_IL_VALU) __builtin_amdgcn_sched_group_barrier(0x002, SNR_IL_VALU, 0);    \
-    }
+    ring_pieces<0, PPH>(ring, voff);
 #define SNR_FSTEP(S)                                                                                                   \
     {                                                                                                                  \
         const char* ws = w + ((S) % SPC) * STEP_BYTES;                                                                 \
@@ -294,12 +372,14 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
             fwd_quarter_load<(((S) + 1) >> 1), (((S) + 1) & 1), 1>(v1, c, h);                                          \
         }                                                                                                              \
         mma_half<NTH, 0, 8>(accC, x[S], fa);                                                                           \
+        ring_pieces<PPH * ((2 * (S) + 1) % (2 * SPC)), PPH>(ring, voff);                                               \
         if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0, MASKS>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v0, mask); \
         SNR_INTERLEAVE(3 * NTH)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + STEP_BYTES);                                   \
-        else if constexpr ((S) + 1 < 16) { w = ring_acquire(ring, lds, tid) + lane * 16; load_frags<NTH, 0>(fa, w); }  \
+        else if constexpr ((S) + 1 < 16) { w = ring_acquire_spread(ring, lds) + lane * 16; load_frags<NTH, 0>(fa, w); } \
         mma_half<NTH, NTH, 8>(accC, x[S], fb);                                                                         \
+        if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0) ring_pieces<PPH * ((2 * (S) + 2) % (2 * SPC)), PPH>(ring, voff); \
         if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1, MASKS>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v1, mask); \
         SNR_INTERLEAVE(3 * NTH)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
@@ -308,7 +388,8 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
     SNR_FSTEP(8) SNR_FSTEP(9) SNR_FSTEP(10) SNR_FSTEP(11) SNR_FSTEP(12) SNR_FSTEP(13) SNR_FSTEP(14) SNR_FSTEP(15)
 #undef SNR_FSTEP
     if (extra) {      // enc_viewdir: k = 256..287 are the direction features
-        w = ring_acquire(ring, lds, tid) + lane * 16;
+        w = ring_acquire_spread(ring, lds) + lane * 16;
+        ring_pieces<0, 8>(ring, voff);
         XOp d0, d1;
         d0.hi = *reinterpret_cast<const bf16x8*>(xdir_lds);        d0.lo = *reinterpret_cast<const bf16x8*>(xdir_lds + 1024);
         d1.hi = *reinterpret_cast<const bf16x8*>(xdir_lds + 2048); d1.lo = *reinterpret_cast<const bf16x8*>(xdir_lds + 3072);
@@ -316,6 +397,7 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
         step_mma<NT, 8>(accC, d1, w + STEP_BYTES);
     }
 }
+
 
 // ------------------------------------------------------------------------------------------ forward kernel
 #ifdef SNR_STAMPS
@@ -372,7 +454,8 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     // ---- weight ring: chunks 0,1 in flight while the positional encodings are computed (scratch = ring buffer 2)
     Ring ring;
     const int total_chunks = 2 + 8 * (sb + 1) + 9 + 8 * tb + 4;
-    ring_start(ring, reinterpret_cast<const char*>(io.packed + L.bf_fwd), total_chunks, -100, lds, tid);
+    const unsigned voff = lane * 16u + 4096u;
+    ring_start_spread(ring, reinterpret_cast<const char*>(io.packed + L.bf_fwd), total_chunks, lds, voff);
 
     XOp x[16];
     char* xdir = lds + OFF_XDIR + wave * 4096 + lane * 16;
@@ -418,13 +501,17 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     SNR_STAMP(2);
 
     // ---- enc_xyz: 4 operand steps straight from the encoding -> accA
-    acc_zero<8, 8>(accA);
     {
-        const char* w = ring_acquire(ring, lds, tid) + lane * 16;      // (its barrier also retires the scratch rows)
+        const char* w = ring_acquire_spread(ring, lds) + lane * 16;      // (its barrier also retires the scratch rows)
+        ring_pieces<0, 4>(ring, voff);
+        acc_bias<8, 8>(accA, vec + VEC_BIAS, h);
         step_mma<8, 8>(accA, x[0], w);
+        ring_pieces<4, 4>(ring, voff);
         step_mma<8, 8>(accA, x[1], w + 16 * 1024);
-        w = ring_acquire(ring, lds, tid) + lane * 16;
+        w = ring_acquire_spread(ring, lds) + lane * 16;
+        ring_pieces<0, 4>(ring, voff);
         step_mma<8, 8>(accA, x[2], w);
+        ring_pieces<4, 4>(ring, voff);
         step_mma<8, 8>(accA, x[3], w + 16 * 1024);
     }
 
@@ -432,8 +519,8 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     // ---- 256-wide layers: layer li consumes the accumulators of layer li-1 (epilogue fused into its steps)
     auto epi_of = [&](int l) {     // epilogue configuration of MFMA layer l's output
         FwdEpi c;
-        c.floor = (l != li_encshape) ? 0.f : -__builtin_inff();
-        c.bias = vec + VEC_BIAS + l * 256;
+        c.floor = (l != li_encshape) ? 0 : (int)0x80000000;
+        c.bias = vec + VEC_BIAS + (l + 1) * 256;
         const int la = latent_after(l, sb, tb);
         c.zl = la >= 0 ? latw + la * 256 : vec + VEC_ZERO;
         return c;
@@ -449,18 +536,18 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     for (; li + 1 <= li_last; li += 2) {
         layer_fwd<8, MASKS>(accA, accB, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
         store_mask(li - 1);
-        if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_BIAS + li * 256, vec + VEC_SIGW, h);
+        if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_SIGW, h);
         SNR_STAMP(3 + li);
         layer_fwd<8, MASKS>(accB, accA, x, xdir, ring, lds, epi_of(li), li + 1 == li_view, mask, tid, lane);
         store_mask(li);
-        if (li + 1 == li_encshape) sig_dot = sigma_partial(accA, vec + VEC_BIAS + (li + 1) * 256, vec + VEC_SIGW, h);
+        if (li + 1 == li_encshape) sig_dot = sigma_partial(accA, vec + VEC_SIGW, h);
         SNR_STAMP(4 + li);
     }
     const bool odd_tail = (li == li_last);
     if (odd_tail) {
         layer_fwd<8, MASKS>(accA, accB, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
         store_mask(li - 1);
-        if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_BIAS + li * 256, vec + VEC_SIGW, h);
+        if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_SIGW, h);
     }
     // ---- rgb.0: 256 -> 128 (4 tiles) from the last 256-wide layer's accumulators
     if (odd_tail) layer_fwd<4, MASKS>(accB, accA, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
@@ -485,10 +572,9 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
                 const f32x4 wr = *reinterpret_cast<const f32x4*>(w2 + n0);
                 const f32x4 wg = *reinterpret_cast<const f32x4*>(w2 + 128 + n0);
                 const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + n0);
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(vec + VEC_BIAS + (li_last + 1) * 256 + n0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = (odd_tail ? accA[t][4 * j + e] : accB[t][4 * j + e]) + bv[e];
+                    float v = odd_tail ? accA[t][4 * j + e] : accB[t][4 * j + e];
                     if (MASKS && v > 0.f) mk[t >> 1] |= 1u << ((t & 1) * 16 + 4 * j + e);
                     v = fmaxf(v, 0.f);
                     pr = fmaf(wr[e], v, pr); pg = fmaf(wg[e], v, pg); pb = fmaf(wb[e], v, pb);
@@ -532,6 +618,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two re-fetches past the stream's end must land before the LDS is handed on
     SNR_STAMP(14);
 }
 
@@ -624,7 +711,7 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
         }                                                                                                              \
         mma_half<NTH, 0, 8>(accC, x[S], fa);                                                                           \
         if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, w0, lane); \
-        SNR_INTERLEAVE(3 * NTH)                                                                                        \
+        SNR_INTERLEAVE_B(3 * NTH)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if (NT == 8 && ninth) {                                                                                        \
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + 16 * 1024);                                        \
@@ -637,7 +724,7 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
         else if constexpr ((S) + 1 < 16) { w = ring_acquire(ring, lds, tid) + lane * 16; load_frags<NTH, 0>(fa, w); }  \
         mma_half<NTH, NTH, 8>(accC, x[S], fb);                                                                         \
         if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, w1, lane); \
-        SNR_INTERLEAVE(3 * NTH)                                                                                        \
+        SNR_INTERLEAVE_B(3 * NTH)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
     SNR_BSTEP(0) SNR_BSTEP(1) SNR_BSTEP(2) SNR_BSTEP(3) SNR_BSTEP(4) SNR_BSTEP(5) SNR_BSTEP(6) SNR_BSTEP(7)

@@ -24,6 +24,10 @@ __global__ void __launch_bounds__(256, 1) k(unsigned long long* out, int iters, 
     bf16x8 dd[4];
     for (int t = 0; t < 4; ++t) dd[t] = xh;
     unsigned long long t0, t1;
+    if (KIND == 10 || KIND == 11 || KIND == 13 || KIND == 14 || KIND == 15) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + (threadIdx.x >> 6) * 1024u);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(dst) : "memory");
+    }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -51,6 +55,60 @@ __global__ void __launch_bounds__(256, 1) k(unsigned long long* out, int iters, 
                     unsigned keep;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                                  : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
+                }
+                if (i == 11 && (it & 3) == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else if (KIND == 8 || KIND == 9) {   // KIND 8: the same pieces, wave w issues one MFMA gap later than wave w-1; KIND 9: only wave 0 issues
+                const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                if (KIND == 8 ? (i % 6 == wv) : (i % 6 == 0 && wv == 0)) {
+                    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + (threadIdx.x >> 6) * 1024u + ((it * 2 + i / 6) & 7) * 4096u);
+                    const unsigned voff = threadIdx.x * 16u + ((it * 2 + i / 6) & 15) * 4096u;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
+                }
+                if (i == 11 && (it & 3) == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else if (KIND == 10) {      // bare instruction: M0 written once before the loop
+                if (i % 6 == 0) {
+                    const unsigned voff = threadIdx.x * 16u + ((it * 2 + i / 6) & 15) * 4096u;
+                    asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src) : "memory");
+                }
+                if (i == 11 && (it & 3) == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else if (KIND == 11) {      // M0 advanced by s_add like the kernel's ring_dma, no save/restore
+                if (i % 6 == 0) {
+                    const unsigned voff = threadIdx.x * 16u + ((it * 2 + i / 6) & 15) * 4096u;
+                    asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_xor_b32 m0, m0, 0x1000" :: "v"(voff), "s"(src) : "memory");
+                }
+                if (i == 11 && (it & 3) == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else if (KIND == 12) {      // compiler builtin (it manages M0)
+                if (i % 6 == 0) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) char*)(const char*)src + threadIdx.x * 16u + ((it * 2 + i / 6) & 15) * 4096u,
+                        (__attribute__((address_space(3))) char*)lds + (threadIdx.x >> 6) * 1024u + ((it * 2 + i / 6) & 7) * 4096u, 16, 0, 0);
+                }
+            } else if (KIND == 13) {      // dwordx1 pieces (256 B per wave-instruction), bare
+                if (i % 6 == 0) {
+                    const unsigned voff = threadIdx.x * 4u + ((it * 2 + i / 6) & 15) * 4096u;
+                    asm volatile("global_load_lds_dword %0, %1" :: "v"(voff), "s"(src) : "memory");
+                }
+                if (i == 11 && (it & 3) == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else if (KIND == 14) {      // bare, 64-bit VGPR address (no SGPR base), fixed M0
+                if (i % 6 == 0) {
+                    const char* ga = (const char*)src + threadIdx.x * 16u + ((it * 2 + i / 6) & 15) * 4096u;
+                    asm volatile("global_load_lds_dwordx4 %0, off" :: "v"(ga) : "memory");
+                }
+                if (i == 11 && (it & 3) == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else if (KIND == 15) {      // bare, SGPR base, immediate offsets -4096..3072 step 1024 over 4 iterations (M0 fixed at base + 4096)
+                if (i % 6 == 0) {
+                    const unsigned voff = threadIdx.x * 16u + 4096u;
+                    switch ((it * 2 + i / 6) & 7) {
+                    case 0: asm volatile("global_load_lds_dwordx4 %0, %1 offset:-4096" :: "v"(voff), "s"(src) : "memory"); break;
+                    case 1: asm volatile("global_load_lds_dwordx4 %0, %1 offset:-3072" :: "v"(voff), "s"(src) : "memory"); break;
+                    case 2: asm volatile("global_load_lds_dwordx4 %0, %1 offset:-2048" :: "v"(voff), "s"(src) : "memory"); break;
+                    case 3: asm volatile("global_load_lds_dwordx4 %0, %1 offset:-1024" :: "v"(voff), "s"(src) : "memory"); break;
+                    case 4: asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src) : "memory"); break;
+                    case 5: asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(voff), "s"(src) : "memory"); break;
+                    case 6: asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" :: "v"(voff), "s"(src) : "memory"); break;
+                    default: asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(voff), "s"(src) : "memory"); break;
+                    }
                 }
                 if (i == 11 && (it & 3) == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             } else if (KIND == 6) {       // the same bytes through registers: global_load_dwordx4 now, ds_write_b128 of the previous one
@@ -85,10 +143,40 @@ void run(unsigned long long* out, const bf16x8* src, const char* name) {
     for (int rep = 0; rep < 2; ++rep) k<ORDER, NFILL, KIND><<<grid, 256>>>(out, iters, src);
     hipDeviceSynchronize();
     hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
-    printf("%-28s fillers/MFMA %d : %.2f cycles per MFMA\n", name, NFILL, (double)h[0] / (iters * 12.0));
+    printf("%-28s fillers/MFMA %d : %.2f cycles per MFMA (waves 1-3: %.2f %.2f %.2f)\n", name, NFILL, (double)h[0] / (iters * 12.0),
+           (double)h[2] / (iters * 12.0), (double)h[4] / (iters * 12.0), (double)h[6] / (iters * 12.0));
 }
 
+__global__ void probe(const unsigned* src, unsigned* out) {
+    __shared__ __attribute__((aligned(16))) unsigned buf[4096];       // 16 KiB
+    for (int i = threadIdx.x; i < 4096; i += 64) buf[i] = 0xdeadbeefu;
+    __syncthreads();
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)buf + 4096u);
+    const unsigned voff = threadIdx.x * 16u + 4096u;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:-4096\n\tglobal_load_lds_dwordx4 %0, %1 offset:-1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072\n\ts_waitcnt vmcnt(0)"
+                 :: "v"(voff), "s"(src), "s"(dst) : "memory");
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 64) out[i] = buf[i];
+}
+static void run_probe() {
+    unsigned *src, *out; static unsigned h[4096], r[4096];
+    hipMalloc(&src, 16384); hipMalloc(&out, 16384);
+    for (int i = 0; i < 4096; ++i) h[i] = i;
+    hipMemcpy(src, h, 16384, hipMemcpyHostToDevice);
+    probe<<<1, 64>>>(src, out);
+    hipMemcpy(r, out, 16384, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int i = 0; i < 4096; ++i) {
+        const int kb = i / 256;            // 1 KiB pieces 0 (-4096), 3 (-1024), 4 (0), 7 (+3072) of an 8 KiB window were copied
+        const bool copied = kb == 0 || kb == 3 || kb == 4 || kb == 7;
+        if (r[i] != (copied ? (unsigned)i : 0xdeadbeefu)) { if (bad < 8) printf("probe mismatch at dword %d: %08x\n", i, r[i]); ++bad; }
+    }
+    printf("immediate-offset LDS-DMA probe: %s (%d mismatches)\n", bad ? "FAIL" : "ok: offset moves the LDS and the global address together", bad);
+}
 int main() {
+    run_probe();
     unsigned long long* out; bf16x8* src;
     hipMalloc(&out, 1024 * 8 * 8); hipMalloc(&src, 4096 * 16);
     hipMemset(src, 0x3c, 4096 * 16);
@@ -98,6 +186,9 @@ int main() {
     run<0, 4, 2>(out, src, "two chains"); run<0, 6, 2>(out, src, "two chains");
     run<0, 1, 3>(out, src, "accvgpr_read + add"); run<0, 2, 3>(out, src, "accvgpr_read + add"); run<0, 3, 3>(out, src, "accvgpr_read + add");
     run<0, 0, 5>(out, src, "LDS-DMA piece / 6 MFMA"); run<0, 0, 6>(out, src, "gload+ds_write / 6 MFMA"); run<0, 0, 7>(out, src, "gload only / 6 MFMA");
+    run<0, 0, 8>(out, src, "LDS-DMA staggered by wave"); run<0, 0, 9>(out, src, "LDS-DMA wave 0 only");
+    run<0, 0, 10>(out, src, "LDS-DMA bare, fixed M0"); run<0, 0, 11>(out, src, "LDS-DMA + s_xor m0"); run<0, 0, 12>(out, src, "LDS-DMA builtin"); run<0, 0, 13>(out, src, "LDS-DMA dword bare");
+    run<0, 0, 14>(out, src, "LDS-DMA bare, vaddr64"); run<0, 0, 15>(out, src, "LDS-DMA bare, imm offsets");
     run<0, 0, 4>(out, src, "ds_read_b128 (8 of 12)"); run<0, 2, 4>(out, src, "ds_read_b128 + fma"); run<0, 3, 4>(out, src, "ds_read_b128 + fma"); run<0, 4, 4>(out, src, "ds_read_b128 + fma");
     return 0;
 }

@@ -1,5 +1,5 @@
 """A/B timing of library variants (tools/build_variant.sh): forward, forward with ReLU bits and backward of the fused render at
-4096 x 64, device-event times.  usage: python tools/ab_time.py NAME [NAME ...]   (NAME 'shipped' = the in-tree library)"""
+4096 x 64, device-event times.  usage: python tools/ab_time.py NAME [NAME ...]  -- min and median over interleaved rounds   (NAME 'shipped' = the in-tree library)"""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,6 +27,10 @@ sig = torch.empty(N * S, device=dev); rgbs = torch.empty(N * S, 3, device=dev)
 masks = torch.empty(int(good.snr_mask_bytes(N * S, 3, 1)), dtype=torch.uint8, device=dev)
 d_rgb = torch.rand(N, 3, device=dev); d_depth = torch.rand(N, device=dev); d_acc = torch.rand(N, device=dev)
 d_lat = torch.empty_like(lat); d_o = torch.zeros(N, 3, device=dev); d_d = torch.zeros(N, 3, device=dev)
+a32 = ops._render_args(ro, vd, z, div, None, lat, pk, U._frame(False, False, True), 1.0, ops.Z_SHARED, 0, N, S, 3, 1, 0)
+for fn in ("snr_render_fwd",):
+    getattr(good, fn).restype, getattr(good, fn).argtypes = _lib._SIGS[fn]
+rgb32 = torch.empty(N, 3, device=dev); depth32 = torch.empty(N, device=dev); acc32 = torch.empty(N, device=dev)
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 def timed(fn, n=30):
@@ -35,7 +39,8 @@ def timed(fn, n=30):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for name in sys.argv[1:]:
+libs = {}
+def setup(name):
     lib = good if name == "shipped" else C.CDLL(os.path.join(ROOT, "tools", "_diag", f"libvariant_{name}.so"), mode=os.RTLD_NOW | os.RTLD_DEEPBIND)
     for fn in ("snr_render_fwd", "snr_render_bwd", "snr_render_bwd_ws_bytes"):
         getattr(lib, fn).restype, getattr(lib, fn).argtypes = _lib._SIGS[fn]
@@ -45,4 +50,17 @@ for name in sys.argv[1:]:
     b = lambda: lib.snr_render_bwd(C.byref(a), sig.data_ptr(), rgbs.data_ptr(), masks.data_ptr(), d_rgb.data_ptr(), d_depth.data_ptr(), d_acc.data_ptr(),
                                    d_lat.data_ptr(), d_o.data_ptr(), d_d.data_ptr(), None, ws.data_ptr(), wsb, st())
     assert f1() == 0 and b() == 0
-    print(f"{name:14s} fwd {timed(f0):.4f} ms   fwd+bits {timed(f1):.4f} ms   bwd {timed(b):.4f} ms", flush=True)
+    good.snr_render_fwd(C.byref(a32), rgb32.data_ptr(), depth32.data_ptr(), acc32.data_ptr(), None, None, None, st())
+    f0(); torch.cuda.synchronize()
+    err = f"rgb {float((rgb - rgb32).abs().max()):.1e} depth {float((depth - depth32).abs().max()):.1e} vs fp32"
+    return f0, f1, b, err, ws
+names = list(dict.fromkeys(sys.argv[1:]))
+for n in names: libs[n] = setup(n)
+res = {n: [[], [], []] for n in names}
+for rnd in range(int(os.environ.get("SNR_AB_ROUNDS", "5"))):          # interleaved rounds: clock drift hits every variant alike
+    for n in names:
+        for k in range(3): res[n][k].append(timed(libs[n][k], 20))
+for n in names:
+    r = res[n]
+    print(f"{n:14s} fwd {min(r[0]):.4f} (med {sorted(r[0])[len(r[0]) // 2]:.4f})   fwd+bits {min(r[1]):.4f} (med {sorted(r[1])[len(r[1]) // 2]:.4f})   "
+          f"bwd {min(r[2]):.4f} (med {sorted(r[2])[len(r[2]) // 2]:.4f}) ms   [{libs[n][3]}]", flush=True)
