@@ -47,88 +47,21 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(OFF_LAT % 16 == 0 && OFF_COMP % 16 == 0, "alignment");
 
 // ------------------------------------------------------------------------------------------ weight ring
+// Three 32 KiB chunks in LDS: chunk ci is being read, ci+1 is landing or has landed, ci+2 ("pending") is being requested, eight
+// 1 KiB DMA instructions per wave, a few at a time under the MFMAs that consume chunk ci.
 struct Ring {
-    const char* next;     // global address of the next chunk to fetch
+    const char* next;     // global address of the chunk after the pending one
     int ci;               // index of the next chunk to consume
     int total;            // chunks in the stream
-    int view0;            // first of the 8 backward enc_viewdir^T chunks (36 KiB each); negative = none
-    int use, fill;        // ring buffer holding chunk ci / receiving the next fetched chunk
-    unsigned wave_lds;    // wave id * 1024 (SGPR): this wave's 1 KiB slice inside every 4 KiB DMA row
-    // spread issue (forward): the chunk whose 8 pieces are issued one or two at a time under the MFMAs of the current chunk
-    const char* pg;       // its global address + this wave's 8 KiB slice
+    int use, fill;        // ring buffer holding chunk ci / receiving the next pending chunk
+    unsigned wave_lds;    // wave id * 8192 (SGPR): this wave's 8 KiB slice of every chunk
+    const char* pg;       // pending chunk: its global address + this wave's slice
     unsigned pm0;         // M0 for its pieces: LDS address of the slice + 4096 (the pieces use immediate offsets -4096 .. +3072)
     const char* last;     // address of the stream's last chunk (fetches past the end re-read it into a vacated buffer)
 };
-__device__ __forceinline__ int ring_bytes(const Ring& r, int i) { return (i >= r.view0 && i < r.view0 + 8) ? BF_CHUNK_VIEW : BF_CHUNK; }
-
-// LDS-DMA of one chunk, 4 KiB per workgroup-instruction.  Issued through inline asm on purpose: hipcc then does not
-// track these loads, so it cannot put a vmcnt(0) in front of the next ds_read "that might alias" (which would drain the
-// two-chunk prefetch every step); completion is counted by hand in ring_acquire (vmcnt(N) + s_barrier before the reads).
-// M0 (LDS destination base, wave-uniform) is written and restored inside the statement that uses it.
-__device__ __forceinline__ void ring_dma(const Ring& r, const char* g, char* lds, int bytes, int tid) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + r.wave_lds);
-    const unsigned voff = threadIdx.x * 16u;
-    unsigned keep, vt;
-    // 8 rows of 4 KiB (every chunk), M0 += 4 KiB and the per-lane source offset += 4 KiB between rows
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\tv_mov_b32 %1, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
-                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
-                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
-                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
-                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
-                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
-                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
-                 "global_load_lds_dwordx4 %1, %3\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep), "=&v"(vt) : "v"(voff), "s"(g), "s"(dst) : "memory");
-    if (bytes > BF_CHUNK) {      // ninth row of a 36 KiB enc_viewdir^T chunk
-        const unsigned dst9 = dst + 0x8000u;
-        const char* g9 = g + 0x8000;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(g9), "s"(dst9) : "memory");
-    }
-}
-
-// prologue: chunks 0 and 1 in flight
-__device__ __forceinline__ void ring_start(Ring& r, const char* stream, int total, int view0, char* lds, int tid) {
-    r.next = stream; r.ci = 0; r.total = total; r.view0 = view0; r.use = 0; r.fill = 2 % NBUF;
-    r.wave_lds = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 1024u);
-    for (int i = 0; i < 2 && i < total; ++i) {
-        const int b = ring_bytes(r, i);
-        ring_dma(r, r.next, lds + i * WB_BYTES, b, tid);
-        r.next += b;
-    }
-}
-
-// Wait for chunk ci (leaving chunk ci+1 in flight), rendezvous, start fetching chunk ci+2 into the buffer chunk
-// ci-1 just vacated.  Returns the LDS address of chunk ci.
-__device__ __forceinline__ const char* ring_acquire(Ring& r, char* lds, int tid) {
-    // every chunk is issued as 8 (32 KiB) or 9 (36 KiB) DMA instructions per wave; leaving the 8 youngest in flight
-    // retires chunk ci completely (and at most one instruction of a 36 KiB chunk ci+1)
-#ifndef SNR_EXP_NOSYNC      /* timing experiments only: results are garbage without the rendezvous */
-#ifndef SNR_EXP_NOVM
-    if (r.ci + 1 < r.total) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-#ifndef SNR_EXP_NOBAR
-    __builtin_amdgcn_s_barrier();
-#endif
-#endif
-    if (r.ci + 2 < r.total) {
-        const int b = ring_bytes(r, r.ci + 2);
-#ifndef SNR_EXP_NODMA
-        ring_dma(r, r.next, lds + r.fill * WB_BYTES, b, tid);
-#endif
-        r.next += b;
-        r.fill = (r.fill == NBUF - 1) ? 0 : r.fill + 1;
-    }
-    const char* p = lds + r.use * WB_BYTES;
-    r.use = (r.use == NBUF - 1) ? 0 : r.use + 1;
-    r.ci += 1;
-    return p;
-}
-
-// ---- spread issue.  A burst of 8 DMA instructions per wave keeps the wave (and, the four waves sharing the CU's address path,
+// LDS-DMA through inline asm on purpose: hipcc then does not track these loads, so it cannot put a vmcnt(0) in front of the next
+// ds_read "that might alias" (which would drain the prefetch every step); completion is counted by hand in ring_acquire
+// (vmcnt(8) + s_barrier before the reads).  A burst of 8 DMA instructions per wave keeps the wave (and, the four waves sharing the CU's address path,
 // the whole workgroup) out of the matrix pipe for ~500 cycles per chunk; one bare instruction between MFMAs costs ~20
 // (tools/_diag/mfma_order.hip).  Bare = no M0 save/restore and no address arithmetic between pieces: wave w copies the contiguous
 // 8 KiB slice w of the chunk, M0 points into the middle of its LDS image and the instruction's immediate offset, which moves the
@@ -144,8 +77,14 @@ template <int K0, int N>
 __device__ __forceinline__ void ring_pieces(const Ring& r, unsigned voff) {
     if constexpr (N > 0) { ring_piece<K0>(r, voff); ring_pieces<K0 + 1, N - 1>(r, voff); }
 }
-__device__ __forceinline__ void ring_start_spread(Ring& r, const char* stream, int total, char* lds, unsigned voff) {
-    r.ci = 0; r.total = total; r.view0 = -100; r.use = 0; r.fill = 2 % NBUF;
+// pieces of the pending chunk that belong to position PP of the 2*SPC half-steps between two acquires (8 pieces over the period)
+template <int PP, int SPC>
+__device__ __forceinline__ void ring_pieces_at(const Ring& r, unsigned voff) {
+    constexpr int K0 = PP * 8 / (2 * SPC), N = (PP + 1) * 8 / (2 * SPC) - K0;
+    ring_pieces<K0, N>(r, voff);
+}
+__device__ __forceinline__ void ring_start(Ring& r, const char* stream, int total, char* lds, unsigned voff) {
+    r.ci = 0; r.total = total; r.use = 0; r.fill = 2 % NBUF;
     r.wave_lds = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 8192u);
     r.last = stream + (size_t)(total - 1) * BF_CHUNK;
     const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds) + r.wave_lds + 4096u;
@@ -155,7 +94,7 @@ __device__ __forceinline__ void ring_start_spread(Ring& r, const char* stream, i
 }
 // Wait for chunk ci (the 8 youngest DMA instructions are chunk ci+1's), rendezvous, and make chunk ci+2 the pending one; the caller
 // issues its 8 pieces before the next acquire.  No branches: past the end of the stream the pending chunk is the last chunk again.
-__device__ __forceinline__ const char* ring_acquire_spread(Ring& r, char* lds) {
+__device__ __forceinline__ const char* ring_acquire(Ring& r, char* lds) {
 #ifndef SNR_EXP_NOSYNC
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -359,7 +298,7 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
     acc_bias<NT, 8>(accC, c.bias, h);
     fwd_half_tile<0, 0, MASKS>(accP[0], x[0], c, h, mask);
     Frags<NTH> fa, fb;
-    const char* w = ring_acquire_spread(ring, lds) + lane * 16;
+    const char* w = ring_acquire(ring, lds) + lane * 16;
     load_frags<NTH, 0>(fa, w);
     ring_pieces<0, PPH>(ring, voff);
 #define SNR_FSTEP(S)                                                                                                   \
@@ -377,7 +316,7 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
         SNR_INTERLEAVE(3 * NTH)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + STEP_BYTES);                                   \
-        else if constexpr ((S) + 1 < 16) { w = ring_acquire_spread(ring, lds) + lane * 16; load_frags<NTH, 0>(fa, w); } \
+        else if constexpr ((S) + 1 < 16) { w = ring_acquire(ring, lds) + lane * 16; load_frags<NTH, 0>(fa, w); } \
         mma_half<NTH, NTH, 8>(accC, x[S], fb);                                                                         \
         if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0) ring_pieces<PPH * ((2 * (S) + 2) % (2 * SPC)), PPH>(ring, voff); \
         if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1, MASKS>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v1, mask); \
@@ -388,7 +327,7 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
     SNR_FSTEP(8) SNR_FSTEP(9) SNR_FSTEP(10) SNR_FSTEP(11) SNR_FSTEP(12) SNR_FSTEP(13) SNR_FSTEP(14) SNR_FSTEP(15)
 #undef SNR_FSTEP
     if (extra) {      // enc_viewdir: k = 256..287 are the direction features
-        w = ring_acquire_spread(ring, lds) + lane * 16;
+        w = ring_acquire(ring, lds) + lane * 16;
         ring_pieces<0, 8>(ring, voff);
         XOp d0, d1;
         d0.hi = *reinterpret_cast<const bf16x8*>(xdir_lds);        d0.lo = *reinterpret_cast<const bf16x8*>(xdir_lds + 1024);
@@ -455,7 +394,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     Ring ring;
     const int total_chunks = 2 + 8 * (sb + 1) + 9 + 8 * tb + 4;
     const unsigned voff = lane * 16u + 4096u;
-    ring_start_spread(ring, reinterpret_cast<const char*>(io.packed + L.bf_fwd), total_chunks, lds, voff);
+    ring_start(ring, reinterpret_cast<const char*>(io.packed + L.bf_fwd), total_chunks, lds, voff);
 
     XOp x[16];
     char* xdir = lds + OFF_XDIR + wave * 4096 + lane * 16;
@@ -502,13 +441,13 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
 
     // ---- enc_xyz: 4 operand steps straight from the encoding -> accA
     {
-        const char* w = ring_acquire_spread(ring, lds) + lane * 16;      // (its barrier also retires the scratch rows)
+        const char* w = ring_acquire(ring, lds) + lane * 16;      // (its barrier also retires the scratch rows)
         ring_pieces<0, 4>(ring, voff);
         acc_bias<8, 8>(accA, vec + VEC_BIAS, h);
         step_mma<8, 8>(accA, x[0], w);
         ring_pieces<4, 4>(ring, voff);
         step_mma<8, 8>(accA, x[1], w + 16 * 1024);
-        w = ring_acquire_spread(ring, lds) + lane * 16;
+        w = ring_acquire(ring, lds) + lane * 16;
         ring_pieces<0, 4>(ring, voff);
         step_mma<8, 8>(accA, x[2], w);
         ring_pieces<4, 4>(ring, voff);
@@ -685,21 +624,24 @@ __device__ __forceinline__ void bwd_half_tile(const f32x16& acc, XOp& out, const
     bwd_quarter<T, HALF, 1>(acc, out, c, w1, lane);
 }
 
-// One transposed layer: 16 operand steps from accP, NT (+1 with `ninth`) output tiles into accC (+ acc9); same
-// half-step pipeline as layer_fwd.
+// One transposed layer: 16 operand steps from accP, NT output tiles into accC; same half-step pipeline as layer_fwd.  With
+// `ninth` (enc_viewdir^T) a ninth output tile, the gradient of the 32 direction features, follows from one more chunk: its 16
+// steps x (hi, lo) KiB are packed behind the layer's 8 regular chunks and multiply the operand steps still held in x.
 template <int NT>
 __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], f32x16& acc9, XOp (&x)[16], Ring& ring, char* lds,
                                           const BwdEpi& c, bool ninth, int tid, int lane) {
     const int h = lane >> 5;
+    const unsigned voff = lane * 16u + 4096u;
     constexpr int NTH = NT / 2;
     constexpr int SPC = (NT == 8) ? 2 : 8;                  // steps per chunk (NT == 2: enc_xyz^T, 8 steps of 4 KiB)
-    const int step_bytes = (NT + (ninth ? 1 : 0)) * 2 * 1024;
+    constexpr int step_bytes = NT * 2 * 1024;
     if (c.dzl) reduce_tiles_lds(accP, c.dzl, reinterpret_cast<float*>(lds + OFF_XDIR) + (threadIdx.x >> 6) * 1024, lane);
     acc_zero<NT, 8>(accC);
     bwd_half_tile<0, 0>(accP[0], x[0], c, h, lane);
     Frags<NTH> fa, fb;
-    const char* w = ring_acquire(ring, lds, tid) + lane * 16;
+    const char* w = ring_acquire(ring, lds) + lane * 16;
     load_frags<NTH, 0>(fa, w);
+    ring_pieces_at<0, SPC>(ring, voff);
 #define SNR_BSTEP(S)                                                                                                   \
     {                                                                                                                  \
         const char* ws = w + ((S) % SPC) * step_bytes;                                                                 \
@@ -710,19 +652,14 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
             w1 = *reinterpret_cast<const f32x4*>(c.wsig + 32 * (((S) + 1) >> 1) + 8 * (2 * (((S) + 1) & 1) + 1) + 4 * h); \
         }                                                                                                              \
         mma_half<NTH, 0, 8>(accC, x[S], fa);                                                                           \
+        ring_pieces_at<(2 * (S) + 1) % (2 * SPC), SPC>(ring, voff);                                                    \
         if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, w0, lane); \
         SNR_INTERLEAVE_B(3 * NTH)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if (NT == 8 && ninth) {                                                                                        \
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + 16 * 1024);                                        \
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ws + 17 * 1024);                                        \
-            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x[S].hi, acc9, 0, 0, 0);                                \
-            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x[S].lo, acc9, 0, 0, 0);                                \
-            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, x[S].hi, acc9, 0, 0, 0);                                \
-        }                                                                                                              \
         if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + step_bytes);                                   \
-        else if constexpr ((S) + 1 < 16) { w = ring_acquire(ring, lds, tid) + lane * 16; load_frags<NTH, 0>(fa, w); }  \
+        else if constexpr ((S) + 1 < 16) { w = ring_acquire(ring, lds) + lane * 16; load_frags<NTH, 0>(fa, w); } \
         mma_half<NTH, NTH, 8>(accC, x[S], fb);                                                                         \
+        if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0) ring_pieces_at<(2 * (S) + 2) % (2 * SPC), SPC>(ring, voff); \
         if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, w1, lane); \
         SNR_INTERLEAVE_B(3 * NTH)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
@@ -730,6 +667,18 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
     SNR_BSTEP(0) SNR_BSTEP(1) SNR_BSTEP(2) SNR_BSTEP(3) SNR_BSTEP(4) SNR_BSTEP(5) SNR_BSTEP(6) SNR_BSTEP(7)
     SNR_BSTEP(8) SNR_BSTEP(9) SNR_BSTEP(10) SNR_BSTEP(11) SNR_BSTEP(12) SNR_BSTEP(13) SNR_BSTEP(14) SNR_BSTEP(15)
 #undef SNR_BSTEP
+    if (NT == 8 && ninth) {
+        w = ring_acquire(ring, lds) + lane * 16;
+        ring_pieces<0, 8>(ring, voff);
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(w + s2 * 2048);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(w + s2 * 2048 + 1024);
+            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x[s2].hi, acc9, 0, 0, 0);
+            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x[s2].lo, acc9, 0, 0, 0);
+            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, x[s2].hi, acc9, 0, 0, 0);
+        }
+    }
 }
 
 #ifdef SNR_STAMPS
@@ -826,8 +775,9 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     SNR_BSTAMP(1);
 
     Ring ring;
-    const int total_chunks = 4 + 8 * tb + 8 + 8 * (sb + 1) + 2;
-    ring_start(ring, reinterpret_cast<const char*>(io.packed + L.bf_bwd), total_chunks, 4 + 8 * tb, lds, tid);   // enc_viewdir^T chunks are 36 KiB
+    const int total_chunks = 4 + 8 * tb + 9 + 8 * (sb + 1) + 2;       // enc_viewdir^T: 8 chunks + 1 for its ninth tile
+    const unsigned voff = lane * 16u + 4096u;
+    ring_start(ring, reinterpret_cast<const char*>(io.packed + L.bf_bwd), total_chunks, lds, voff);
 
     XOp x[16];
     auto mask_words = [&](int slot, uint32_t (&m)[4]) {        // runtime slot out of the register array (static unroll)
@@ -868,7 +818,8 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
         const char* w = nullptr;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            if ((s & 1) == 0) w = ring_acquire(ring, lds, tid) + lane * 16;
+            if ((s & 1) == 0) { w = ring_acquire(ring, lds) + lane * 16; ring_pieces<0, 4>(ring, voff); }
+            else ring_pieces<4, 4>(ring, voff);
             step_mma<8, 8>(accA, x[s], w + (s & 1) * 16 * 1024);
         }
     }
@@ -905,7 +856,9 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
         for (int la = 0; la < L.n_lat; ++la)
             *reinterpret_cast<f32x4*>(io.partial + (tile32 * L.n_lat + la) * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(dzl + la * 256 + lane * 4);
     }
-    // ---- positional-encoding backward through the scratch rows
+    // ---- positional-encoding backward through the scratch rows (they alias ring buffer 2: the re-fetches past the stream's end
+    // must have landed in every wave's slice first)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     float* sc = reinterpret_cast<float*>(lds + OFF_PE) + (wave * 32 + p) * PE_ROWF;
 #pragma unroll
@@ -1013,7 +966,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
 //   [s][tile][plane hi/lo][lane][8].
 //   forward  (transpose == 0): value = W[row][k]           row = output feature, k = input feature
 //   backward (transpose == 1): value = W[k][row]           row = input feature,  k = output feature
-__global__ void pack_bf16_kernel(const float* __restrict__ Wt, int n_out, int k_in, int transpose, int n_tiles, int KS,
+__global__ void pack_bf16_kernel(const float* __restrict__ Wt, int n_out, int k_in, int transpose, int n_tiles, int KS, int tile0,
                                  __bf16* __restrict__ dst) {
     const long long total = (long long)n_tiles * KS * 64 * 8;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -1021,7 +974,7 @@ __global__ void pack_bf16_kernel(const float* __restrict__ Wt, int n_out, int k_
         const int lane = (int)((i >> 3) & 63);
         const int tile = (int)((i >> 9) % n_tiles);
         const int s = (int)((i >> 9) / n_tiles);
-        const int row = 32 * tile + (lane & 31), hh = lane >> 5;
+        const int row = 32 * (tile0 + tile) + (lane & 31), hh = lane >> 5;
         const int k = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
         float v = 0.f;
         if (!transpose) { if (row < n_out && k < k_in) v = Wt[(long long)row * k_in + k]; }
@@ -1047,10 +1000,10 @@ int snr_bf16_supported_(int sb, int tb, long long points_per_obj) {
 int snr_bf16_pack_(const float* const* W /* per-point weight tensors in MFMA-layer order */, int sb, int tb, float* packed, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
     const Layout L = make_layout(sb, tb);
-    auto launch = [&](const float* w, int n_out, int k_in, int transpose, int n_tiles, int KS, __bf16* dst) {
+    auto launch = [&](const float* w, int n_out, int k_in, int transpose, int n_tiles, int KS, __bf16* dst, int tile0 = 0) {
         const long long total = (long long)n_tiles * KS * 512;
         int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-        bf::pack_bf16_kernel<<<grid, 256, 0, st>>>(w, n_out, k_in, transpose, n_tiles, KS, dst);
+        bf::pack_bf16_kernel<<<grid, 256, 0, st>>>(w, n_out, k_in, transpose, n_tiles, KS, tile0, dst);
     };
     const int n_layers = sb + tb + 4;
     // forward stream
@@ -1072,9 +1025,13 @@ int snr_bf16_pack_(const float* const* W /* per-point weight tensors in MFMA-lay
         const int n_out = is_rgb0 ? 128 : 256;
         const int k_in = is_xyz ? D_XYZ : (is_view ? 256 + D_DIR : 256);
         const int KS = n_out / 16;                                 // reduction over the layer's outputs
-        const int n_tiles = is_xyz ? 2 : (is_view ? 9 : 8);        // tiles of 32 input features
+        const int n_tiles = is_xyz ? 2 : 8;                        // tiles of 32 input features
         launch(W[li], n_out, k_in, 1, n_tiles, KS, reinterpret_cast<__bf16*>(b));
         b += (long long)n_tiles * 2 * KS * 1024;
+        if (is_view) {                                             // the direction features: ninth tile, a chunk of its own
+            launch(W[li], n_out, k_in, 1, 1, KS, reinterpret_cast<__bf16*>(b), 8);
+            b += 2ll * KS * 1024;
+        }
     }
     if (b - reinterpret_cast<char*>(packed + L.bf_bwd) != L.bf_bwd_bytes) return SNR_E_SHAPE;
     return snr_check_launch_();
