@@ -192,19 +192,6 @@ __device__ __forceinline__ void fwd_quarter_load(EpiVec& v, const FwdEpi& c, int
     const int j = 2 * HALF + JJ;
     v.z = *reinterpret_cast<const f32x4*>(c.zl + 32 * T + 8 * j + 4 * h);
 }
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-// two values at a time: the latent add and the hi/lo split run on the packed-fp32 VALU ops (v_pk_add_f32), one issue slot per pair
-// (LLVM scalarises <2 x float> adds whose elements come from separate registers, hence the asm)
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ void split_store2(f32x2 y, XOp& o, int jp) {
-    const bf16x2 hp = __builtin_convertvector(y, bf16x2);
-    const f32x2 lo = pk_sub(y, __builtin_convertvector(hp, f32x2));
-    const bf16x2 lp = __builtin_convertvector(lo, bf16x2);
-    o.hi[2 * jp] = hp[0]; o.hi[2 * jp + 1] = hp[1];
-    o.lo[2 * jp] = lp[0]; o.lo[2 * jp + 1] = lp[1];
-}
 template <int T, int HALF, int JJ, bool MASKS>
 __device__ __forceinline__ void fwd_quarter(const f32x16& acc, XOp& out, const FwdEpi& c, const EpiVec& v, uint32_t (&mask)[4]) {
 #ifdef SNR_EXP_NOEPI
@@ -212,21 +199,17 @@ __device__ __forceinline__ void fwd_quarter(const f32x16& acc, XOp& out, const F
 #endif
     const int j = 2 * HALF + JJ;
 #pragma unroll
-    for (int e2 = 0; e2 < 2; ++e2) {
-        const int r = 4 * j + 2 * e2;
-        const float a0 = acc[r], a1 = acc[r + 1];      // bias already inside (acc_bias).  Scalars on purpose: __builtin_bit_cast of
-                                                       // an ext-vector ELEMENT reads element 0 whatever the index (clang 19, ROCm 7.2)
+    for (int e = 0; e < 4; ++e) {
+        const int r = 4 * j + e;
+        const float a = acc[r];           // bias already inside (acc_bias)
         // ReLU bits (only stored for ReLU layers), one VALU op per value and no VCC: v_alignbit shifts the word left and
         // takes in the sign bit of a; the 32 values of a word arrive in register order (tile 2w r0..15, tile 2w+1 r0..15), so
         // store_mask recovers bit (T&1)*16 + r = "a > 0" as ~bitreverse(word).  (a == +0.0 counts as positive.)
-        if (MASKS) {
-            mask[T >> 1] = __builtin_amdgcn_alignbit(mask[T >> 1], __builtin_bit_cast(uint32_t, a0), 31);
-            mask[T >> 1] = __builtin_amdgcn_alignbit(mask[T >> 1], __builtin_bit_cast(uint32_t, a1), 31);
-        }
-        f32x2 m = {__builtin_bit_cast(float, max(__builtin_bit_cast(int, a0), c.floor)),
-                   __builtin_bit_cast(float, max(__builtin_bit_cast(int, a1), c.floor))};         // v_max_i32: no canonicalisation, -0 -> 0
-        m = pk_add(m, f32x2{v.z[2 * e2], v.z[2 * e2 + 1]});
-        split_store2(m, out, (r & 7) >> 1);
+        if (MASKS) mask[T >> 1] = __builtin_amdgcn_alignbit(mask[T >> 1], __builtin_bit_cast(uint32_t, a), 31);
+        // ReLU as v_max_i32 on the bit pattern (no canonicalising second max, -0 -> +0), then the latent term, then the hi/lo split.
+        // Plain C++ on purpose: the same epilogue on v_pk_add_f32 through inline asm has a quarter fewer VALU ops and is 2-4 % SLOWER,
+        // the scheduler cannot place asm statements under the MFMAs (sched_group_barrier does not see them as VALU).
+        split_store(__builtin_bit_cast(float, max(__builtin_bit_cast(int, a), c.floor)) + v.z[e], out, r & 7);
     }
     if (JJ == 1) pin(out);
     if (MASKS) asm volatile("" : "+v"(mask[T >> 1]));      // keep the bit capture here (LLVM otherwise recomputes it at the layer's end)
@@ -258,10 +241,10 @@ __device__ __forceinline__ float sigma_partial(const f32x16 (&acc)[8], const flo
 
 // interleave request for one half-step region: after every MFMA one LDS read (while there are any) and a few VALU ops, so the
 // fragment fetches for the next half-step and the previous layer's epilogue are spread under the MFMAs instead of in blocks.
-// Measured (tools/ab_time.py, interleaved rounds): forward, ~20 epilogue ops per 12 MFMAs: read + 2 VALU per MFMA is best (-2 % against
-// 4 VALU and no read request); backward, ~34 ops per 12 MFMAs: 4 VALU and no read request.
+// Measured (tools/ab_time.py, interleaved rounds): forward, ~26 epilogue ops per 12 MFMAs: 2 VALU per MFMA and no read request is best (-4 % against
+// 4 VALU, -2 % against no request at all); backward, ~34 ops per 12 MFMAs: 3 VALU and no read request (-1 % against 4).
 #ifndef SNR_IL_DS
-#define SNR_IL_DS 1
+#define SNR_IL_DS 0
 #endif
 #ifndef SNR_IL_VALU
 #define SNR_IL_VALU 2
@@ -270,7 +253,7 @@ __device__ __forceinline__ float sigma_partial(const f32x16 (&acc)[8], const flo
 #define SNR_ILB_DS 0
 #endif
 #ifndef SNR_ILB_VALU
-#define SNR_ILB_VALU 4
+#define SNR_ILB_VALU 3
 #endif
 #define SNR_INTERLEAVE_(N_MFMA, DS, VALU)                                                \
     _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA); ++g_) {                            \
