@@ -83,6 +83,11 @@ __device__ __forceinline__ void ring_pieces_at(const Ring& r, unsigned voff) {
     constexpr int K0 = PP * 8 / (2 * SPC), N = (PP + 1) * 8 / (2 * SPC) - K0;
     ring_pieces<K0, N>(r, voff);
 }
+// the same inside the stream's LAST layer of NCH chunks: period W (0 = after the layer's first acquire) requests chunk W + 2 of the layer
+template <int PP, int SPC, int W, int NCH, bool TAIL>
+__device__ __forceinline__ void ring_pieces_in(const Ring& r, unsigned voff) {
+    if constexpr (!TAIL || W + 2 < NCH) ring_pieces_at<PP, SPC>(r, voff);
+}
 __device__ __forceinline__ void ring_start(Ring& r, const char* stream, int total, char* lds, unsigned voff) {
     r.ci = 0; r.total = total; r.use = 0; r.fill = 2 % NBUF;
     r.wave_lds = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 8192u);
@@ -93,10 +98,14 @@ __device__ __forceinline__ void ring_start(Ring& r, const char* stream, int tota
     r.next = stream + 2 * BF_CHUNK;
 }
 // Wait for chunk ci (the 8 youngest DMA instructions are chunk ci+1's), rendezvous, and make chunk ci+2 the pending one; the caller
-// issues its 8 pieces before the next acquire.  No branches: past the end of the stream the pending chunk is the last chunk again.
+// issues its 8 pieces before the next acquire.  No branches; the stream's last layer (rgb.0 forward, enc_xyz^T backward: the narrow
+// instances of the layer templates) knows at compile time which of its periods have no chunk left to request and that its final
+// acquire has nothing younger behind it, so no DMA is in flight when the layers are done.  (`last` only guards a miscounted stream.)
+template <bool LAST = false>      // LAST: the stream's final chunk, no younger DMA behind it
 __device__ __forceinline__ const char* ring_acquire(Ring& r, char* lds) {
 #ifndef SNR_EXP_NOSYNC
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    if constexpr (LAST) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #endif
     const char* nx = r.next < r.last ? r.next : r.last;
@@ -274,7 +283,8 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
     const unsigned voff = lane * 16u + 4096u;         // DMA source offset of this lane inside the wave's slice (+ 4096, see ring_piece)
     constexpr int NTH = NT / 2;
     constexpr int SPC = (NT == 8) ? 2 : 4;            // steps per 32 KiB chunk
-    constexpr int PPH = 8 / (2 * SPC);                // DMA pieces per half-step: a chunk's 8 pieces over the 2*SPC half-steps up to the next acquire
+    constexpr bool TAIL = (NT != 8);                  // rgb.0: the stream ends with this layer
+    constexpr int NCH = 16 / SPC;                     // chunks of this layer
     constexpr int STEP_BYTES = NT * 2 * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) mask[i] = 0u;
@@ -283,7 +293,7 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
     Frags<NTH> fa, fb;
     const char* w = ring_acquire(ring, lds) + lane * 16;
     load_frags<NTH, 0>(fa, w);
-    ring_pieces<0, PPH>(ring, voff);
+    ring_pieces_in<0, SPC, 0, NCH, TAIL>(ring, voff);
 #define SNR_FSTEP(S)                                                                                                   \
     {                                                                                                                  \
         const char* ws = w + ((S) % SPC) * STEP_BYTES;                                                                 \
@@ -294,14 +304,15 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
             fwd_quarter_load<(((S) + 1) >> 1), (((S) + 1) & 1), 1>(v1, c, h);                                          \
         }                                                                                                              \
         mma_half<NTH, 0, 8>(accC, x[S], fa);                                                                           \
-        ring_pieces<PPH * ((2 * (S) + 1) % (2 * SPC)), PPH>(ring, voff);                                               \
+        ring_pieces_in<(2 * (S) + 1) % (2 * SPC), SPC, (2 * (S) + 1) / (2 * SPC), NCH, TAIL>(ring, voff);              \
         if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0, MASKS>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v0, mask); \
         SNR_INTERLEAVE(3 * NTH)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + STEP_BYTES);                                   \
-        else if constexpr ((S) + 1 < 16) { w = ring_acquire(ring, lds) + lane * 16; load_frags<NTH, 0>(fa, w); } \
+        else if constexpr ((S) + 1 < 16) { w = ring_acquire<TAIL && ((S) + 1) / SPC == NCH - 1>(ring, lds) + lane * 16; load_frags<NTH, 0>(fa, w); } \
         mma_half<NTH, NTH, 8>(accC, x[S], fb);                                                                         \
-        if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0) ring_pieces<PPH * ((2 * (S) + 2) % (2 * SPC)), PPH>(ring, voff); \
+        if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0)                                                \
+            ring_pieces_in<(2 * (S) + 2) % (2 * SPC), SPC, (2 * (S) + 2) / (2 * SPC), NCH, TAIL>(ring, voff);          \
         if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1, MASKS>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v1, mask); \
         SNR_INTERLEAVE(3 * NTH)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
@@ -540,7 +551,6 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two re-fetches past the stream's end must land before the LDS is handed on
     SNR_STAMP(14);
 }
 
@@ -618,13 +628,15 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
     constexpr int NTH = NT / 2;
     constexpr int SPC = (NT == 8) ? 2 : 8;                  // steps per chunk (NT == 2: enc_xyz^T, 8 steps of 4 KiB)
     constexpr int step_bytes = NT * 2 * 1024;
+    constexpr bool TAIL = (NT != 8);                        // enc_xyz^T: the stream ends with this layer
+    constexpr int NCH = 16 / SPC;
     if (c.dzl) reduce_tiles_lds(accP, c.dzl, reinterpret_cast<float*>(lds + OFF_XDIR) + (threadIdx.x >> 6) * 1024, lane);
     acc_zero<NT, 8>(accC);
     bwd_half_tile<0, 0>(accP[0], x[0], c, h, lane);
     Frags<NTH> fa, fb;
-    const char* w = ring_acquire(ring, lds) + lane * 16;
+    const char* w = ring_acquire<TAIL && NCH == 1>(ring, lds) + lane * 16;
     load_frags<NTH, 0>(fa, w);
-    ring_pieces_at<0, SPC>(ring, voff);
+    ring_pieces_in<0, SPC, 0, NCH, TAIL>(ring, voff);
 #define SNR_BSTEP(S)                                                                                                   \
     {                                                                                                                  \
         const char* ws = w + ((S) % SPC) * step_bytes;                                                                 \
@@ -635,14 +647,15 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
             w1 = *reinterpret_cast<const f32x4*>(c.wsig + 32 * (((S) + 1) >> 1) + 8 * (2 * (((S) + 1) & 1) + 1) + 4 * h); \
         }                                                                                                              \
         mma_half<NTH, 0, 8>(accC, x[S], fa);                                                                           \
-        ring_pieces_at<(2 * (S) + 1) % (2 * SPC), SPC>(ring, voff);                                                    \
+        ring_pieces_in<(2 * (S) + 1) % (2 * SPC), SPC, (2 * (S) + 1) / (2 * SPC), NCH, TAIL>(ring, voff);              \
         if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, w0, lane); \
         SNR_INTERLEAVE_B(3 * NTH)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + step_bytes);                                   \
-        else if constexpr ((S) + 1 < 16) { w = ring_acquire(ring, lds) + lane * 16; load_frags<NTH, 0>(fa, w); } \
+        else if constexpr ((S) + 1 < 16) { w = ring_acquire<TAIL && ((S) + 1) / SPC == NCH - 1>(ring, lds) + lane * 16; load_frags<NTH, 0>(fa, w); } \
         mma_half<NTH, NTH, 8>(accC, x[S], fb);                                                                         \
-        if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0) ring_pieces_at<(2 * (S) + 2) % (2 * SPC), SPC>(ring, voff); \
+        if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0)                                                \
+            ring_pieces_in<(2 * (S) + 2) % (2 * SPC), SPC, (2 * (S) + 2) / (2 * SPC), NCH, TAIL>(ring, voff);          \
         if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, w1, lane); \
         SNR_INTERLEAVE_B(3 * NTH)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
@@ -839,9 +852,8 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
         for (int la = 0; la < L.n_lat; ++la)
             *reinterpret_cast<f32x4*>(io.partial + (tile32 * L.n_lat + la) * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(dzl + la * 256 + lane * 4);
     }
-    // ---- positional-encoding backward through the scratch rows (they alias ring buffer 2: the re-fetches past the stream's end
-    // must have landed in every wave's slice first)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- positional-encoding backward through the scratch rows (they alias ring buffer 2; the ring retired its last DMA at the
+    // final acquire)
     __syncthreads();
     float* sc = reinterpret_cast<float*>(lds + OFF_PE) + (wave * 32 + p) * PE_ROWF;
 #pragma unroll

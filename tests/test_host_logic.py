@@ -316,6 +316,26 @@ def test_small_utilities_match_reference(amd, golden):
         assert float((a - g[k]).abs().max()) < 1e-6, k
 
 
+def test_m0_is_written_only_by_the_weight_ring(tmp_path):
+    """The bf16x3 kernels issue their LDS-DMA through inline asm that sets M0 itself and does not restore it (csrc/snr_bf16.hip,
+    ring_piece).  That is only sound while the compiler keeps no value of its own in M0: every mention of m0 in the generated code
+    must be the ring's own `s_mov_b32 m0, sN`."""
+    import re, shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sup-nerf_amd", "csrc", "snr_bf16.hip")
+    out = tmp_path / "snr_bf16.s"
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "--offload-device-only", "-S", src, "-o", str(out)],
+                   check=True, capture_output=True)
+    lines = [l.strip() for l in open(out) if re.search(r"\bm0\b", l.split(";")[0])]
+    assert lines, "the ring's DMA instructions are gone?"
+    bad = [l for l in lines if not re.fullmatch(r"s_mov_b32 m0, s\d+", l.split(";")[0].strip())]
+    assert not bad, bad[:5]
+    n_dma = sum(1 for l in open(out) if "global_load_lds_dwordx4" in l)
+    assert n_dma == len(lines)
+
+
 def test_reference_file_formats_round_trip(amd, tmp_path):
     """models.pth / codes+poses.pth with the reference's keys (src/trainer_unified_nuscenes.py:476-490, src/optimizer_nuscenes.py:1463-1476)."""
     m = amd.SUPNeRF(shape_blocks=3, texture_blocks=1)
