@@ -555,37 +555,58 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
 }
 
 // ------------------------------------------------------------------------------------------ backward
-// Latent-term gradient of one layer: sum every feature of the 8 finished accumulator tiles over the wave's 32 points.
-// Done through a wave-private LDS scratch, half a tile at a time: lane (p,h) writes its 8 values of the half tile as two
-// ds_write_b128 into row p (16 features + 4 pad floats), then lane (f, q) adds the 8 rows of point group q for feature f,
-// the four groups meet through two permlane swaps at the very end, and the 256 sums are parked in LDS (`out`) until the kernel's
-// last phase stores them -- so no global store is queued between the hand-counted DMA waits of the layer chain.
-// (The previous version, a register butterfly of 16 ds_bpermute per tile in the middle of the MFMA pipeline, cost 35-45 k
-// cycles per latent layer = 40 % of the backward kernel.)
-constexpr int RED_STRIDE = 20;      // floats per scratch row: 16 features + pad (16-byte aligned rows, conflict-free column reads)
-__device__ __forceinline__ void reduce_tiles_lds(const f32x16 (&acc)[8], float* __restrict__ out /*LDS, 256*/, float* scratch /*LDS, 32*RED_STRIDE*/,
-                                                 int lane) {
-    const int p = lane & 31, h = lane >> 5, f = lane & 15, q = lane >> 4;
-    float s[16];
+// Latent-term gradient of one layer: sum every feature of the 8 finished accumulator tiles over the wave's 32 points; the 256 sums
+// are parked in LDS (`out`) until the kernel's last phase stores them, so no global store is queued between the hand-counted DMA
+// waits of the layer chain.  History: a register butterfly of 16 ds_bpermute per tile inside the MFMA pipeline cost 35-45 k cycles
+// per latent layer; a transpose through a wave-private LDS scratch ~4 k; this version ~3 k.
+// On the VALU alone (no LDS round trips): a reduce-scatter over the 32 point lanes with DPP row operations.
+// Each step pairs lanes (row_mirror: i <-> 15-i, row_half_mirror: j <-> 7-j inside a group of 8) and pairs registers; the lanes of one
+// half of a pair sum register set 0, the other half set 1 (bank_mask picks the halves), so every step halves the live registers.
+// The two in-quad levels are plain sums (bank_mask cannot split a quad), the two rows of a half meet through v_permlane16_swap.
+//   A  tiles t | t+4      lanes i<8 | i>=8        64 -> 32 registers (per half of the 16 accumulator registers)
+//   B  tiles t | t+2      j<4 | j>=4              32 -> 16
+//   C, D  quad sums                                16
+//   E  tiles 0 | 1        even | odd row          16 -> 8
+// so lane (h, rho = row parity, A = bit 3, B = bit 2) ends up with the 32-point sums of tile rho + 2B + 4A, registers r = 0..15, i.e.
+// features 32*tile + 8*(r>>2) + 4h + (r&3); one lane per quad stores them.  All through asm volatile: the statements keep their order,
+// which keeps every DPP read >= 2 instructions behind the write of its source (the hazard the compiler would otherwise pad).
+#define SNR_DPP_SELF(R, CTRL, BANK) asm volatile("v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:" BANK : "+v"(R))
+#define SNR_DPP_FROM(R0, R1, CTRL, BANK) asm volatile("v_add_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:" BANK : "+v"(R0) : "v"(R1))
+__device__ __forceinline__ void reduce_tiles_dpp(const f32x16 (&acc)[8], float* __restrict__ out /*LDS, 256*/, int lane) {
+    const int h = lane >> 5, tile = ((lane >> 4) & 1) + 2 * ((lane >> 2) & 1) + 4 * ((lane >> 3) & 1);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {            // half tile k: tile k>>1, registers 8*(k&1) .. +7
-        const int t = k >> 1, r0 = 8 * (k & 1);
-        f32x4 v0 = {acc[t][r0], acc[t][r0 + 1], acc[t][r0 + 2], acc[t][r0 + 3]};
-        f32x4 v1 = {acc[t][r0 + 4], acc[t][r0 + 5], acc[t][r0 + 6], acc[t][r0 + 7]};
-        *reinterpret_cast<f32x4*>(scratch + p * RED_STRIDE + 4 * h) = v0;
-        *reinterpret_cast<f32x4*>(scratch + p * RED_STRIDE + 8 + 4 * h) = v1;
-        __builtin_amdgcn_wave_barrier();
-        float a = 0.f;
+    for (int rh = 0; rh < 2; ++rh) {
+        float v[8][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a += scratch[(8 * q + i) * RED_STRIDE + f];
-        s[k] = a;
-        __builtin_amdgcn_wave_barrier();
-    }
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s[k] = sum_halves(sum_row_pairs(s[k]));       // the four point groups meet on the VALU
-    if (lane < 16) {
+            for (int k = 0; k < 8; ++k) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[t][k]) : "a"(acc[t][8 * rh + k]));
 #pragma unroll
-        for (int k = 0; k < 16; ++k) out[16 * k + f] = s[k];
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { SNR_DPP_SELF(v[t][k], "row_mirror", "0x3"); SNR_DPP_FROM(v[t][k], v[t + 4][k], "row_mirror", "0xc"); }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { SNR_DPP_SELF(v[t][k], "row_half_mirror", "0x5"); SNR_DPP_FROM(v[t][k], v[t + 2][k], "row_half_mirror", "0xa"); }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) SNR_DPP_SELF(v[t][k], "quad_perm:[1,0,3,2]", "0xf");
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) SNR_DPP_SELF(v[t][k], "quad_perm:[2,3,0,1]", "0xf");
+        float s[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(v[0][k]), "+v"(v[1][k]));
+            s[k] = v[0][k] + v[1][k];
+        }
+        if ((lane & 3) == 0) {
+            *reinterpret_cast<f32x4*>(out + 32 * tile + 8 * (2 * rh) + 4 * h) = f32x4{s[0], s[1], s[2], s[3]};
+            *reinterpret_cast<f32x4*>(out + 32 * tile + 8 * (2 * rh + 1) + 4 * h) = f32x4{s[4], s[5], s[6], s[7]};
+        }
     }
 }
 
@@ -596,7 +617,15 @@ struct BwdEpi {
     const float* wsig;    // LDS: density-head weights below enc_shape (a block of zeros otherwise)
     float dpre;           // d loss / d (pre-softplus density) of this lane's point
     float* dzl;           // LDS: where this wave parks the layer's latent-term gradient (256 floats), or null
+#ifdef SNR_STAMPS
+    unsigned long long* st;   // diagnostics: this wave tile's stamp row (lane 0 of live tiles), or null
+#endif
 };
+#ifdef SNR_STAMPS
+#define SNR_LSTAMP(c, i) do { if ((c).st) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); (c).st[i] = t_; } } while (0)
+#else
+#define SNR_LSTAMP(c, i) do {} while (0)
+#endif
 template <int T, int HALF, int JJ>
 __device__ __forceinline__ void bwd_quarter(const f32x16& acc, XOp& out, const BwdEpi& c, const f32x4& wv, int lane) {
     const int j = 2 * HALF + JJ;
@@ -630,7 +659,8 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
     constexpr int step_bytes = NT * 2 * 1024;
     constexpr bool TAIL = (NT != 8);                        // enc_xyz^T: the stream ends with this layer
     constexpr int NCH = 16 / SPC;
-    if (c.dzl) reduce_tiles_lds(accP, c.dzl, reinterpret_cast<float*>(lds + OFF_XDIR) + (threadIdx.x >> 6) * 1024, lane);
+    if (c.dzl) reduce_tiles_dpp(accP, c.dzl, lane);
+    if (NT == 2) SNR_LSTAMP(c, 10);
     acc_zero<NT, 8>(accC);
     bwd_half_tile<0, 0>(accP[0], x[0], c, h, lane);
     Frags<NTH> fa, fb;
@@ -661,6 +691,7 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
     SNR_BSTEP(0) SNR_BSTEP(1) SNR_BSTEP(2) SNR_BSTEP(3) SNR_BSTEP(4) SNR_BSTEP(5) SNR_BSTEP(6) SNR_BSTEP(7)
+    if (NT == 2) SNR_LSTAMP(c, 15);
     SNR_BSTEP(8) SNR_BSTEP(9) SNR_BSTEP(10) SNR_BSTEP(11) SNR_BSTEP(12) SNR_BSTEP(13) SNR_BSTEP(14) SNR_BSTEP(15)
 #undef SNR_BSTEP
     if (NT == 8 && ninth) {
@@ -827,6 +858,9 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
         c.dpre = (l == li_encshape) ? dpre : 0.f;
         const int la = latent_after(l, sb, tb);
         c.dzl = (la >= 0 && io.partial) ? reinterpret_cast<float*>(lds + OFF_LAT) + (wave * MAX_LAT + la) * 256 : nullptr;
+#ifdef SNR_STAMPS
+        c.st = (io.d_t && lane == 0 && tile32 * 32 < io.n_points) ? reinterpret_cast<unsigned long long*>(io.d_t) + tile32 * 16 : nullptr;
+#endif
         return c;
     };
     int li = li_last;

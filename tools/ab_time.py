@@ -48,7 +48,7 @@ def setup(name):
     f0 = lambda: lib.snr_render_fwd(C.byref(a), rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), None, None, None, st())
     f1 = lambda: lib.snr_render_fwd(C.byref(a), rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), sig.data_ptr(), rgbs.data_ptr(), masks.data_ptr(), st())
     b = lambda: lib.snr_render_bwd(C.byref(a), sig.data_ptr(), rgbs.data_ptr(), masks.data_ptr(), d_rgb.data_ptr(), d_depth.data_ptr(), d_acc.data_ptr(),
-                                   d_lat.data_ptr(), d_o.data_ptr(), d_d.data_ptr(), None, ws.data_ptr(), wsb, st())
+                                   (None if os.environ.get('SNR_AB_NOLAT') else d_lat.data_ptr()), d_o.data_ptr(), d_d.data_ptr(), None, ws.data_ptr(), wsb, st())
     assert f1() == 0 and b() == 0
     good.snr_render_fwd(C.byref(a32), rgb32.data_ptr(), depth32.data_ptr(), acc32.data_ptr(), None, None, None, st())
     f0(); torch.cuda.synchronize()

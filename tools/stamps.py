@@ -80,12 +80,12 @@ for _ in range(3):
     assert rc == 0, rc
 torch.cuda.synchronize()
 tb = dbg2.cpu().numpy().view(np.uint64).reshape(-1, 16)[: N * S // 32].astype(np.int64)
-bn = ["start", "composite bwd", "colour head", "rgb0^T"] + [f"layer {6 - i}^T done" for i in range(6)] + ["", "(layers done)", "enc_xyz^T", "PE bwd", "end"]
+bn = ["start", "composite bwd", "colour head", "rgb0^T"] + [f"layer {6 - i}^T done" for i in range(6)] + ["[enc_xyz^T: latent reduce done]", "(layers done)", "enc_xyz^T", "PE bwd", "end", "[enc_xyz^T: 8 of 16 steps]"]
 db = tb - tb[:, :1]
 print("backward, cycles from kernel start (median over %d wave tiles):" % len(tb))
 prev = 0
-for i, nme in enumerate(bn):
+for i, nme in sorted(enumerate(bn), key=lambda t: float(np.median(db[:, t[0]]))):      # in time order (stamps 10 and 15 sit inside enc_xyz^T)
     if not nme or not tb[:, i].any(): continue
     m = float(np.median(db[:, i]))
-    print(f"  {nme:16s} {m:10.0f}  (+{m - prev:8.0f})")
+    print(f"  {nme:32s} {m:10.0f}  (+{m - prev:8.0f})")
     prev = m
