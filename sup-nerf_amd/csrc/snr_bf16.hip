@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(256, 1)
 bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom g,
                 float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_acc) {
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6) /* SGPR: so is all that derives from it */, p = lane & 31, h = lane >> 5;
     const long long tile128 = blockIdx.x;
     const long long tile32 = tile128 * 4 + wave;
     const long long gp_raw = tile128 * 128 + wave * 32 + p;
@@ -459,6 +459,9 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         return c;
     };
     const bool tile_live = tile32 * 32 < io.n_points;     // the last workgroup may own wave tiles past the end: they store nothing
+    // lane id recomputed where it is needed again late (density / colour heads, composite, stores): values derived from the early
+    // `lane` would have to stay in VGPRs across the whole layer chain, and the allocator spills them
+    auto fresh_lane = [&]() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t & 63; };
     auto store_mask = [&](int l) {   // ReLU bits of layer l (complete once the next layer has consumed all its tiles)
         if (MASKS && tile_live && l != li_encshape)
             io.masks[(tile32 * n_relu + relu_slot(l, sb)) * 64 + lane] =
@@ -469,18 +472,18 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     for (; li + 1 <= li_last; li += 2) {
         layer_fwd<8, MASKS>(accA, accB, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
         store_mask(li - 1);
-        if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_SIGW, h);
+        if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_SIGW, fresh_lane() >> 5);
         SNR_STAMP(3 + li);
         layer_fwd<8, MASKS>(accB, accA, x, xdir, ring, lds, epi_of(li), li + 1 == li_view, mask, tid, lane);
         store_mask(li);
-        if (li + 1 == li_encshape) sig_dot = sigma_partial(accA, vec + VEC_SIGW, h);
+        if (li + 1 == li_encshape) sig_dot = sigma_partial(accA, vec + VEC_SIGW, fresh_lane() >> 5);
         SNR_STAMP(4 + li);
     }
     const bool odd_tail = (li == li_last);
     if (odd_tail) {
         layer_fwd<8, MASKS>(accA, accB, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
         store_mask(li - 1);
-        if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_SIGW, h);
+        if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_SIGW, fresh_lane() >> 5);
     }
     // ---- rgb.0: 256 -> 128 (4 tiles) from the last 256-wide layer's accumulators
     if (odd_tail) layer_fwd<4, MASKS>(accB, accA, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
@@ -488,6 +491,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     store_mask(li_last);
     SNR_STAMP(12);
 
+    const int lane_t = fresh_lane(), p_t = lane_t & 31, h_t = lane_t >> 5;
     // density head (enc_shape's output dotted with w_sigma inside the epilogues)
     const float pre = sum_halves(sig_dot) + vec[VEC_MISC + 0];
     const float o_sigma = pre > 20.f ? pre : log1pf(expf(pre));
@@ -501,7 +505,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n0 = 32 * t + 8 * j + 4 * h;
+                const int n0 = 32 * t + 8 * j + 4 * h_t;
                 const f32x4 wr = *reinterpret_cast<const f32x4*>(w2 + n0);
                 const f32x4 wg = *reinterpret_cast<const f32x4*>(w2 + 128 + n0);
                 const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + n0);
@@ -513,7 +517,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
                     pr = fmaf(wr[e], v, pr); pg = fmaf(wg[e], v, pg); pb = fmaf(wb[e], v, pb);
                 }
             }
-        if (MASKS && tile_live) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mk[0], mk[1], 0u, 0u);
+        if (MASKS && tile_live) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane_t] = make_uint4(mk[0], mk[1], 0u, 0u);
     }
     const float cr = sum_halves(pr) + vec[VEC_MISC + 4];
     const float cg = sum_halves(pg) + vec[VEC_MISC + 5];
@@ -521,15 +525,18 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
 
     SNR_STAMP(13);
 #ifndef SNR_STAMPS
-    if (live && lane < 32) {
-        if (io.sigmas) io.sigmas[gp] = o_sigma;
-        if (io.rgbs) { io.rgbs[gp * 3] = cr; io.rgbs[gp * 3 + 1] = cg; io.rgbs[gp * 3 + 2] = cb; }
+    {   // (the point index again, from the fresh lane id)
+        const long long gp_e = tile128 * 128 + wave * 32 + p_t;
+        if (gp_e < io.n_points && lane_t < 32) {
+            if (io.sigmas) io.sigmas[gp_e] = o_sigma;
+            if (io.rgbs) { io.rgbs[gp_e * 3] = cr; io.rgbs[gp_e * 3 + 1] = cg; io.rgbs[gp_e * 3 + 2] = cb; }
+        }
     }
 #endif
     if (MODE == 1) {
         float* comp = reinterpret_cast<float*>(lds + OFF_COMP);
-        if (lane < 32) {
-            float* c = comp + (wave * 32 + p) * COMP_STRIDE;
+        if (lane_t < 32) {
+            float* c = comp + (wave * 32 + p_t) * COMP_STRIDE;
             c[0] = o_sigma; c[1] = cr; c[2] = cg; c[3] = cb;      // c[4] = composite depth, parked there at the start
         }
         __syncthreads();
@@ -540,12 +547,12 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
             const long long ray = tile128 * rays_here + r;
             if (ray >= g.n_rays) break;
             const float* c0 = comp + r * S * COMP_STRIDE;
-            RayOut o = composite_ray_fwd(S, lane, white, [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
+            RayOut o = composite_ray_fwd(S, lane_t, white, [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
                 const float* c = c0 + k * COMP_STRIDE;
                 s_ = c[0]; r_ = c[1]; g_ = c[2]; b_ = c[3]; z_ = c[4];
                 zn_ = (k < S - 1) ? c[COMP_STRIDE + 4] : 0.f;
             });
-            if (lane == 0) {
+            if (lane_t == 0) {
                 out_rgb[ray * 3] = o.r; out_rgb[ray * 3 + 1] = o.g; out_rgb[ray * 3 + 2] = o.b;
                 out_depth[ray] = o.depth; out_acc[ray] = o.acc;
             }
