@@ -144,6 +144,16 @@ __device__ __forceinline__ void load_frags(Frags<NTH>& f, const char* ws) {
         f.lo[t] = *reinterpret_cast<const bf16x8*>(ws + (2 * (T0 + t) + 1) * 1024);
     }
 }
+// the same, the finished sums going to `out` (the last operand step of a layer: see layer_fwd)
+template <int NTH, int T0, int NA>
+__device__ __forceinline__ void mma_half_to(f32x16 (&out)[NA], const f32x16 (&acc)[NA], const XOp& x, const Frags<NTH>& f) {
+#pragma unroll
+    for (int t = 0; t < NTH; ++t) {
+        f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.hi[t], x.hi, acc[T0 + t], 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.hi[t], x.lo, a, 0, 0, 0);
+        out[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.lo[t], x.hi, a, 0, 0, 0);
+    }
+}
 template <int NTH, int T0, int NA>
 __device__ __forceinline__ void mma_half(f32x16 (&acc)[NA], const XOp& x, const Frags<NTH>& f) {
 #pragma unroll
@@ -272,13 +282,18 @@ __device__ __forceinline__ float sigma_partial(const f32x16 (&acc)[8], const flo
     }
 #define SNR_INTERLEAVE(N_MFMA) SNR_INTERLEAVE_(N_MFMA, SNR_IL_DS, SNR_IL_VALU)
 #define SNR_INTERLEAVE_B(N_MFMA) SNR_INTERLEAVE_(N_MFMA, SNR_ILB_DS, SNR_ILB_VALU)
-// One layer with 16 operand steps taken from accP (+ 2 direction steps for enc_viewdir), NT output tiles into accC.
+// One layer with 16 operand steps taken from acc (+ 2 direction steps for enc_viewdir), NT output tiles back into acc: the sums
+// build up in a second, local accumulator set; the previous layer's set is dead once its last quarter has become operand step 15
+// (during step 14), so the MFMAs of step 15 deposit the finished tiles there (vdst != srcC).  One code instance therefore serves
+// every layer of the chain (no A->B / B->A pair, no odd/even tails): the bf16x3 kernels are half the size they were, which
+// matters with a 64 KiB instruction cache shared by two CUs.
 // Each step is two half-steps of NT/2 tiles.  The A fragments of a half-step are fetched from LDS while the previous
 // half-step's MFMAs run (two fragment buffers), the next chunk is acquired half a step before it is needed, and the
 // previous layer's epilogue for operand step S+1 is split over the two half-steps of step S.
 template <int NT, bool MASKS>
-__device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], XOp (&x)[16], const char* xdir_lds, Ring& ring, char* lds,
+__device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], XOp (&x)[16], const char* xdir_lds, Ring& ring, char* lds,
                                           const FwdEpi& c, bool extra, uint32_t (&mask)[4], int tid, int lane) {
+    f32x16 accC[8];
     const int h = lane >> 5;
     const unsigned voff = lane * 16u + 4096u;         // DMA source offset of this lane inside the wave's slice (+ 4096, see ring_piece)
     constexpr int NTH = NT / 2;
@@ -303,14 +318,14 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
             fwd_quarter_load<(((S) + 1) >> 1), (((S) + 1) & 1), 0>(v0, c, h);                                          \
             fwd_quarter_load<(((S) + 1) >> 1), (((S) + 1) & 1), 1>(v1, c, h);                                          \
         }                                                                                                              \
-        mma_half<NTH, 0, 8>(accC, x[S], fa);                                                                           \
+        if constexpr ((S) == 15) mma_half_to<NTH, 0, 8>(accP, accC, x[S], fa); else mma_half<NTH, 0, 8>(accC, x[S], fa);       \
         ring_pieces_in<(2 * (S) + 1) % (2 * SPC), SPC, (2 * (S) + 1) / (2 * SPC), NCH, TAIL>(ring, voff);              \
         if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0, MASKS>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v0, mask); \
         SNR_INTERLEAVE(3 * NTH)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + STEP_BYTES);                                   \
         else if constexpr ((S) + 1 < 16) { w = ring_acquire<TAIL && ((S) + 1) / SPC == NCH - 1>(ring, lds) + lane * 16; load_frags<NTH, 0>(fa, w); } \
-        mma_half<NTH, NTH, 8>(accC, x[S], fb);                                                                         \
+        if constexpr ((S) == 15) mma_half_to<NTH, NTH, 8>(accP, accC, x[S], fb); else mma_half<NTH, NTH, 8>(accC, x[S], fb);   \
         if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0)                                                \
             ring_pieces_in<(2 * (S) + 2) % (2 * SPC), SPC, (2 * (S) + 2) / (2 * SPC), NCH, TAIL>(ring, voff);          \
         if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1, MASKS>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v1, mask); \
@@ -326,8 +341,8 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
         XOp d0, d1;
         d0.hi = *reinterpret_cast<const bf16x8*>(xdir_lds);        d0.lo = *reinterpret_cast<const bf16x8*>(xdir_lds + 1024);
         d1.hi = *reinterpret_cast<const bf16x8*>(xdir_lds + 2048); d1.lo = *reinterpret_cast<const bf16x8*>(xdir_lds + 3072);
-        step_mma<NT, 8>(accC, d0, w);
-        step_mma<NT, 8>(accC, d1, w + STEP_BYTES);
+        step_mma<NT, 8>(accP, d0, w);
+        step_mma<NT, 8>(accP, d1, w + STEP_BYTES);
     }
 }
 
@@ -428,7 +443,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         }
     }
 
-    f32x16 accA[8], accB[8];
+    f32x16 accA[8];
     uint32_t mask[4];
     float sig_dot = 0.f;
     SNR_STAMP(2);
@@ -467,27 +482,15 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
             io.masks[(tile32 * n_relu + relu_slot(l, sb)) * 64 + lane] =
                 make_uint4(~__builtin_bitreverse32(mask[0]), ~__builtin_bitreverse32(mask[1]), ~__builtin_bitreverse32(mask[2]), ~__builtin_bitreverse32(mask[3]));
     };
-    int li = 1;
 #pragma unroll 1
-    for (; li + 1 <= li_last; li += 2) {
-        layer_fwd<8, MASKS>(accA, accB, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
+    for (int li = 1; li <= li_last; ++li) {
+        layer_fwd<8, MASKS>(accA, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
         store_mask(li - 1);
-        if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_SIGW, fresh_lane() >> 5);
+        if (li == li_encshape) sig_dot = sigma_partial(accA, vec + VEC_SIGW, fresh_lane() >> 5);
         SNR_STAMP(3 + li);
-        layer_fwd<8, MASKS>(accB, accA, x, xdir, ring, lds, epi_of(li), li + 1 == li_view, mask, tid, lane);
-        store_mask(li);
-        if (li + 1 == li_encshape) sig_dot = sigma_partial(accA, vec + VEC_SIGW, fresh_lane() >> 5);
-        SNR_STAMP(4 + li);
-    }
-    const bool odd_tail = (li == li_last);
-    if (odd_tail) {
-        layer_fwd<8, MASKS>(accA, accB, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
-        store_mask(li - 1);
-        if (li == li_encshape) sig_dot = sigma_partial(accB, vec + VEC_SIGW, fresh_lane() >> 5);
     }
     // ---- rgb.0: 256 -> 128 (4 tiles) from the last 256-wide layer's accumulators
-    if (odd_tail) layer_fwd<4, MASKS>(accB, accA, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
-    else          layer_fwd<4, MASKS>(accA, accB, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
+    layer_fwd<4, MASKS>(accA, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
     store_mask(li_last);
     SNR_STAMP(12);
 
@@ -511,7 +514,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
                 const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + n0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = odd_tail ? accA[t][4 * j + e] : accB[t][4 * j + e];
+                    float v = accA[t][4 * j + e];
                     if (MASKS && v > 0.f) mk[t >> 1] |= 1u << ((t & 1) * 16 + 4 * j + e);
                     v = fmaxf(v, 0.f);
                     pr = fmaf(wr[e], v, pr); pg = fmaf(wg[e], v, pg); pb = fmaf(wb[e], v, pb);
