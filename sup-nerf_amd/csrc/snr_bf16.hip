@@ -590,7 +590,7 @@ __device__ __forceinline__ void reduce_tiles_dpp(const f32x16 (&acc)[8], float* 
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[t][k]) : "a"(acc[t][8 * rh + k]));
+            for (int k = 0; k < 8; ++k) { v[t][k] = acc[t][8 * rh + k]; asm volatile("" : "+v"(v[t][k])); }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -656,12 +656,14 @@ __device__ __forceinline__ void bwd_half_tile(const f32x16& acc, XOp& out, const
     bwd_quarter<T, HALF, 1>(acc, out, c, w1, lane);
 }
 
-// One transposed layer: 16 operand steps from accP, NT output tiles into accC; same half-step pipeline as layer_fwd.  With
+// One transposed layer: 16 operand steps from acc, NT output tiles back into acc (one code instance for the whole chain, like
+// layer_fwd); same half-step pipeline.  With
 // `ninth` (enc_viewdir^T) a ninth output tile, the gradient of the 32 direction features, follows from one more chunk: its 16
 // steps x (hi, lo) KiB are packed behind the layer's 8 regular chunks and multiply the operand steps still held in x.
 template <int NT>
-__device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], f32x16& acc9, XOp (&x)[16], Ring& ring, char* lds,
+__device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16& acc9, XOp (&x)[16], Ring& ring, char* lds,
                                           const BwdEpi& c, bool ninth, int tid, int lane) {
+    f32x16 accC[8];
     const int h = lane >> 5;
     const unsigned voff = lane * 16u + 4096u;
     constexpr int NTH = NT / 2;
@@ -686,14 +688,14 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16 (&accC)[8], 
             w0 = *reinterpret_cast<const f32x4*>(c.wsig + 32 * (((S) + 1) >> 1) + 8 * (2 * (((S) + 1) & 1)) + 4 * h);     \
             w1 = *reinterpret_cast<const f32x4*>(c.wsig + 32 * (((S) + 1) >> 1) + 8 * (2 * (((S) + 1) & 1) + 1) + 4 * h); \
         }                                                                                                              \
-        mma_half<NTH, 0, 8>(accC, x[S], fa);                                                                           \
+        if constexpr ((S) == 15) mma_half_to<NTH, 0, 8>(accP, accC, x[S], fa); else mma_half<NTH, 0, 8>(accC, x[S], fa);       \
         ring_pieces_in<(2 * (S) + 1) % (2 * SPC), SPC, (2 * (S) + 1) / (2 * SPC), NCH, TAIL>(ring, voff);              \
         if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, w0, lane); \
         SNR_INTERLEAVE_B(3 * NTH)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + step_bytes);                                   \
         else if constexpr ((S) + 1 < 16) { w = ring_acquire<TAIL && ((S) + 1) / SPC == NCH - 1>(ring, lds) + lane * 16; load_frags<NTH, 0>(fa, w); } \
-        mma_half<NTH, NTH, 8>(accC, x[S], fb);                                                                         \
+        if constexpr ((S) == 15) mma_half_to<NTH, NTH, 8>(accP, accC, x[S], fb); else mma_half<NTH, NTH, 8>(accC, x[S], fb);   \
         if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0)                                                \
             ring_pieces_in<(2 * (S) + 2) % (2 * SPC), SPC, (2 * (S) + 2) / (2 * SPC), NCH, TAIL>(ring, voff);          \
         if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, w1, lane); \
@@ -845,7 +847,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
             }
     }
 
-    f32x16 accA[8], accB[8], acc9;
+    f32x16 accA[8], acc9;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc9[r] = 0.f;
     SNR_BSTAMP(2);
@@ -873,21 +875,15 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
 #endif
         return c;
     };
-    int li = li_last;
     SNR_BSTAMP(3);
 #pragma unroll 1
-    for (; li - 1 >= 1; li -= 2) {
-        layer_bwd<8>(accA, accB, acc9, x, ring, lds, epi_of(li), li == li_view, tid, lane);
+    for (int li = li_last; li >= 1; --li) {
+        layer_bwd<8>(accA, acc9, x, ring, lds, epi_of(li), li == li_view, tid, lane);
         SNR_BSTAMP(4 + li_last - li);
-        layer_bwd<8>(accB, accA, acc9, x, ring, lds, epi_of(li - 1), li - 1 == li_view, tid, lane);
-        SNR_BSTAMP(5 + li_last - li);
     }
-    const bool odd_tail = (li == 1);
-    if (odd_tail) layer_bwd<8>(accA, accB, acc9, x, ring, lds, epi_of(1), 1 == li_view, tid, lane);
     SNR_BSTAMP(11);
     // ---- enc_xyz^T : 256 -> 64 positional-encoding features (two tiles, fp32)
-    if (odd_tail) layer_bwd<2>(accB, accA, acc9, x, ring, lds, epi_of(0), false, tid, lane);
-    else          layer_bwd<2>(accA, accB, acc9, x, ring, lds, epi_of(0), false, tid, lane);
+    layer_bwd<2>(accA, acc9, x, ring, lds, epi_of(0), false, tid, lane);
 
     SNR_BSTAMP(12);
     // ---- the parked latent-term gradients of this wave tile -> global partials (the ring is idle now)
@@ -902,8 +898,8 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     float* sc = reinterpret_cast<float*>(lds + OFF_PE) + (wave * 32 + p) * PE_ROWF;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        sc[8 * (r >> 2) + 4 * h + (r & 3)] = odd_tail ? accA[0][r] : accB[0][r];
-        sc[32 + 8 * (r >> 2) + 4 * h + (r & 3)] = odd_tail ? accA[1][r] : accB[1][r];
+        sc[8 * (r >> 2) + 4 * h + (r & 3)] = accA[0][r];
+        sc[32 + 8 * (r >> 2) + 4 * h + (r & 3)] = accA[1][r];
     }
     float gx = 0.f, gy = 0.f, gz = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
 #pragma unroll 1
