@@ -108,7 +108,11 @@ __device__ __forceinline__ const char* ring_acquire(Ring& r, char* lds) {
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #endif
+#ifdef SNR_EXP_SAMECHUNK      /* timing experiment: every fetch re-reads the stream's last chunk (L2-hot) */
+    const char* nx = r.last;
+#else
     const char* nx = r.next < r.last ? r.next : r.last;
+#endif
     r.pg = nx + r.wave_lds;
     r.pm0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds) + r.fill * WB_BYTES + r.wave_lds + 4096u;
     r.next = nx + BF_CHUNK;
