@@ -264,13 +264,13 @@ __device__ __forceinline__ float sigma_partial(const f32x16 (&acc)[8], const flo
 
 // interleave request for one half-step region: after every MFMA one LDS read (while there are any) and a few VALU ops, so the
 // fragment fetches for the next half-step and the previous layer's epilogue are spread under the MFMAs instead of in blocks.
-// Measured (tools/ab_time.py, interleaved rounds): forward, ~26 epilogue ops per 12 MFMAs: 2 VALU per MFMA and no read request is best (-4 % against
-// 4 VALU, -2 % against no request at all); backward, ~34 ops per 12 MFMAs: 3 VALU and no read request (-1 % against 4).
+// Measured (tools/ab_time.py, interleaved rounds): forward: 2-3 VALU per MFMA and no read request is best (-4 % against 4 VALU, -2 % against no request
+// at all; 3 since the one-instance layer moved the accumulator reads out of the epilogue); backward, ~34 ops per 12 MFMAs: 3 VALU and no read request (-1 % against 4).
 #ifndef SNR_IL_DS
 #define SNR_IL_DS 0
 #endif
 #ifndef SNR_IL_VALU
-#define SNR_IL_VALU 2
+#define SNR_IL_VALU 3
 #endif
 #ifndef SNR_ILB_DS
 #define SNR_ILB_DS 0
