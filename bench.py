@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_RAY = 57.56e6          # forward, S = 64
 # HBM bytes per 4096x64 forward launch from the committed counter profile (cannot be collected from inside this process)
-HBM_TRAFFIC = {"bf16x3": 16073728.0, "fp32": None}
+HBM_TRAFFIC = {"bf16x3": 16067584.0, "fp32": None}
 PEAK_TFLOPS = {"fp32": 157.3,    # MI355X_MICROARCH.md "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f32
                "bf16x3": 2500.0}  # dense BF16 MFMA peak; the split-bf16 path issues 3 MFMAs per algorithmic product
 N_RAYS, N_SAMPLES, IM_SZ = 4096, 64, 64
@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline launches (no other-precision / forward+backward / optimise-loop / HBM-kernel legs): the form "
+                         "profiled for profiles/*_bench_kernel_stats.csv, so the per-kernel average there is the headline kernel alone")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
                     help="decoder GEMM arithmetic of the headline run (the other mode is timed too and reported under 'extra')")
     args = ap.parse_args()
@@ -130,114 +133,116 @@ def main():
     torch.cuda.synchronize()
     kern_ms = e0.elapsed_time(e1) / args.steps
     achieved = N_RAYS * FLOP_PER_RAY / (kern_ms * 1e-3) / 1e12
-    # the other arithmetic mode, same launches (reported, not the headline)
-    for _ in range(5):
-        step(cfg_other)
-    torch.cuda.synchronize()
-    e0.record()
-    n_other = max(10, args.steps // 4)
-    for _ in range(n_other):
-        out_other = step(cfg_other)
-    e1.record()
-    torch.cuda.synchronize()
-    other_ms = e0.elapsed_time(e1) / n_other
-    other_tf = N_RAYS * FLOP_PER_RAY / (other_ms * 1e-3) / 1e12
-
-    # ---- forward + backward leg (the optimiser's inner iteration: gradients wrt codes and pose)
-    sc_g, tc_g = w["sc"].clone().requires_grad_(), w["tc"].clone().requires_grad_()
-    pose_g = ob["cam_pose"].to(dev).requires_grad_()
-    tgt = w["img"].reshape(-1, 3).to(dev)
-
-    def step_fb():
-        ro, vd = U.get_rays(ob["K"], pose_g, ob["roi"], uv_steps=[IM_SZ, IM_SZ])
-        rgb, depth, acc = model.fused_render(ro, vd, z, div, None, sc_g, tc_g, cfg)
-        loss = ((rgb - tgt) ** 2).mean() + 0.1 * acc.mean()
-        sc_g.grad = tc_g.grad = pose_g.grad = None
-        loss.backward()
-
-    for _ in range(3):
-        step_fb()
-    barrier()
-    n_fb = max(10, args.steps // 4)
-    t0 = time.perf_counter()
-    for _ in range(n_fb):
-        step_fb()
-    barrier()
-    fb_elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([fb_elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        fb_elapsed = float(t.item())
-    fwd_bwd_rays = world * N_RAYS * n_fb / fb_elapsed
-
-    # ---- BASELINE config 3 in one process: the optimise loop over 64 objects, all of them in one launch per iteration
-    loop = {}
-    if rank == 0:
-        from supnerf_amd import driver as D
-        hp = D.load_hpams()
-        hp["render_im_sz"] = IM_SZ
-        n_obj, n_it = 64, 4
-        hp["optimize"]["num_opts"] = n_it
-        objs = D.make_objects(list(range(200, 200 + n_obj)), IM_SZ)
-        gl = torch.Generator().manual_seed(3)
-        sc_l, tc_l = torch.randn(n_obj, 256, generator=gl) * 0.3, torch.randn(n_obj, 256, generator=gl) * 0.3
-        D.optimize_objects_batched(model, dev, objs[:8], hp, sc_l[:8], tc_l[:8], list(range(8)))          # warm-up
+    other_ms, other_tf, fwd_bwd_rays, fb_elapsed, n_fb, loop, hbm = None, None, None, None, 1, {}, {}
+    if not args.headline_only:
+        # the other arithmetic mode, same launches (reported, not the headline)
+        for _ in range(5):
+            step(cfg_other)
         torch.cuda.synchronize()
+        e0.record()
+        n_other = max(10, args.steps // 4)
+        for _ in range(n_other):
+            out_other = step(cfg_other)
+        e1.record()
+        torch.cuda.synchronize()
+        other_ms = e0.elapsed_time(e1) / n_other
+        other_tf = N_RAYS * FLOP_PER_RAY / (other_ms * 1e-3) / 1e12
+
+        # ---- forward + backward leg (the optimiser's inner iteration: gradients wrt codes and pose)
+        sc_g, tc_g = w["sc"].clone().requires_grad_(), w["tc"].clone().requires_grad_()
+        pose_g = ob["cam_pose"].to(dev).requires_grad_()
+        tgt = w["img"].reshape(-1, 3).to(dev)
+
+        def step_fb():
+            ro, vd = U.get_rays(ob["K"], pose_g, ob["roi"], uv_steps=[IM_SZ, IM_SZ])
+            rgb, depth, acc = model.fused_render(ro, vd, z, div, None, sc_g, tc_g, cfg)
+            loss = ((rgb - tgt) ** 2).mean() + 0.1 * acc.mean()
+            sc_g.grad = tc_g.grad = pose_g.grad = None
+            loss.backward()
+
+        for _ in range(3):
+            step_fb()
+        barrier()
+        n_fb = max(10, args.steps // 4)
         t0 = time.perf_counter()
-        D.optimize_objects_batched(model, dev, objs, hp, sc_l, tc_l, list(range(n_obj)))
-        torch.cuda.synchronize()
-        t_b = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        D.optimize_object(model, dev, objs[0], hp, sc_l[:1], tc_l[:1], seed=0)
-        torch.cuda.synchronize()
-        t_1 = time.perf_counter() - t0
-        loop = {"objects": n_obj, "iterations": n_it, "rays_per_object": N_RAYS,
-                "batched_ms_per_iteration": t_b / n_it * 1e3, "batched_object_iterations_per_s": n_obj * n_it / t_b,
-                "batched_rays_per_s_fwd_bwd_plus_depth_render": n_obj * n_it * N_RAYS / t_b,
-                "one_object_loop_ms_per_iteration": t_1 / n_it * 1e3, "one_object_loop_object_iterations_per_s": n_it / t_1,
-                "note": "iteration = fused forward + backward (codes, pose) + 64-pixel depth render + AdamW; the batched loop runs all objects "
-                        "in one launch each and never syncs with the host; the one-object loop is the reference's structure (setup included in both)"}
-        del objs
+        for _ in range(n_fb):
+            step_fb()
+        barrier()
+        fb_elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([fb_elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fb_elapsed = float(t.item())
+        fwd_bwd_rays = world * N_RAYS * n_fb / fb_elapsed
 
-    # ---- the two HBM-bound stand-alone kernels (encode with PE output, composite) at 16 objects x 4096 x 64: achieved GB/s
-    hbm = {}
-    if rank == 0:
-        Bh = 64
-        ro_h, vd_h = rays_o.repeat(Bh, 1), viewdir.repeat(Bh, 1)
-        z_h = z[None].repeat(Bh, 1).contiguous()
-        div_h = div.repeat(Bh)
-        cfg_h = ops.RenderCfg(N_SAMPLES, ops.Z_PER_OBJECT, N_RAYS, 3, 1, frame=U._frame(False, False, True))
-        P_h = Bh * N_RAYS * N_SAMPLES
+        # ---- BASELINE config 3 in one process: the optimise loop over 64 objects, all of them in one launch per iteration
+        loop = {}
+        if rank == 0:
+            from supnerf_amd import driver as D
+            hp = D.load_hpams()
+            hp["render_im_sz"] = IM_SZ
+            n_obj, n_it = 64, 4
+            hp["optimize"]["num_opts"] = n_it
+            objs = D.make_objects(list(range(200, 200 + n_obj)), IM_SZ)
+            gl = torch.Generator().manual_seed(3)
+            sc_l, tc_l = torch.randn(n_obj, 256, generator=gl) * 0.3, torch.randn(n_obj, 256, generator=gl) * 0.3
+            D.optimize_objects_batched(model, dev, objs[:8], hp, sc_l[:8], tc_l[:8], list(range(8)))          # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            D.optimize_objects_batched(model, dev, objs, hp, sc_l, tc_l, list(range(n_obj)))
+            torch.cuda.synchronize()
+            t_b = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            D.optimize_object(model, dev, objs[0], hp, sc_l[:1], tc_l[:1], seed=0)
+            torch.cuda.synchronize()
+            t_1 = time.perf_counter() - t0
+            loop = {"objects": n_obj, "iterations": n_it, "rays_per_object": N_RAYS,
+                    "batched_ms_per_iteration": t_b / n_it * 1e3, "batched_object_iterations_per_s": n_obj * n_it / t_b,
+                    "batched_rays_per_s_fwd_bwd_plus_depth_render": n_obj * n_it * N_RAYS / t_b,
+                    "one_object_loop_ms_per_iteration": t_1 / n_it * 1e3, "one_object_loop_object_iterations_per_s": n_it / t_1,
+                    "note": "iteration = fused forward + backward (codes, pose) + 64-pixel depth render + AdamW; the batched loop runs all objects "
+                            "in one launch each and never syncs with the host; the one-object loop is the reference's structure (setup included in both)"}
+            del objs
 
-        def timed(fn, n=10):
-            for _ in range(2):
-                fn()
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(n):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / n * 1e-3
-        t_enc = timed(lambda: ops.encode(ro_h, vd_h, z_h, div_h, None, cfg_h, want_pe=True))
-        enc_bytes = P_h * (12 + 12 + 4 + 63 * 4) + Bh * N_RAYS * (24 + 27 * 4)          # xyz, viewdir, z, PE(xyz) per point; rays in, PE(dir) out
-        sig_h = torch.rand(Bh * N_RAYS, N_SAMPLES, device=dev)
-        rgb_h = torch.rand(Bh * N_RAYS, N_SAMPLES, 3, device=dev)
-        t_cmp = timed(lambda: ops.composite_fwd(sig_h, rgb_h, z_h, ops.Z_PER_OBJECT, False, N_RAYS))
-        cmp_bytes = P_h * 16 + Bh * N_RAYS * 20
-        # scene composite (vis_scene): 131072 pixels x 3 objects x 64 samples, depth merge + composite
-        P_s, n_s = 131072, 3 * N_SAMPLES
-        z_s = (torch.rand(P_s, 3, 1, device=dev) * 20 + 2 + torch.sort(torch.rand(P_s, 3, N_SAMPLES, device=dev), dim=-1)[0] * 4).view(P_s, n_s)
-        sig_s, rgb_s = torch.rand(P_s, n_s, device=dev), torch.rand(P_s, n_s, 3, device=dev)
-        t_scn = timed(lambda: ops.scene_composite(sig_s, rgb_s, z_s, True))
-        scn_bytes = P_s * n_s * 20 + P_s * 20
-        del z_s, sig_s, rgb_s
-        hbm = {"encode": {"GB_per_s": enc_bytes / t_enc / 1e9, "ms": t_enc * 1e3, "bytes": enc_bytes, "frac_of_8TBps": enc_bytes / t_enc / 8e12},
-               "scene_composite": {"GB_per_s": scn_bytes / t_scn / 1e9, "ms": t_scn * 1e3, "bytes": scn_bytes, "frac_of_8TBps": scn_bytes / t_scn / 8e12,
-                                   "shape": f"{P_s} pixels x 3 objects x {N_SAMPLES} samples"},
-               "composite_fwd": {"GB_per_s": cmp_bytes / t_cmp / 1e9, "ms": t_cmp * 1e3, "bytes": cmp_bytes, "frac_of_8TBps": cmp_bytes / t_cmp / 8e12},
-               "shape": f"{Bh} objects x {N_RAYS} rays x {N_SAMPLES} samples"}
-        del sig_h, rgb_h
+        # ---- the two HBM-bound stand-alone kernels (encode with PE output, composite) at 16 objects x 4096 x 64: achieved GB/s
+        hbm = {}
+        if rank == 0:
+            Bh = 64
+            ro_h, vd_h = rays_o.repeat(Bh, 1), viewdir.repeat(Bh, 1)
+            z_h = z[None].repeat(Bh, 1).contiguous()
+            div_h = div.repeat(Bh)
+            cfg_h = ops.RenderCfg(N_SAMPLES, ops.Z_PER_OBJECT, N_RAYS, 3, 1, frame=U._frame(False, False, True))
+            P_h = Bh * N_RAYS * N_SAMPLES
+
+            def timed(fn, n=10):
+                for _ in range(2):
+                    fn()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / n * 1e-3
+            t_enc = timed(lambda: ops.encode(ro_h, vd_h, z_h, div_h, None, cfg_h, want_pe=True))
+            enc_bytes = P_h * (12 + 12 + 4 + 63 * 4) + Bh * N_RAYS * (24 + 27 * 4)          # xyz, viewdir, z, PE(xyz) per point; rays in, PE(dir) out
+            sig_h = torch.rand(Bh * N_RAYS, N_SAMPLES, device=dev)
+            rgb_h = torch.rand(Bh * N_RAYS, N_SAMPLES, 3, device=dev)
+            t_cmp = timed(lambda: ops.composite_fwd(sig_h, rgb_h, z_h, ops.Z_PER_OBJECT, False, N_RAYS))
+            cmp_bytes = P_h * 16 + Bh * N_RAYS * 20
+            # scene composite (vis_scene): 131072 pixels x 3 objects x 64 samples, depth merge + composite
+            P_s, n_s = 131072, 3 * N_SAMPLES
+            z_s = (torch.rand(P_s, 3, 1, device=dev) * 20 + 2 + torch.sort(torch.rand(P_s, 3, N_SAMPLES, device=dev), dim=-1)[0] * 4).view(P_s, n_s)
+            sig_s, rgb_s = torch.rand(P_s, n_s, device=dev), torch.rand(P_s, n_s, 3, device=dev)
+            t_scn = timed(lambda: ops.scene_composite(sig_s, rgb_s, z_s, True))
+            scn_bytes = P_s * n_s * 20 + P_s * 20
+            del z_s, sig_s, rgb_s
+            hbm = {"encode": {"GB_per_s": enc_bytes / t_enc / 1e9, "ms": t_enc * 1e3, "bytes": enc_bytes, "frac_of_8TBps": enc_bytes / t_enc / 8e12},
+                   "scene_composite": {"GB_per_s": scn_bytes / t_scn / 1e9, "ms": t_scn * 1e3, "bytes": scn_bytes, "frac_of_8TBps": scn_bytes / t_scn / 8e12,
+                                       "shape": f"{P_s} pixels x 3 objects x {N_SAMPLES} samples"},
+                   "composite_fwd": {"GB_per_s": cmp_bytes / t_cmp / 1e9, "ms": t_cmp * 1e3, "bytes": cmp_bytes, "frac_of_8TBps": cmp_bytes / t_cmp / 8e12},
+                   "shape": f"{Bh} objects x {N_RAYS} rays x {N_SAMPLES} samples"}
+            del sig_h, rgb_h
 
     result = {
         "metric": "rays/sec at 4096 rays x 64 samples (fused render forward)",
@@ -250,14 +255,15 @@ def main():
                    "rays": N_RAYS, "samples": N_SAMPLES, "objects_per_gpu": 1, "sharding": "objects across ranks, no data-path collective"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                      "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": HBM_TRAFFIC.get(args.precision),
-                     "traffic_unit": "bytes per launch", "traffic_source": "profiles/r01_v5_fwd_pmc.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) "
+                     "traffic_unit": "bytes per launch", "traffic_source": "profiles/r01_v6_fwd_pmc.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) "
                                                                           "+ WRITE_SIZE in separate passes; 8 XCD L2s fetch the 1.74 MB weight stream once each",
                      "kernel": "bf16_fwd_kernel<1,false>" if args.precision == "bf16x3" else "decoder_fwd_kernel<1>",
                      "kernel_ms": kern_ms, "flop_per_launch": N_RAYS * FLOP_PER_RAY,
                      "note": "achieved = ALGORITHMIC flops (57.56 MFLOP/ray) / kernel time; bf16x3 issues 3x that on the bf16 MFMA pipe "
                              "(mfma_pipe_frac), fp32 issues 1x on the fp32 MFMA pipe",
                      "mfma_pipe_frac": (3.0 if args.precision == "bf16x3" else 1.0) * achieved / PEAK_TFLOPS[args.precision]},
-        "extra": {other + "_mode": {"rays_per_s": N_RAYS / (other_ms * 1e-3), "kernel_ms": other_ms, "achieved_tflops": other_tf,
+        "extra": None if args.headline_only else {
+                  other + "_mode": {"rays_per_s": N_RAYS / (other_ms * 1e-3), "kernel_ms": other_ms, "achieved_tflops": other_tf,
                                     "frac_of_peak": other_tf / PEAK_TFLOPS[other]},
                   "hbm_bound_kernels": hbm, "optimise_loop": loop,
                   "fwd_bwd_rays_per_s": fwd_bwd_rays, "fwd_bwd_ms_per_iter": fb_elapsed / n_fb * 1e3,

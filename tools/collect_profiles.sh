@@ -9,7 +9,7 @@ out=$repo/gpurun_out/prof_$tag
 raw=/tmp/prof_raw_$tag
 mkdir -p $out $raw
 # 1. the bench command itself: per-kernel durations must agree with bench.py's roofline.kernel_ms
-rocprofv3 --kernel-trace --stats --output-format csv -d $raw/bench -o bench -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/bench -o bench -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --headline-only > $out/bench.json 2> $out/bench.err
 # 2. the optimiser's inner iteration: forward with ReLU bits + backward
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/fwd_bwd -o fwd_bwd -- python3 tools/prof_fwd.py bf16x3 20 bwd > $out/fwd_bwd.log 2>&1
 # 3. counters of the dominant kernel, separate passes (no trace domains mixed in)
