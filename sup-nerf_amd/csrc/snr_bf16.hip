@@ -379,16 +379,28 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
 
     // ---- stage the small vectors and this wave's latent terms in LDS (plain loads, before any DMA is queued)
     {
-        const float* src = io.packed + L.bias;
-        for (int i = tid; i < L.n_mfma_layers * 256; i += 256) vec[VEC_BIAS + i] = src[i];
+        // 16-byte loads, all issued before the first wait (fixed trip counts): the dword loops with run-time bounds paid one global
+        // round trip per iteration
+        const f32x4* src4 = reinterpret_cast<const f32x4*>(io.packed + L.bias);
+        f32x4* dst4 = reinterpret_cast<f32x4*>(vec + VEC_BIAS);
+        const int n4 = L.n_mfma_layers * 64;
+        f32x4 bv[MAX_LAYERS * 64 / 256];
+#pragma unroll
+        for (int k = 0; k < MAX_LAYERS * 64 / 256; ++k) bv[k] = src4[min(tid + 256 * k, n4 - 1)];
         vec[VEC_SIGW + tid] = io.packed[L.sigma_w + tid];
         for (int i = tid; i < 384; i += 256) vec[VEC_RGBW + i] = io.packed[L.rgb2_w + i];
         if (tid < 4) vec[VEC_MISC + tid] = io.packed[L.sigma_b + tid];
         if (tid >= 4 && tid < 8) vec[VEC_MISC + tid] = io.packed[L.rgb2_b + tid - 4];
         vec[VEC_ZERO + tid] = 0.f;
         const long long first = tile32 * 32 < io.n_points ? tile32 * 32 : io.n_points - 1;
-        const float* ls = io.latent + (first / io.points_per_obj) * L.n_lat * 256;
-        for (int i = lane; i < L.n_lat * 256; i += 64) latw[i] = ls[i];
+        const f32x4* ls4 = reinterpret_cast<const f32x4*>(io.latent + (first / io.points_per_obj) * L.n_lat * 256);
+        f32x4 lv[MAX_LAT];
+#pragma unroll
+        for (int la = 0; la < MAX_LAT; ++la) lv[la] = ls4[max(min(la, L.n_lat - 1), 0) * 64 + lane];   // (n_lat == 0: the caller passes one dummy row)
+#pragma unroll
+        for (int k = 0; k < MAX_LAYERS * 64 / 256; ++k) if (tid + 256 * k < n4) dst4[tid + 256 * k] = bv[k];
+#pragma unroll
+        for (int la = 0; la < MAX_LAT; ++la) if (la < L.n_lat) reinterpret_cast<f32x4*>(latw)[la * 64 + lane] = lv[la];
     }
     float px, py, pz, dx, dy, dz, zc = 0.f;
     if (MODE == 0) {
