@@ -776,6 +776,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
         const SamplePoint sp = make_sample(g, ray, (int)(gp - ray * g.S));
         px_ = sp.x; py_ = sp.y; pz_ = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc; tval = sp.t;
     }
+    const float sig_gp = io.sigmas[gp];       // (issued here: behind the composite's barriers it would be one more exposed round trip)
     float gs = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gzc = 0.f;
     if (MODE == 0) {
         if (live) {
@@ -825,7 +826,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
             gs = c[0]; gr = c[1]; gg = c[2]; gb = c[3]; gzc = c[4];
         }
     }
-    const float dpre = gs * (1.f - expf(-io.sigmas[gp]));
+    const float dpre = gs * (1.f - expf(-sig_gp));
     __syncthreads();
     SNR_BSTAMP(1);
 
