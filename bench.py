@@ -177,7 +177,7 @@ def main():
 
         # ---- BASELINE config 3 in one process: the optimise loop over 64 objects, all of them in one launch per iteration
         loop = {}
-        if rank == 0:
+        if rank == 0 and world == 1:      # (single-GPU runs only: at N > 1 every rank does the same work and leaves together)
             from supnerf_amd import driver as D
             hp = D.load_hpams()
             hp["render_im_sz"] = IM_SZ
@@ -206,7 +206,7 @@ def main():
 
         # ---- the two HBM-bound stand-alone kernels (encode with PE output, composite) at 16 objects x 4096 x 64: achieved GB/s
         hbm = {}
-        if rank == 0:
+        if rank == 0 and world == 1:
             Bh = 64
             ro_h, vd_h = rays_o.repeat(Bh, 1), viewdir.repeat(Bh, 1)
             z_h = z[None].repeat(Bh, 1).contiguous()
@@ -306,6 +306,7 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
