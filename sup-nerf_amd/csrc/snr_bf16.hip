@@ -640,7 +640,7 @@ __device__ __forceinline__ void reduce_tiles_dpp(const f32x16 (&acc)[8], float* 
 // per-object reduction for the latent gradient, layer l's ReLU bits, the density-head term below enc_shape.
 struct BwdEpi {
     uint32_t m[4];        // ReLU bits of layer l (all ones when it has no activation)
-    const float* wsig;    // LDS: density-head weights below enc_shape (a block of zeros otherwise)
+    const float* wsig;    // LDS: density-head weights (only below enc_shape: null otherwise)
     float dpre;           // d loss / d (pre-softplus density) of this lane's point
     float* dzl;           // LDS: where this wave parks the layer's latent-term gradient (256 floats), or null
 #ifdef SNR_STAMPS
@@ -653,12 +653,12 @@ struct BwdEpi {
 #define SNR_LSTAMP(c, i) do {} while (0)
 #endif
 template <int T, int HALF, int JJ>
-__device__ __forceinline__ void bwd_quarter(const f32x16& acc, XOp& out, const BwdEpi& c, const f32x4& wv, int lane) {
+__device__ __forceinline__ void bwd_quarter(const f32x16& acc, XOp& out, const BwdEpi& c, int lane) {
     const int j = 2 * HALF + JJ;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int r = 4 * j + e;
-        float v = fmaf(c.dpre, wv[e], acc[r]);
+        float v = acc[r];
         v = ((c.m[T >> 1] >> ((T & 1) * 16 + r)) & 1u) ? v : 0.f;
         split_store(v, out, r & 7);
     }
@@ -666,10 +666,8 @@ __device__ __forceinline__ void bwd_quarter(const f32x16& acc, XOp& out, const B
 }
 template <int T, int HALF>
 __device__ __forceinline__ void bwd_half_tile(const f32x16& acc, XOp& out, const BwdEpi& c, int h, int lane) {
-    const f32x4 w0 = *reinterpret_cast<const f32x4*>(c.wsig + 32 * T + 8 * (2 * HALF) + 4 * h);
-    const f32x4 w1 = *reinterpret_cast<const f32x4*>(c.wsig + 32 * T + 8 * (2 * HALF + 1) + 4 * h);
-    bwd_quarter<T, HALF, 0>(acc, out, c, w0, lane);
-    bwd_quarter<T, HALF, 1>(acc, out, c, w1, lane);
+    bwd_quarter<T, HALF, 0>(acc, out, c, lane);
+    bwd_quarter<T, HALF, 1>(acc, out, c, lane);
 }
 
 // One transposed layer: 16 operand steps from acc, NT output tiles back into acc (one code instance for the whole chain, like
@@ -688,6 +686,17 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16& acc9, XOp (
     constexpr bool TAIL = (NT != 8);                        // enc_xyz^T: the stream ends with this layer
     constexpr int NCH = 16 / SPC;
     if (c.dzl) reduce_tiles_dpp(accP, c.dzl, lane);
+    if (c.wsig) {       // below enc_shape the density head adds d_pre * w_sigma (one pass here instead of an fma + a vector load in every
+                        // layer's epilogue)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(c.wsig + 32 * t + 8 * j + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) accP[t][4 * j + e] = fmaf(c.dpre, wv[e], accP[t][4 * j + e]);
+            }
+    }
     if (NT == 2) SNR_LSTAMP(c, 10);
     acc_zero<NT, 8>(accC);
     bwd_half_tile<0, 0>(accP[0], x[0], c, h, lane);
@@ -698,15 +707,10 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16& acc9, XOp (
 #define SNR_BSTEP(S)                                                                                                   \
     {                                                                                                                  \
         const char* ws = w + ((S) % SPC) * step_bytes;                                                                 \
-        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;                                                                      \
         load_frags<NTH, NTH>(fb, ws);                                                                                  \
-        if constexpr ((S) + 1 < 16) {                                                                                  \
-            w0 = *reinterpret_cast<const f32x4*>(c.wsig + 32 * (((S) + 1) >> 1) + 8 * (2 * (((S) + 1) & 1)) + 4 * h);     \
-            w1 = *reinterpret_cast<const f32x4*>(c.wsig + 32 * (((S) + 1) >> 1) + 8 * (2 * (((S) + 1) & 1) + 1) + 4 * h); \
-        }                                                                                                              \
         if constexpr ((S) == 15) mma_half_to<NTH, 0, 8>(accP, accC, x[S], fa); else mma_half<NTH, 0, 8>(accC, x[S], fa);       \
         ring_pieces_in<(2 * (S) + 1) % (2 * SPC), SPC, (2 * (S) + 1) / (2 * SPC), NCH, TAIL>(ring, voff);              \
-        if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, w0, lane); \
+        if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, lane); \
         SNR_INTERLEAVE_B(3 * NTH)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + step_bytes);                                   \
@@ -714,7 +718,7 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16& acc9, XOp (
         if constexpr ((S) == 15) mma_half_to<NTH, NTH, 8>(accP, accC, x[S], fb); else mma_half<NTH, NTH, 8>(accC, x[S], fb);   \
         if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0)                                                \
             ring_pieces_in<(2 * (S) + 2) % (2 * SPC), SPC, (2 * (S) + 2) / (2 * SPC), NCH, TAIL>(ring, voff);          \
-        if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, w1, lane); \
+        if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, lane); \
         SNR_INTERLEAVE_B(3 * NTH)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
@@ -883,7 +887,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     auto epi_of = [&](int l) {      // how the gradient wrt (output of layer l [+ latent]) becomes the operand of W_l^T
         BwdEpi c;
         mask_words(l == li_encshape ? -1 : relu_slot(l, sb), c.m);
-        c.wsig = (l == li_encshape) ? vec + VEC_SIGW : vec + VEC_ZERO;
+        c.wsig = (l == li_encshape) ? vec + VEC_SIGW : nullptr;
         c.dpre = (l == li_encshape) ? dpre : 0.f;
         const int la = latent_after(l, sb, tb);
         c.dzl = (la >= 0 && io.partial) ? reinterpret_cast<float*>(lds + OFF_LAT) + (wave * MAX_LAT + la) * 256 : nullptr;
