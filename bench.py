@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_RAY = 57.56e6          # forward, S = 64
 # HBM bytes per 4096x64 forward launch from the committed counter profile (cannot be collected from inside this process)
-HBM_TRAFFIC = {"bf16x3": 16067584.0, "fp32": None}
+HBM_TRAFFIC = {"bf16x3": 16056320.0, "fp32": None}
 PEAK_TFLOPS = {"fp32": 157.3,    # MI355X_MICROARCH.md "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f32
                "bf16x3": 2500.0}  # dense BF16 MFMA peak; the split-bf16 path issues 3 MFMAs per algorithmic product
 N_RAYS, N_SAMPLES, IM_SZ = 4096, 64, 64
