@@ -157,7 +157,8 @@ def optimize_object(model, device, obj: Dict, hpams: dict, shapecode0, textureco
     ys, xs = np.where(mask[:, :, 0].numpy() > 0)
     pick = rs.permutation(len(ys))[:n_lidar]
     y_vec, x_vec = ys[pick], xs[pick]
-    metrics = torch.zeros(opt["num_opts"], 4)
+    metrics = torch.zeros(opt["num_opts"], 4, device=dev)      # stays on the device: the reference's per-iteration .item() logging
+    gt_dev = gt_pose.to(dev)                                    # would put three host syncs into every iteration
     depth0 = None
     for it in range(opt["num_opts"]):
         optim.zero_grad()
@@ -184,8 +185,8 @@ def optimize_object(model, device, obj: Dict, hpams: dict, shapecode0, textureco
             pred_R = cam2opt[:, :3].detach().T if not opt.get("opt_cam_pose", 0) else cam2opt[:, :3].detach()
             pred_t = (-pred_R @ cam2opt[:, 3:].detach()) if not opt.get("opt_cam_pose", 0) else cam2opt[:, 3:].detach()
             row = torch.stack([-10 * torch.log10(mse_fg.detach()), (d_vec - depth0).abs().mean(),
-                               rot_dist(pred_R.cpu(), gt_pose[:, :3]).to(dev), (pred_t.cpu() - gt_pose[:, 3:]).norm().to(dev)])
-        metrics[it] = row.cpu()          # one small D2H per iteration, like the reference's .item() logging
+                               rot_dist(pred_R, gt_dev[:, :3]), (pred_t - gt_dev[:, 3:]).norm()])
+        metrics[it] = row
         if it > reg_iters:
             optim.step()
         if (it + 1) % opt["lr_half_interval"] == 0:
@@ -193,10 +194,10 @@ def optimize_object(model, device, obj: Dict, hpams: dict, shapecode0, textureco
             lr = {k: v * 2 ** (-halvings) for k, v in lr.items()}     # cumulative like update_learning_rate (:1771-1775)
             optim = make_optimizer(shapecode, texturecode, rot_vec, trans_vec, lr)
         if log is not None:
-            log(it, float(loss), metrics[it])
+            log(it, float(loss), metrics[it].cpu())
     if jitter is not None:
         U.JITTER_OVERRIDE = None
-    return metrics, shapecode.detach(), texturecode.detach(), cam2opt.detach()
+    return metrics.cpu(), shapecode.detach(), texturecode.detach(), cam2opt.detach()
 
 
 # ------------------------------------------------------------------ many objects per launch (BASELINE config 3)
@@ -211,12 +212,17 @@ def _rays_batch(K, c2w, px, py):
 
 
 def optimize_objects_batched(model, device, objs: List[Dict], hpams: dict, shapecodes0, texturecodes0, seeds: Sequence[int],
-                             pose_noise=(0.05, 0.3), reg_iters=3, n_lidar=64, jitter=None):
+                             pose_noise=(0.05, 0.3), reg_iters=3, n_lidar=64, jitter=None, graph=False, device_optimizer=None):
     """The iteration of ``optimize_object`` for B objects at once: ONE fused forward, one backward and one 64-pixel
     depth render per iteration for all of them (per-object codes, poses, depth tables and targets; the loss is the sum
     of the per-object losses, so every object sees exactly its own gradient), AdamW over the stacked leaves, metrics
     kept on the device until the end -- no host round trip inside the loop.  Jitter: ``jitter`` (num_opts, 2, B, S) or,
     by default, drawn up front from one CPU generator per object (seeded like the per-object loop seeds its RandomState).
+    ``graph=True`` records the iteration once as a HIP graph (``torch.cuda.graphs``; two graphs: without and with the AdamW step)
+    and replays it -- at small B the eager loop is bound by the ~150 host-side launches of an iteration, not by the GPU.  The
+    graphed loop uses a capturable AdamW (learning rates and step count on the device) whose state is reset in place where the
+    reference re-creates its optimiser; ``device_optimizer=True`` selects that optimiser without the graph (its arithmetic differs
+    from the host-side AdamW in the last bits, which twenty optimisation steps amplify: the tests compare like with like).
     Returns metrics (B, num_opts, 4), shape codes, texture codes, poses (B,3,4)."""
     opt = hpams["optimize"]
     S, im_sz, T = hpams["n_samples"], hpams["render_im_sz"], opt["num_opts"]
@@ -254,16 +260,27 @@ def optimize_objects_batched(model, device, objs: List[Dict], hpams: dict, shape
         jitter = torch.stack([torch.rand(T, 2, S, generator=g) for g in gens], dim=2)
     jitter = jitter.to(dev)
     lr = {k: opt[k] for k in ("lr_shape", "lr_texture", "lr_pose")}
-    optim = make_optimizer(shapecode, texturecode, rot_vec, trans_vec, lr)
+    dev_opt = graph if device_optimizer is None else (device_optimizer or graph)
+    if dev_opt:     # lr as device tensors so that the halvings reach the recorded optimiser step
+        optim = torch.optim.AdamW([{"params": shapecode, "lr": torch.tensor(float(lr["lr_shape"]), device=dev)},
+                                   {"params": texturecode, "lr": torch.tensor(float(lr["lr_texture"]), device=dev)},
+                                   {"params": rot_vec, "lr": torch.tensor(float(lr["lr_pose"]), device=dev)},
+                                   {"params": trans_vec, "lr": torch.tensor(float(lr["lr_pose"]), device=dev)}], capturable=True)
+    else:
+        optim = make_optimizer(shapecode, texturecode, rot_vec, trans_vec, lr)
     frame = U._frame(False, False, hpams["shapenet_obj_cood"])
     sb, tb = getattr(model, "shape_blocks", 0), getattr(model, "texture_blocks", 0)
     a = torch.abs(occ); denom = a.sum(dim=(1, 2)) + 1e-9; fg = occ.clamp_min(0); fg_denom = fg.sum(dim=(1, 2)) + 1e-9
     metrics = torch.zeros(T, B, 4, device=dev)
-    depth0 = None
     half = diag / 2
     idx = torch.arange(S, device=dev, dtype=torch.float32)[None, :]
-    for it in range(T):
-        optim.zero_grad()
+    jit_cur = torch.empty(2, B, S, device=dev)            # this iteration's two jitter draws (a fixed address for the recorded graph)
+    depth0 = torch.zeros(B, n_lidar, device=dev)
+    row = torch.zeros(B, 4, device=dev)
+    pose = torch.zeros(B, 3, 4, device=dev)
+
+    def iteration(first: bool, do_step: bool):
+        optim.zero_grad(set_to_none=not dev_opt)
         R = axis_angle_to_matrix(rot_vec)
         t = trans_vec.unsqueeze(-1)
         if not opt.get("opt_cam_pose", 0):
@@ -282,7 +299,7 @@ def optimize_objects_batched(model, device, objs: List[Dict], hpams: dict, shape
             z = torch.where(idx < S // 2, start + step * idx, end - step * (S - 1 - idx)) + jit * hw
             cfg = U.ops.RenderCfg(S, U.ops.Z_PER_OBJECT, rays_per_obj, sb, tb, frame=frame, precision=None)
             return model.fused_render(rays_o, viewdir, z.contiguous(), diag, None, shapecode, texturecode, cfg)
-        rgb, depth, acc = render(px, py, jitter[it, 0], n)
+        rgb, depth, acc = render(px, py, jit_cur[0], n)
         rgb, acc = rgb.view(B, n, 3), acc.view(B, n, 1)
         sq = (rgb - tgt) ** 2
         loss_rgb = (sq * a).sum(dim=(1, 2)) / denom
@@ -290,21 +307,61 @@ def optimize_objects_batched(model, device, objs: List[Dict], hpams: dict, shape
         (loss_rgb + hpams["loss_occ_coef"] * loss_occ).sum().backward()
         with torch.no_grad():
             mse_fg = (sq.detach() * fg).sum(dim=(1, 2)) / fg_denom
-            d_vec = render(lx, ly, jitter[it, 1], n_lidar)[1].view(B, n_lidar)
-            if depth0 is None:
-                depth0 = d_vec.clone()
+            d_vec = render(lx, ly, jit_cur[1], n_lidar)[1].view(B, n_lidar)
+            if first:
+                depth0.copy_(d_vec)
             c = cam2opt.detach()
             pred_R = c[:, :, :3].transpose(-2, -1) if not opt.get("opt_cam_pose", 0) else c[:, :, :3]
             pred_t = -pred_R @ c[:, :, 3:] if not opt.get("opt_cam_pose", 0) else c[:, :, 3:]
-            metrics[it] = torch.stack([-10 * torch.log10(mse_fg), (d_vec - depth0).abs().mean(dim=1), rot_dist(pred_R, gtR),
-                                       (pred_t - gtT).flatten(1).norm(dim=1)], dim=1)
-        if it > reg_iters:
+            row.copy_(torch.stack([-10 * torch.log10(mse_fg), (d_vec - depth0).abs().mean(dim=1), rot_dist(pred_R, gtR),
+                                   (pred_t - gtT).flatten(1).norm(dim=1)], dim=1))
+            pose.copy_(c)
+        if do_step:
             optim.step()
+
+    def restart_optimizer(scale: float):
+        """What re-creating the optimiser does (src/optimizer_nuscenes.py:1771-1775), in place: fresh moments and step count,
+        every learning rate times ``scale``."""
+        for grp in optim.param_groups:
+            grp["lr"].mul_(scale)
+        for st_ in optim.state.values():
+            st_["step"].zero_(); st_["exp_avg"].zero_(); st_["exp_avg_sq"].zero_()
+
+    graphs = {}
+    for it in range(T):
+        jit_cur.copy_(jitter[it])
+        do_step = it > reg_iters
+        if not graph or it == 0:
+            iteration(it == 0, do_step)
+        else:
+            if do_step not in graphs:
+                if do_step and not optim.state:          # create the AdamW state outside the recording: a step with lr = 0 changes nothing
+                    saved = [grp["lr"].clone() for grp in optim.param_groups]
+                    for grp in optim.param_groups:
+                        grp["lr"].zero_()
+                    optim.step()
+                    for grp, v in zip(optim.param_groups, saved):
+                        grp["lr"].copy_(v)
+                    restart_optimizer(1.0)
+                g_ = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g_):
+                    iteration(False, do_step)
+                graphs[do_step] = g_
+            graphs[do_step].replay()
+        metrics[it].copy_(row)
         if (it + 1) % opt["lr_half_interval"] == 0:
             halvings = (it + 1) // opt["lr_half_interval"]
-            lr = {k: v * 2 ** (-halvings) for k, v in lr.items()}
-            optim = make_optimizer(shapecode, texturecode, rot_vec, trans_vec, lr)
-    return metrics.permute(1, 0, 2).contiguous(), shapecode.detach(), texturecode.detach(), cam2opt.detach()
+            if dev_opt:
+                if optim.state:
+                    restart_optimizer(2.0 ** (-halvings))
+                else:
+                    for grp in optim.param_groups:
+                        grp["lr"].mul_(2.0 ** (-halvings))
+            else:
+                lr = {k: v * 2 ** (-halvings) for k, v in lr.items()}
+                optim = make_optimizer(shapecode, texturecode, rot_vec, trans_vec, lr)
+    return metrics.permute(1, 0, 2).contiguous(), shapecode.detach(), texturecode.detach(), pose.clone()
 
 
 def make_objects(ids: Sequence[int], im_sz: int) -> List[Dict]:

@@ -159,3 +159,22 @@ def test_optimize_objects_batches_and_shards():
     one = D.optimize_objects(model, dev, 5, hp, seed=1, batch=64)
     assert full.shape == (5, 12) and bool(torch.isfinite(full).all())
     assert float((full - one).abs().max()) < 1e-3                              # the batch size does not change an object's numbers
+
+
+def test_graph_replayed_loop_equals_eager_loop():
+    """optimize_objects_batched(graph=True): the iteration recorded once as a HIP graph and replayed must do what the eager loop does
+    (same device-side AdamW in both, see the docstring); lr halving inside the window, steps gated by reg_iters."""
+    import supnerf_amd as A
+    D = A.driver
+    dev = torch.device("cuda:0")
+    model = A.CodeNeRF(3, 1); model.load_state_dict(O.init_decoder_params()); model = model.to(dev)
+    hp = D.load_hpams(); hp["render_im_sz"] = 16; hp["optimize"]["num_opts"] = 12; hp["optimize"]["lr_half_interval"] = 5
+    objs = D.make_objects([300, 301], 16)
+    g = torch.Generator().manual_seed(9)
+    sc, tc = torch.randn(2, 256, generator=g) * 0.3, torch.randn(2, 256, generator=g) * 0.3
+    eager = D.optimize_objects_batched(model, dev, objs, hp, sc, tc, [0, 1], n_lidar=16, device_optimizer=True)
+    graph = D.optimize_objects_batched(model, dev, objs, hp, sc, tc, [0, 1], n_lidar=16, graph=True)
+    assert torch.isfinite(graph[0]).all()
+    for a, b, tol, name in zip(eager, graph, (1e-4, 1e-5, 1e-5, 1e-5), ("metrics", "shape codes", "texture codes", "poses")):
+        assert float((a - b).abs().max()) < tol, (name, float((a - b).abs().max()))
+    assert float((graph[1].cpu() - sc).abs().max()) > 1e-3          # the replayed steps did move the codes
