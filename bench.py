@@ -98,6 +98,8 @@ def main():
     cfg = ops.RenderCfg(N_SAMPLES, ops.Z_SHARED, N_RAYS, 3, 1, frame=U._frame(False, False, True), precision=args.precision)
     other = "fp32" if args.precision == "bf16x3" else "bf16x3"
     cfg_other = ops.RenderCfg(N_SAMPLES, ops.Z_SHARED, N_RAYS, 3, 1, frame=U._frame(False, False, True), precision=other)
+    # like model.fused_render: the latent terms also folded into the next layers' biases (prepared beside the latent terms, outside the path)
+    cfg.latent_bias = cfg_other.latent_bias = model.latent_biases(lat)
     model.precision = args.precision
     assert rays_o.shape[0] == N_RAYS
 

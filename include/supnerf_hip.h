@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SNR_ABI_VERSION 3
+#define SNR_ABI_VERSION 4
 
 enum {
     SNR_OK = 0,
@@ -142,6 +142,11 @@ typedef struct snr_render_args {
     int32_t shape_blocks;
     int32_t texture_blocks;
     int32_t precision;      /* SNR_FP32 / SNR_BF16X3 */
+    /* optional (may be null), forward only, (B, NLAT, 256): for every latent term z_j the bias the NEXT layer's accumulators start
+     * from, b + W z_j (z_j is added after a ReLU, so it only ever reaches that layer through W z_j; the reference computes
+     * `shape_layer_j(y + z_j)`, src/model_supnerf.py:253-263).  With it the split-bf16 forward drops the latent add and its vector
+     * loads from every epilogue (-4 %); `latent` is still what the gradient d_latent of snr_render_bwd refers to. */
+    const float* latent_bias;
 } snr_render_args;
 
 int snr_render_fwd(const snr_render_args* a, float* rgb, float* depth, float* acc_trans,

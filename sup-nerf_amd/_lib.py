@@ -23,7 +23,8 @@ class RenderArgs(C.Structure):
                 ("z_scale", C.c_void_p), ("latent", C.c_void_p), ("packed", C.c_void_p),
                 ("frame", C.c_float * 9), ("xyz_mul", C.c_float), ("z_mode", C.c_int32), ("flags", C.c_int32),
                 ("n_rays", C.c_int64), ("rays_per_obj", C.c_int64), ("n_samples", C.c_int32),
-                ("shape_blocks", C.c_int32), ("texture_blocks", C.c_int32), ("precision", C.c_int32)]
+                ("shape_blocks", C.c_int32), ("texture_blocks", C.c_int32), ("precision", C.c_int32),
+                ("latent_bias", C.c_void_p)]
 
 
 _lib = None
@@ -68,7 +69,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)       # AttributeError if the header and the library disagree
             fn.restype, fn.argtypes = res, args
-        if l.snr_abi_version() != 3:
+        if l.snr_abi_version() != 4:
             raise SnrError("libsupnerf_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -209,13 +209,14 @@ __device__ __forceinline__ void pin(XOp& o) { asm volatile("" : "+v"(o.hi), "+v"
 // with one wave per SIMD the layer chain is bounded by instruction ISSUE (about six 4-cycle slots per 32-cycle MFMA).
 // bias and latent vectors of one quarter: fetched from LDS at the top of a step, consumed half a step or more later, so no
 // lgkmcnt wait sits between the MFMAs (an exposed LDS round trip there stalls the in-order wave AND the matrix pipe)
+// ZADD = false: the latent terms came folded into the biases (snr_render_args::latent_bias), nothing is added here
 struct EpiVec { f32x4 z; };
-template <int T, int HALF, int JJ>
+template <int T, int HALF, int JJ, bool ZADD = true>
 __device__ __forceinline__ void fwd_quarter_load(EpiVec& v, const FwdEpi& c, int h) {
     const int j = 2 * HALF + JJ;
-    v.z = *reinterpret_cast<const f32x4*>(c.zl + 32 * T + 8 * j + 4 * h);
+    if constexpr (ZADD) v.z = *reinterpret_cast<const f32x4*>(c.zl + 32 * T + 8 * j + 4 * h);
 }
-template <int T, int HALF, int JJ, bool MASKS>
+template <int T, int HALF, int JJ, bool MASKS, bool ZADD = true>
 __device__ __forceinline__ void fwd_quarter(const f32x16& acc, XOp& out, const FwdEpi& c, const EpiVec& v, uint32_t (&mask)[4]) {
 #ifdef SNR_EXP_NOEPI
     return;
@@ -232,18 +233,19 @@ __device__ __forceinline__ void fwd_quarter(const f32x16& acc, XOp& out, const F
         // ReLU as v_max_i32 on the bit pattern (no canonicalising second max, -0 -> +0), then the latent term, then the hi/lo split.
         // Plain C++ on purpose: the same epilogue on v_pk_add_f32 through inline asm has a quarter fewer VALU ops and is 2-4 % SLOWER,
         // the scheduler cannot place asm statements under the MFMAs (sched_group_barrier does not see them as VALU).
-        split_store(__builtin_bit_cast(float, max(__builtin_bit_cast(int, a), c.floor)) + v.z[e], out, r & 7);
+        const float y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, a), c.floor));
+        split_store(ZADD ? y + v.z[e] : y, out, r & 7);
     }
     if (JJ == 1) pin(out);
     if (MASKS) asm volatile("" : "+v"(mask[T >> 1]));      // keep the bit capture here (LLVM otherwise recomputes it at the layer's end)
 }
-template <int T, int HALF, bool MASKS>
+template <int T, int HALF, bool MASKS, bool ZADD = true>
 __device__ __forceinline__ void fwd_half_tile(const f32x16& acc, XOp& out, const FwdEpi& c, int h, uint32_t (&mask)[4]) {
     EpiVec v0, v1;
-    fwd_quarter_load<T, HALF, 0>(v0, c, h);
-    fwd_quarter_load<T, HALF, 1>(v1, c, h);
-    fwd_quarter<T, HALF, 0, MASKS>(acc, out, c, v0, mask);
-    fwd_quarter<T, HALF, 1, MASKS>(acc, out, c, v1, mask);
+    fwd_quarter_load<T, HALF, 0, ZADD>(v0, c, h);
+    fwd_quarter_load<T, HALF, 1, ZADD>(v1, c, h);
+    fwd_quarter<T, HALF, 0, MASKS, ZADD>(acc, out, c, v0, mask);
+    fwd_quarter<T, HALF, 1, MASKS, ZADD>(acc, out, c, v1, mask);
 }
 
 // density head on finished enc_shape accumulators (bias included): this lane's share of w_sigma . y
@@ -294,7 +296,7 @@ __device__ __forceinline__ float sigma_partial(const f32x16 (&acc)[8], const flo
 // Each step is two half-steps of NT/2 tiles.  The A fragments of a half-step are fetched from LDS while the previous
 // half-step's MFMAs run (two fragment buffers), the next chunk is acquired half a step before it is needed, and the
 // previous layer's epilogue for operand step S+1 is split over the two half-steps of step S.
-template <int NT, bool MASKS>
+template <int NT, bool MASKS, bool ZADD>
 __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], XOp (&x)[16], const char* xdir_lds, Ring& ring, char* lds,
                                           const FwdEpi& c, bool extra, uint32_t (&mask)[4], int tid, int lane) {
     f32x16 accC[8];
@@ -308,7 +310,7 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], XOp (&x)[16], const
 #pragma unroll
     for (int i = 0; i < 4; ++i) mask[i] = 0u;
     acc_bias<NT, 8>(accC, c.bias, h);
-    fwd_half_tile<0, 0, MASKS>(accP[0], x[0], c, h, mask);
+    fwd_half_tile<0, 0, MASKS, ZADD>(accP[0], x[0], c, h, mask);
     Frags<NTH> fa, fb;
     const char* w = ring_acquire(ring, lds) + lane * 16;
     load_frags<NTH, 0>(fa, w);
@@ -319,12 +321,12 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], XOp (&x)[16], const
         EpiVec v0, v1;                                                                                                 \
         load_frags<NTH, NTH>(fb, ws);                                                                                  \
         if constexpr ((S) + 1 < 16) {                                                                                  \
-            fwd_quarter_load<(((S) + 1) >> 1), (((S) + 1) & 1), 0>(v0, c, h);                                          \
-            fwd_quarter_load<(((S) + 1) >> 1), (((S) + 1) & 1), 1>(v1, c, h);                                          \
+            fwd_quarter_load<(((S) + 1) >> 1), (((S) + 1) & 1), 0, ZADD>(v0, c, h);                                          \
+            fwd_quarter_load<(((S) + 1) >> 1), (((S) + 1) & 1), 1, ZADD>(v1, c, h);                                          \
         }                                                                                                              \
         if constexpr ((S) == 15) mma_half_to<NTH, 0, 8>(accP, accC, x[S], fa); else mma_half<NTH, 0, 8>(accC, x[S], fa);       \
         ring_pieces_in<(2 * (S) + 1) % (2 * SPC), SPC, (2 * (S) + 1) / (2 * SPC), NCH, TAIL>(ring, voff);              \
-        if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0, MASKS>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v0, mask); \
+        if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0, MASKS, ZADD>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v0, mask); \
         SNR_INTERLEAVE(3 * NTH)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + STEP_BYTES);                                   \
@@ -332,7 +334,7 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], XOp (&x)[16], const
         if constexpr ((S) == 15) mma_half_to<NTH, NTH, 8>(accP, accC, x[S], fb); else mma_half<NTH, NTH, 8>(accC, x[S], fb);   \
         if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0)                                                \
             ring_pieces_in<(2 * (S) + 2) % (2 * SPC), SPC, (2 * (S) + 2) / (2 * SPC), NCH, TAIL>(ring, voff);          \
-        if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1, MASKS>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v1, mask); \
+        if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1, MASKS, ZADD>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v1, mask); \
         SNR_INTERLEAVE(3 * NTH)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
@@ -359,7 +361,7 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], XOp (&x)[16], const
 #define SNR_STAMP(i) do {} while (0)
 #endif
 
-template <int MODE, bool MASKS>
+template <int MODE, bool MASKS, bool EBIAS>      // EBIAS: io.latent_bias holds the latent terms folded into the next layers' biases
 __global__ void __launch_bounds__(256, 1)
 bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom g,
                 float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_acc) {
@@ -393,7 +395,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         if (tid >= 4 && tid < 8) vec[VEC_MISC + tid] = io.packed[L.rgb2_b + tid - 4];
         vec[VEC_ZERO + tid] = 0.f;
         const long long first = tile32 * 32 < io.n_points ? tile32 * 32 : io.n_points - 1;
-        const f32x4* ls4 = reinterpret_cast<const f32x4*>(io.latent + (first / io.points_per_obj) * L.n_lat * 256);
+        const f32x4* ls4 = reinterpret_cast<const f32x4*>((EBIAS ? io.latent_bias : io.latent) + (first / io.points_per_obj) * L.n_lat * 256);
         f32x4 lv[MAX_LAT];
 #pragma unroll
         for (int la = 0; la < MAX_LAT; ++la) lv[la] = ls4[max(min(la, L.n_lat - 1), 0) * 64 + lane];   // (n_lat == 0: the caller passes one dummy row)
@@ -484,9 +486,9 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     auto epi_of = [&](int l) {     // epilogue configuration of MFMA layer l's output
         FwdEpi c;
         c.floor = (l != li_encshape) ? 0 : (int)0x80000000;
-        c.bias = vec + VEC_BIAS + (l + 1) * 256;
         const int la = latent_after(l, sb, tb);
-        c.zl = la >= 0 ? latw + la * 256 : vec + VEC_ZERO;
+        c.bias = (EBIAS && la >= 0) ? latw + la * 256 : vec + VEC_BIAS + (l + 1) * 256;
+        c.zl = (!EBIAS && la >= 0) ? latw + la * 256 : vec + VEC_ZERO;
         return c;
     };
     const bool tile_live = tile32 * 32 < io.n_points;     // the last workgroup may own wave tiles past the end: they store nothing
@@ -500,13 +502,13 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     };
 #pragma unroll 1
     for (int li = 1; li <= li_last; ++li) {
-        layer_fwd<8, MASKS>(accA, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
+        layer_fwd<8, MASKS, !EBIAS>(accA, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
         store_mask(li - 1);
         if (li == li_encshape) sig_dot = sigma_partial(accA, vec + VEC_SIGW, fresh_lane() >> 5);
         SNR_STAMP(3 + li);
     }
     // ---- rgb.0: 256 -> 128 (4 tiles) from the last 256-wide layer's accumulators
-    layer_fwd<4, MASKS>(accA, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
+    layer_fwd<4, MASKS, !EBIAS>(accA, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
     store_mask(li_last);
     SNR_STAMP(12);
 
@@ -1097,12 +1099,15 @@ int snr_bf16_launch_fwd_(int mode, const DecoderIO& io, const Layout& L, const f
                          float* depth, float* acc, void* stream_) {
     const unsigned grid = (unsigned)((io.n_points + 127) / 128);
     hipStream_t st = (hipStream_t)stream_;
+    const bool ebias = mode == 1 && io.latent_bias && L.n_lat > 0;
     if (io.masks) {
-        if (mode == 0) bf::bf16_fwd_kernel<0, true><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
-        else bf::bf16_fwd_kernel<1, true><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+        if (mode == 0) bf::bf16_fwd_kernel<0, true, false><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+        else if (ebias) bf::bf16_fwd_kernel<1, true, true><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+        else bf::bf16_fwd_kernel<1, true, false><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
     } else {
-        if (mode == 0) bf::bf16_fwd_kernel<0, false><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
-        else bf::bf16_fwd_kernel<1, false><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+        if (mode == 0) bf::bf16_fwd_kernel<0, false, false><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+        else if (ebias) bf::bf16_fwd_kernel<1, false, true><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+        else bf::bf16_fwd_kernel<1, false, false><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
     }
     return snr_check_launch_();
 }

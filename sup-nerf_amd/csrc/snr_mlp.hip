@@ -273,6 +273,7 @@ int snr_render_fwd(const snr_render_args* a, float* rgb, float* depth, float* ac
     const long long P = a->n_rays * a->n_samples;
     DecoderIO io{a->packed, a->latent, a->shape_blocks, a->texture_blocks, P, a->rays_per_obj * a->n_samples, sigmas, rgbs,
                  (uint4*)relu_masks, nullptr, false};
+    io.latent_bias = a->latent_bias;
     const Layout L = make_layout(a->shape_blocks, a->texture_blocks);
     if (a->precision == SNR_BF16X3) {
         if (!snr_bf16_supported_(a->shape_blocks, a->texture_blocks, a->rays_per_obj * a->n_samples)) return SNR_E_UNSUPPORTED;

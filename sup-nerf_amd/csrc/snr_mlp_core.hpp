@@ -136,6 +136,7 @@ struct DecoderIO {
     uint4* masks;             // optional
     float* act;               // optional, training: inputs of MFMA layers 1..NL-1 and of rgb.2, [slot][P][256]
     bool live;                // this lane's point exists (set per lane by the kernel)
+    const float* latent_bias; // optional (B, n_lat, 256): see snr_render_args::latent_bias (split-bf16 fused forward only)
 };
 
 // registers (operand layout) -> row-major [P][256] dump of NT*32 features of one point

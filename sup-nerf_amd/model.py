@@ -76,6 +76,18 @@ class _DecoderBase(nn.Module):
             return shape_latent.new_zeros(shape_latent.shape[0], 1, 256)
         return torch.stack(outs, dim=1)
 
+    def latent_biases(self, lat: torch.Tensor) -> Optional[torch.Tensor]:
+        """(B, shape_blocks+texture_blocks, 256): for every latent term z_j the bias the NEXT layer starts from, b + W z_j.  z_j is
+        added after a ReLU (``shape_layer_j(y + z_j)``, src/model_supnerf.py:253-263), so it only reaches that layer through W z_j;
+        with these the split-bf16 forward drops the latent add from every epilogue.  No gradient: the backward kernel returns the
+        gradient of the latent terms themselves.  None when there are no blocks."""
+        if self.shape_blocks + self.texture_blocks == 0:
+            return None
+        with torch.no_grad():
+            lins = [getattr(self, f"shape_layer_{j + 1}")[0] for j in range(self.shape_blocks)]
+            lins += [getattr(self, f"texture_layer_{j + 1}")[0] for j in range(self.texture_blocks)]
+            return torch.stack([F.linear(lat[:, j].detach(), lin.weight, lin.bias) for j, lin in enumerate(lins)], dim=1).contiguous()
+
     def forward(self, xyz, viewdir, shape_latent, texture_latent):
         """sigmas (N,S,1), rgbs (N,S,3) -- same contract as the reference forward
         (src/model_supnerf.py:241-269); rays are object-major over the B codes."""
@@ -98,6 +110,7 @@ class _DecoderBase(nn.Module):
         lat = self.latent_terms(shape_latent, texture_latent)
         if cfg.precision is None:
             cfg.precision = self.precision
+        cfg.latent_bias = self.latent_biases(lat)
         return ops.FusedRender.apply(rays_o, rays_d, t_vals, xyz_div, z_scale, lat, self.packed_weights(), cfg)
 
 

@@ -298,7 +298,7 @@ class DecoderPointsTrain(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------ fused render
 def _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, frame, xyz_mul, z_mode, flags, rays_per_obj,
-                 n_samples, shape_blocks, texture_blocks, precision=FP32):
+                 n_samples, shape_blocks, texture_blocks, precision=FP32, latent_bias=None):
     a = RenderArgs()
     a.rays_o, a.rays_d, a.t_vals = rays_o.data_ptr(), rays_d.data_ptr(), t_vals.data_ptr()
     a.xyz_div = xyz_div.data_ptr()
@@ -311,6 +311,7 @@ def _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, frame
     a.n_rays, a.rays_per_obj = int(rays_o.shape[0]), int(rays_per_obj)
     a.n_samples, a.shape_blocks, a.texture_blocks = int(n_samples), int(shape_blocks), int(texture_blocks)
     a.precision = int(precision)
+    a.latent_bias = latent_bias.data_ptr() if latent_bias is not None else 0
     return a
 
 
@@ -329,6 +330,9 @@ class RenderCfg:
         self.shape_blocks, self.texture_blocks = shape_blocks, texture_blocks
         self.frame, self.xyz_mul = tuple(float(v) for v in frame), float(xyz_mul)
         self.flags = (WHITE_BKGD if white_bkgd else 0) | (METRIC_Z if metric_z else 0)
+        # optional (B, NLAT, 256) fp32 on the device: the latent terms folded into the next layers' biases (model.latent_biases);
+        # forward only, no gradient flows through it (the backward kernel returns the gradient of the latent terms themselves)
+        self.latent_bias = None
 
 
 def render_fwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg: RenderCfg, save_for_bwd=False):
@@ -347,8 +351,13 @@ def render_fwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg: Re
         rgbs = torch.empty(N * S, 3, device=dev)
         masks = torch.empty(_lib.lib().snr_mask_bytes(N * S, cfg.shape_blocks, cfg.texture_blocks), dtype=torch.uint8, device=dev)
     prec = resolve_precision(cfg.precision, cfg.shape_blocks, cfg.texture_blocks, cfg.rays_per_obj * S)
+    lb = getattr(cfg, "latent_bias", None)
+    if lb is not None:
+        lb = _f32c(lb.detach())
+        if lb.shape != latent.shape or lb.device != dev:
+            raise SnrError(f"latent_bias must match the latent terms: {tuple(lb.shape)} on {lb.device} vs {tuple(latent.shape)} on {dev}")
     a = _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg.frame, cfg.xyz_mul, cfg.z_mode, cfg.flags,
-                     cfg.rays_per_obj, S, cfg.shape_blocks, cfg.texture_blocks, prec)
+                     cfg.rays_per_obj, S, cfg.shape_blocks, cfg.texture_blocks, prec, latent_bias=lb)
     with torch.cuda.device(dev):
         check(_lib.lib().snr_render_fwd(C.byref(a), _p(rgb), _p(depth), _p(acc), _p(sig), _p(rgbs), _p(masks), _stream(dev)),
               "snr_render_fwd")

@@ -284,6 +284,36 @@ def test_decoder_forward_other_block_counts(amd, dev):
         assert maxdiff(rgb.view(N, S, 3), rgb_o) < 2e-5, (sb, tb, prec)
 
 
+def test_latent_terms_folded_into_biases(amd, dev, golden, packed, oracle_params):
+    """snr_render_args::latent_bias (the latent terms folded into the next layers' biases, b + W z): the split-bf16 forward with it must
+    render what it renders with the plain latent terms, and save the same ReLU bits for the backward."""
+    g = golden("render_a_nusc")
+    ops = amd.ops
+    pk, p = packed
+    S = int(g["n_samples"])
+    ro, vd, z = _geom_family_a(g, dev, S, bool(g["shapenet_obj_cood"]))
+    lat = O.latent_terms(oracle_params, g["shapecode"], g["texturecode"]).to(dev)
+    div = torch.tensor([float(g["obj_diag"])], device=dev)
+    frame = frame_matrix(False, bool(g["kitti2nusc"]), bool(g["shapenet_obj_cood"]))
+    names = [f"shape_layer_{j + 1}.0" for j in range(3)] + ["texture_layer_1.0"]
+    lb = torch.stack([torch.nn.functional.linear(lat[:, j], oracle_params[n + ".weight"].to(dev), oracle_params[n + ".bias"].to(dev))
+                      for j, n in enumerate(names)], dim=1).contiguous()
+    outs = []
+    for bias in (None, lb):
+        cfg = ops.RenderCfg(S, ops.Z_SHARED, ro.shape[0], 3, 1, frame=frame, precision="bf16x3")
+        cfg.latent_bias = bias
+        outs.append(ops.render_fwd(ro, vd, z, div, None, lat, pk, cfg, save_for_bwd=True))
+    for a, b, tol in zip(outs[0][:5], outs[1][:5], (2e-6, 2e-5, 2e-6, 2e-5, 2e-5)):
+        assert maxdiff(a, b) < tol
+    # ReLU bits: identical up to pre-activations within rounding of zero
+    diff_bits = int((outs[0][5] != outs[1][5]).sum())
+    assert diff_bits <= outs[0][5].numel() // 100000 + 8, diff_bits
+    assert maxdiff(outs[1][0], g["rgb"]) < 2e-5
+    with pytest.raises(amd.SnrError):
+        cfg.latent_bias = lb[:, :2]
+        ops.render_fwd(ro, vd, z, div, None, lat, pk, cfg)
+
+
 # ------------------------------------------------------------------ fused render
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("tag", ["a_nusc", "a_kitti", "a_demo"])

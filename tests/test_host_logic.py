@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(amd):
     lib = amd._lib.lib()                      # loads without a GPU; no compute call is made here
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.snr_abi_version() == 3
+    assert lib.snr_abi_version() == 4
     assert lib.snr_packed_bytes(3, 1) == 3615264 + (2 * 32768 + 5 * 8 * 32768 + 8 * 36864 + 4 * 32768) * 2 and lib.snr_packed_bytes(9, 1) == 0
     assert lib.snr_precision_supported(1, 3, 1, 4096 * 64) == 1 and lib.snr_precision_supported(1, 5, 5, 4096 * 64) == 0
     assert lib.snr_precision_supported(1, 3, 1, 35) == 0 and lib.snr_precision_supported(0, 5, 5, 35) == 1

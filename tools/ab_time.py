@@ -21,7 +21,9 @@ with torch.no_grad():
 pk = model.packed_weights()
 div = torch.full((1,), float(ob["obj_diag"]), device=dev)
 ro, vd = ro.contiguous(), vd.contiguous()
-a = ops._render_args(ro, vd, z, div, None, lat, pk, U._frame(False, False, True), 1.0, ops.Z_SHARED, 0, N, S, 3, 1, int(os.environ.get("SNR_AB_PRECISION", "1")))
+lb = None if os.environ.get("SNR_AB_NOLB") else model.latent_biases(lat)      # latent terms folded into the biases (as model.fused_render passes them)
+a = ops._render_args(ro, vd, z, div, None, lat, pk, U._frame(False, False, True), 1.0, ops.Z_SHARED, 0, N, S, 3, 1, int(os.environ.get("SNR_AB_PRECISION", "1")),
+                     latent_bias=lb)
 rgb = torch.empty(N, 3, device=dev); depth = torch.empty(N, device=dev); acc = torch.empty(N, device=dev)
 sig = torch.empty(N * S, device=dev); rgbs = torch.empty(N * S, 3, device=dev)
 masks = torch.empty(int(good.snr_mask_bytes(N * S, 3, 1)), dtype=torch.uint8, device=dev)
