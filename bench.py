@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_RAY = 57.56e6          # forward, S = 64
 # HBM bytes per 4096x64 forward launch from the committed counter profile (cannot be collected from inside this process)
-HBM_TRAFFIC = {"bf16x3": 16056320.0, "fp32": None}
+HBM_TRAFFIC = {"bf16x3": 16020480.0, "fp32": None}
 PEAK_TFLOPS = {"fp32": 157.3,    # MI355X_MICROARCH.md "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f32
                "bf16x3": 2500.0}  # dense BF16 MFMA peak; the split-bf16 path issues 3 MFMAs per algorithmic product
 N_RAYS, N_SAMPLES, IM_SZ = 4096, 64, 64
@@ -266,9 +266,9 @@ def main():
                    "rays": N_RAYS, "samples": N_SAMPLES, "objects_per_gpu": 1, "sharding": "objects across ranks, no data-path collective"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                      "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": HBM_TRAFFIC.get(args.precision),
-                     "traffic_unit": "bytes per launch", "traffic_source": "profiles/r01_v6_fwd_pmc.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) "
+                     "traffic_unit": "bytes per launch", "traffic_source": "profiles/r01_v7_fwd_pmc.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) "
                                                                           "+ WRITE_SIZE in separate passes; 8 XCD L2s fetch the 1.74 MB weight stream once each",
-                     "kernel": "bf16_fwd_kernel<1,false>" if args.precision == "bf16x3" else "decoder_fwd_kernel<1>",
+                     "kernel": "bf16_fwd_kernel<1,false,true>" if args.precision == "bf16x3" else "decoder_fwd_kernel<1>",
                      "kernel_ms": kern_ms, "flop_per_launch": N_RAYS * FLOP_PER_RAY,
                      "note": "achieved = ALGORITHMIC flops (57.56 MFLOP/ray) / kernel time; bf16x3 issues 3x that on the bf16 MFMA pipe "
                              "(mfma_pipe_frac), fp32 issues 1x on the fp32 MFMA pipe",

@@ -22,6 +22,7 @@ with torch.no_grad():
 pk = model.packed_weights()
 div = torch.full((1,), float(ob["obj_diag"]), device=dev)
 cfg = ops.RenderCfg(S, ops.Z_SHARED, N, 3, 1, frame=U._frame(False, False, True), precision=prec)
+cfg.latent_bias = model.latent_biases(lat)          # as model.fused_render passes them
 if not bwd:
     for _ in range(n):
         ops.render_fwd(ro, vd, z, div, None, lat, pk, cfg)
