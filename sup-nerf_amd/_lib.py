@@ -29,6 +29,17 @@ class RenderArgs(C.Structure):
 
 _lib = None
 
+
+def header_abi_version() -> int:
+    """SNR_ABI_VERSION as include/supnerf_hip.h declares it: the single source of truth the loader, build() and the tests
+    compare the library against."""
+    import re
+    with open(os.path.join(_HERE, "..", "include", "supnerf_hip.h")) as f:
+        m = re.search(r"#define\s+SNR_ABI_VERSION\s+(\d+)", f.read())
+    if m is None:
+        raise SnrError("include/supnerf_hip.h does not define SNR_ABI_VERSION")
+    return int(m.group(1))
+
 _P = C.c_void_p
 _SIGS = {
     "snr_abi_version": (C.c_int, []),
@@ -69,8 +80,10 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)       # AttributeError if the header and the library disagree
             fn.restype, fn.argtypes = res, args
-        if l.snr_abi_version() != 4:
-            raise SnrError("libsupnerf_hip.so ABI version mismatch")
+        want = header_abi_version()
+        if l.snr_abi_version() != want:
+            raise SnrError(f"libsupnerf_hip.so ABI version {l.snr_abi_version()} != include/supnerf_hip.h's {want}: rebuild "
+                           "(python sup-nerf_amd/build.py --force)")
         _lib = l
     return _lib
 

@@ -21,14 +21,7 @@ def volume_rendering3(sigmas, rgbs, z_vals, white_bkgd=False):
     return U._composite(sigmas, rgbs, z_vals, Z_PER_RAY, white_bkgd)
 
 
-def _unit_depths(near, far, n_samples, jitter=None):
-    """src/renderer.py:27-41: stratified depths between per-ray near/far (N,1); device ``rand_like`` jitter."""
-    step = 1.0 / n_samples
-    t = torch.linspace(0, 1 - step, n_samples, device=near.device)[None, :].repeat(near.shape[0], 1)
-    if jitter is None:
-        jitter = U._jitter_override()
-    t = t + (torch.rand_like(t) if jitter is None else jitter.to(t.device)) * step
-    return near * (1 - t) + far * t
+_unit_depths = U._unit_depths     # the stratified per-ray depth table lives beside its module-level twin, utils.sample_from_rays_v2
 
 
 def _box_bounds(rays_o_n, viewdir, obj_sz, diag):

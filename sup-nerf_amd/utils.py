@@ -120,6 +120,23 @@ def sample_from_rays(ro, vd, near, far, N_samples, z_fixed=False):
     return xyz, vdir, z
 
 
+def _unit_depths(near, far, n_samples, jitter=None):
+    """src/renderer.py:27-41 == src/utils.py:170-184: stratified depths between per-ray near/far (N,1); device ``rand_like``
+    jitter (one draw of (N,S) from the device generator, like the reference)."""
+    step = 1.0 / n_samples
+    t = torch.linspace(0, 1 - step, n_samples, device=near.device)[None, :].repeat(near.shape[0], 1)
+    if jitter is None:
+        jitter = _jitter_override()
+    t = t + (torch.rand_like(t) if jitter is None else jitter.to(t.device)) * step
+    return near * (1 - t) + far * t
+
+
+def sample_from_rays_v2(rays, n_samples):
+    """src/utils.py:170-184 (imported by name in scripts/demo.py:14): rays (B,8) = [origin, direction, near, far] ->
+    stratified depths (B, n_samples).  The module-level twin of ``NeRFRenderer.sample_from_ray``."""
+    return _unit_depths(rays[:, -2:-1], rays[:, -1:], n_samples)
+
+
 def _frame(sym_flip, kitti2nusc, shapenet_obj_cood):
     """Row-major 3x3 combining, in the reference's order (src/utils.py:475-495): y mirror, KITTI->nuScenes
     (x,y,z)->(x,z,-y), nuScenes->ShapeNet (x,y,z)->(-y,x,z)."""

@@ -1,6 +1,7 @@
 """CPU tests of the host side: the C-ABI library loads and exports what the header declares, the host geometry
 matches the oracle, the product path refuses CPU tensors (no fallback), sharding / metric gather logic incl. a
 world_size-2 gloo run."""
+import inspect
 import os
 import re
 import subprocess
@@ -28,11 +29,30 @@ def test_library_exports_every_declared_symbol(amd):
     lib = amd._lib.lib()                      # loads without a GPU; no compute call is made here
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.snr_abi_version() == 4
+    assert lib.snr_abi_version() == amd._lib.header_abi_version() == int(re.search(r"SNR_ABI_VERSION (\d+)", hdr).group(1))
     assert lib.snr_packed_bytes(3, 1) == 3615264 + (2 * 32768 + 5 * 8 * 32768 + 8 * 36864 + 4 * 32768) * 2 and lib.snr_packed_bytes(9, 1) == 0
     assert lib.snr_precision_supported(1, 3, 1, 4096 * 64) == 1 and lib.snr_precision_supported(1, 5, 5, 4096 * 64) == 0
     assert lib.snr_precision_supported(1, 3, 1, 35) == 0 and lib.snr_precision_supported(0, 5, 5, 35) == 1
     assert lib.snr_mask_bytes(262144, 3, 1) == 262144 // 32 * 7 * 1024
+
+
+def test_graft_entry_build(amd):
+    """__graft_entry__.build() is what the driver runs on the CPU box: it must compile (or find up to date) the library, load it,
+    resolve every symbol and agree with the header on the ABI version."""
+    import __graft_entry__ as G
+    G.build()
+
+
+def test_sample_from_rays_v2_is_the_renderer_method(amd, golden):
+    """utils.sample_from_rays_v2 (src/utils.py:170-184, imported by scripts/demo.py:14) against the reference's numbers."""
+    g = golden("twins")
+    amd.utils.JITTER_OVERRIDE = g["sfr_jitter"]
+    try:
+        z = amd.utils.sample_from_rays_v2(g["sfr_rays"], 32)
+    finally:
+        amd.utils.JITTER_OVERRIDE = None
+    assert z.shape == g["sfr_z"].shape and float((z - g["sfr_z"]).abs().max()) < 1e-6
+    assert list(inspect.signature(amd.utils.sample_from_rays_v2).parameters) == ["rays", "n_samples"]
 
 
 def test_product_path_has_no_cpu_fallback(amd):
