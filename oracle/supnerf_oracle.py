@@ -819,3 +819,55 @@ def synthetic_targets(index: int, im_sz: int):
     mask = torch.where(r < 1.0, torch.ones_like(r), -torch.ones_like(r))
     mask = torch.where((r >= 1.0) & (r < 1.3), torch.zeros_like(r), mask)
     return img, mask[..., None]
+
+
+# --------------------------------------------------------------------------
+# KITTI-side host geometry of the cross-domain loop (src/optimizer_kitti.py:638-651)
+# --------------------------------------------------------------------------
+
+def roi_process(roi: Tensor, H: Optional[int] = None, W: Optional[int] = None, roi_margin: int = 0, sq_pad: bool = False) -> Tensor:
+    """src/utils.py:1392-1415 on an integer box [xmin, ymin, xmax, ymax], restated with python scalars: margin, square padding
+    about the centre (float centre and half size, truncated toward zero when written back into the integer box), clip to
+    [0, W-1] x [0, H-1]."""
+    integer = not roi.dtype.is_floating_point
+    x0, y0, x1, y1 = [v - roi_margin if i < 2 else v + roi_margin for i, v in enumerate(roi.tolist())]
+    if sq_pad:
+        cx, cy = np.float32(x0 + x1) / np.float32(2), np.float32(y0 + y1) / np.float32(2)
+        half = np.float64(max(x1 - x0, y1 - y0)) / 2
+        vals = [np.float32(cx - half), np.float32(cy - half), np.float32(cx + half), np.float32(cy + half)]
+        x0, y0, x1, y1 = [int(v) if integer else float(v) for v in vals]       # int(): toward zero, like the tensor write
+    if H is not None and W is not None:
+        x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, W - 1), min(y1, H - 1)
+    return torch.tensor([x0, y0, x1, y1], dtype=roi.dtype)
+
+
+def obj_pose_kitti2nusc(obj_pose: Tensor, obj_h: Tensor) -> Tensor:
+    """src/utils.py:1354-1366 without the in-place write: (B,3,4) KITTI-convention object poses -> nuScenes convention.
+    Column j of the new rotation: x stays, the new y axis is the old z (left), the new z axis is minus the old y (up); the origin
+    moves from the box bottom to the box centre (camera y points down, so T_y decreases by h/2)."""
+    R, T = obj_pose[:, :, :3], obj_pose[:, :, 3].clone()
+    T[:, 1] = T[:, 1] - obj_h / 2
+    R_new = torch.stack([R[:, :, 0], R[:, :, 2], -R[:, :, 1]], dim=-1)
+    return torch.cat([R_new, T[:, :, None]], dim=-1)
+
+
+def eval_curves(saved: dict, max_iter: int):
+    """What ``collect_eval_results`` (src/utils.py:786-880) plots from a ``codes+poses.pth`` dict: per-iteration mean PSNR (negative
+    values zeroed), lidar-count-weighted depth error, mean rotation error in degrees, mean translation error.  Infinite PSNRs and
+    NaN rotation errors are cleared the way the reference does it: it indexes the (objects, iterations) table with ``argwhere``'s
+    (row, col) PAIRS, i.e. with both numbers as ROW indices, so an offending entry at (r, c) zeroes objects r and c entirely (and
+    raises when c >= number of objects) -- restated as is."""
+    ps = np.asarray([np.array(v)[:max_iter] for v in saved["psnr_eval"].values()], dtype=np.float64)
+    for r, c in np.argwhere(np.isinf(ps)):
+        ps[r] = 0
+        ps[c] = 0
+    ps[ps < 0] = 0
+    de = np.asarray([np.array(v)[:max_iter] for v in saved["depth_err_mean"].values()], dtype=np.float64)
+    cnt = np.asarray(list(saved["lidar_pts_cnt"].values()), dtype=np.float64)
+    R = np.asarray([torch.stack(v).numpy()[:max_iter] for v in saved["R_eval"].values()], dtype=np.float64)
+    for r, c in np.argwhere(np.isnan(R)):
+        R[r] = 0
+        R[c] = 0
+    T = np.asarray([torch.stack(v).numpy()[:max_iter] for v in saved["T_eval"].values()], dtype=np.float64)
+    return ps.mean(0), (de * cnt[:, None]).sum(0) / cnt.sum(), R.mean(0) / np.pi * 180, T.mean(0)
+

@@ -26,17 +26,29 @@ import torch
 
 from . import synthetic, utils as U
 
-DEFAULT_HPAMS = {
-    "n_samples": 64, "render_im_sz": 32, "shapenet_obj_cood": 1, "sym_aug": 0, "loss_occ_coef": 0.1,
+DEFAULT_HPAMS = {     # the keys of jsonfiles/supnerf.nusc.vehicle.car.json that the loop reads
+    "n_samples": 64, "render_im_sz": 32, "roi_margin": 5, "shapenet_obj_cood": 1, "sym_aug": 0, "loss_occ_coef": 0.1,
+    "dataset": {"name": "nusc", "img_h": 900, "img_w": 1600, "mask_pixels": 2500, "max_dist": 40},
     "net_hyperparams": {"shape_blocks": 3, "texture_blocks": 1, "latent_dim": 256, "num_xyz_freq": 10, "num_dir_freq": 4},
     "optimize": {"num_opts": 100, "opt_cam_pose": 0, "lr_shape": 0.02, "lr_texture": 0.02, "lr_pose": 0.01, "lr_half_interval": 1000},
 }
 
 
-def load_hpams(path: Optional[str] = None) -> dict:
-    """Read a reference config file (jsonfiles/*.json) -- same keys, verbatim -- or the shipped defaults."""
+# jsonfiles/supnerf.kitti.car.json differs from the nuScenes file on the loop's path only in these (tests/golden/kitti.json holds
+# the reference file's values)
+KITTI_OVERRIDES = {"roi_margin": 15, "dataset": {"name": "kitti", "mask_pixels": 1600, "max_dist": 40, "min_depth": 3}}
+
+
+def load_hpams(path: Optional[str] = None, dataset: str = "nusc") -> dict:
+    """Read a reference config file (jsonfiles/*.json) -- same keys, verbatim -- or the shipped defaults of ``dataset``
+    ('nusc' | 'kitti')."""
     if path is None:
-        return json.loads(json.dumps(DEFAULT_HPAMS))
+        hp = json.loads(json.dumps(DEFAULT_HPAMS))
+        if dataset == "kitti":
+            hp.update(json.loads(json.dumps(KITTI_OVERRIDES)))
+        elif dataset != "nusc":
+            raise ValueError(f"unknown dataset {dataset!r}")
+        return hp
     with open(path) as f:
         return json.load(f)
 
@@ -376,14 +388,36 @@ def make_objects(ids: Sequence[int], im_sz: int) -> List[Dict]:
     return out
 
 
+def make_kitti_objects(ids: Sequence[int], hpams: dict) -> List[Dict]:
+    """BASELINE config 4 (src/optimizer_kitti.py:606-672): synthetic KITTI labels -> the dicts ``optimize_object`` consumes.  Per object,
+    in the reference's order: ``obj_pose_kitti2nusc`` on the KITTI-convention pose (:638), ``roi_process(roi, H, W, roi_margin, sq_pad=True)``
+    on the 2D box (:651; margin 15, clipped to the 1242 x 375 image, so truncated cars give non-square crops), the crop and its mask with the
+    background whitened (:654-658).  The camera-in-object pose the renderer wants is the inverse of the converted object pose (:751-754);
+    after that the render path is the nuScenes one (the ``kitti2nusc=`` flag of the render functions stays False)."""
+    out = []
+    margin = hpams.get("roi_margin", 15)
+    for i in ids:
+        ob = synthetic.synthetic_kitti_object(i)
+        pose_nusc = U.obj_pose_kitti2nusc(ob["obj_pose"][None].clone(), torch.tensor([float(ob["wlh"][2])]))[0]
+        R_c2o = pose_nusc[:, :3].T
+        cam_pose = torch.cat([R_c2o, -R_c2o @ pose_nusc[:, 3:]], -1)
+        roi = U.roi_process(ob["box2d"], ob["im_h"], ob["im_w"], margin, sq_pad=True)
+        h, w = int(roi[3] - roi[1]), int(roi[2] - roi[0])
+        img, mask = synthetic.synthetic_crop_targets(i, h, w)
+        img = img * (mask > 0) + (mask <= 0)
+        out.append(dict(wlh=ob["wlh"], obj_diag=np.linalg.norm(ob["wlh"]).astype(np.float32), cam_pose=cam_pose, obj_pose=pose_nusc,
+                        K=ob["K"], roi=roi, img=img, mask=mask, index=i))
+    return out
+
+
 def optimize_objects(model, device, n_objects: int, hpams: Optional[dict] = None, rank: int = 0, world_size: int = 1, seed: int = 0,
-                     group=None, batch: int = 64):
+                     group=None, batch: int = 64, dataset: str = "nusc"):
     """Shard ``n_objects`` synthetic objects over the ranks, optimise the local slice ``batch`` objects per launch
     (``batch=1``: the reference's one-object-at-a-time loop with its global random streams), all-gather the metric rows.
     Returns (n_objects, num_opts*4) on every rank."""
-    hpams = hpams or load_hpams()
+    hpams = hpams or load_hpams(dataset=dataset)
     mine = list(shard_slice(n_objects, world_size, rank))
-    objs = make_objects(mine, hpams["render_im_sz"])
+    objs = make_kitti_objects(mine, hpams) if dataset == "kitti" else make_objects(mine, hpams["render_im_sz"])
     rows = []
 
     def start_codes(index):

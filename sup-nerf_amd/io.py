@@ -56,12 +56,24 @@ def save_opts_w_pose(save_dir: str, num_obj: int, shapecodes: dict, texturecodes
     return path
 
 
-def metric_rows_to_eval_dicts(metrics: torch.Tensor, ids, cam_id: int = 0):
-    """(n_objects, num_opts*4) rows of ``driver.optimize_objects`` -> the four per-iteration metric dicts of the reference."""
+def metric_rows_to_eval_dicts(metrics: torch.Tensor, ids, cam_id: int = 0, n_lidar: int = 64):
+    """(n_objects, num_opts*4) rows of ``driver.optimize_objects`` -> the per-iteration metric dicts of the reference, with the element
+    types its reader relies on (``collect_eval_results``, src/utils.py:786-880): ``psnr_eval`` / ``depth_err_mean`` lists of floats
+    (``np.array(list)[:max_iter]``), ``R_eval`` / ``T_eval`` lists of 0-dim tensors (``torch.stack(list)``, they come from
+    ``calc_pose_err``, src/optimizer_nuscenes.py:1694-1702), ``lidar_pts_cnt`` one count per key (the weights of the depth-error mean).
+    Returns (psnr_eval, depth_err_mean, R_eval, T_eval, lidar_pts_cnt)."""
     m = metrics.view(metrics.shape[0], -1, 4).cpu()
-    psnr, depth, R, T = {}, {}, {}, {}
+    psnr, depth, R, T, cnt = {}, {}, {}, {}, {}
     for row, i in zip(m, ids):
         key = f"{i}_{cam_id}"
         psnr[key], depth[key] = row[:, 0].tolist(), row[:, 1].tolist()
-        R[key], T[key] = row[:, 2].tolist(), row[:, 3].tolist()
-    return psnr, depth, R, T
+        R[key], T[key] = list(row[:, 2].clone().unbind(0)), list(row[:, 3].clone().unbind(0))
+        cnt[key] = int(n_lidar)
+    return psnr, depth, R, T, cnt
+
+
+def save_driver_results(save_dir: str, metrics: torch.Tensor, ids, shapecodes=None, texturecodes=None, poses=None, cam_id: int = 0,
+                        n_lidar: int = 64) -> str:
+    """``driver.optimize_objects`` output -> ``codes+poses.pth`` that ``scripts/eval_saved_result.py`` plots unchanged."""
+    psnr, depth, R, T, cnt = metric_rows_to_eval_dicts(metrics, ids, cam_id, n_lidar)
+    return save_opts_w_pose(save_dir, len(list(ids)), shapecodes or {}, texturecodes or {}, poses or {}, psnr, depth, R, T, lidar_pts_cnt=cnt)

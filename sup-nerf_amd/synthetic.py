@@ -71,3 +71,51 @@ def synthetic_targets(index, im_sz):
     mask = torch.where(r < 1.0, torch.ones_like(r), -torch.ones_like(r))
     mask = torch.where((r >= 1.0) & (r < 1.3), torch.zeros_like(r), mask)
     return img, mask[..., None]
+
+
+# ------------------------------------------------------------------ KITTI-convention objects (BASELINE config 4)
+KITTI_IM_W, KITTI_IM_H = 1242, 375
+
+
+def _kitti_corners(obj_pose, wlh):
+    """The 8 box corners in the camera frame for a KITTI-convention pose (x front, y down, z left, origin at the box bottom:
+    src/utils.py:1086-1090)."""
+    w, l, h = [float(v) for v in wlh]
+    x = l / 2 * np.array([1, 1, 1, 1, -1, -1, -1, -1], dtype=np.float64)
+    y = h / 2 * np.array([-2, -2, 0, 0, -2, -2, 0, 0], dtype=np.float64)
+    z = w / 2 * np.array([1, -1, -1, 1, 1, -1, -1, 1], dtype=np.float64)
+    return obj_pose[:, :3].astype(np.float64) @ np.vstack([x, y, z]) + obj_pose[:, 3:].astype(np.float64)
+
+
+def synthetic_kitti_object(index, K=KITTI_K, im_w=KITTI_IM_W, im_h=KITTI_IM_H):
+    """Deterministic in ``index``: a car as a KITTI label would describe it (src/data_kitti.py:430-449): ``obj_pose`` (3,4) =
+    [R_y(ry) | t] with t the bottom centre of the box in the camera frame (x right, y down, z forward), ``wlh``, the tight 2D box
+    ``box2d`` int32[4] of the projected corners clipped to the 1242 x 375 image, K = a typical P2[:, :3].  The pose is still in the
+    KITTI convention: ``utils.obj_pose_kitti2nusc`` converts it on the host like src/optimizer_kitti.py:638-639."""
+    rs = np.random.RandomState(5000 + index)
+    wlh = (WLH_MEAN + WLH_STD * rs.randn(3)).astype(np.float32)
+    ry = rs.uniform(-np.pi, np.pi)
+    depth = rs.uniform(8.0, 35.0)
+    lateral = rs.uniform(-0.22, 0.22) * depth
+    c, s = np.cos(ry), np.sin(ry)
+    R_obj = np.array([[c, 0., s], [0., 1., 0.], [-s, 0., c]], dtype=np.float32)
+    t_obj = np.array([lateral, 1.65, depth], dtype=np.float32)          # camera 1.65 m above the road
+    obj_pose = np.concatenate([R_obj, t_obj[:, None]], axis=1).astype(np.float32)
+    uvw = K.astype(np.float64) @ _kitti_corners(obj_pose, wlh)
+    u, v = uvw[0] / uvw[2], uvw[1] / uvw[2]
+    box = np.array([np.floor(u.min()), np.floor(v.min()), np.ceil(u.max()), np.ceil(v.max())])
+    box = np.clip(box, [0, 0, 0, 0], [im_w - 1, im_h - 1, im_w - 1, im_h - 1]).astype(np.int32)
+    return dict(wlh=wlh, obj_pose=torch.from_numpy(obj_pose), K=torch.from_numpy(K.copy()), box2d=torch.from_numpy(box),
+                im_w=im_w, im_h=im_h)
+
+
+def synthetic_crop_targets(index, h, w):
+    """Target crop (h,w,3) in [0,1) and occupancy mask (h,w,1) in {-1,0,1} of a (possibly non-square) roi: what the KITTI loop cuts
+    out of the image and its instance mask (src/optimizer_kitti.py:651-656) before ``render_rays_v2`` resizes it."""
+    g = torch.Generator().manual_seed(7000 + index)
+    img = torch.rand(h, w, 3, generator=g)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, h), torch.linspace(-1, 1, w), indexing="ij")
+    r = (xx / 0.8) ** 2 + (yy / 0.6) ** 2
+    mask = torch.where(r < 1.0, torch.ones_like(r), -torch.ones_like(r))
+    mask = torch.where((r >= 1.0) & (r < 1.3), torch.zeros_like(r), mask)
+    return img, mask[..., None]

@@ -373,3 +373,51 @@ def ray_box_intersection(ray_o, ray_d, aabb_min=None, aabb_max=None):
     if hit.shape[0] == 0:
         return None, None, None
     return t_near[hit], t_far[hit], hit
+
+
+# ------------------------------------------------------------------------------------ dataset-side geometry on the loop's path
+def roi_process(roi, H=None, W=None, roi_margin=0, sq_pad=False):
+    """src/utils.py:1392-1415: grow the 2D box [xmin, ymin, xmax, ymax] by ``roi_margin``, optionally pad the shorter side to a
+    square about the centre, then clip to the image (truncated objects end up non-square).  Integer tensors stay integer: the
+    centre and half size are computed in the tensor's dtype exactly like the reference's in-place writes (float results are
+    truncated toward zero on assignment)."""
+    out = roi.clone()
+    out[0:2] -= roi_margin
+    out[2:4] += roi_margin
+    if sq_pad:
+        cx, cy = (out[0] + out[2]) / 2, (out[1] + out[3]) / 2
+        sz = np.maximum(out[2] - out[0], out[3] - out[1])
+        out[0], out[2] = cx - sz / 2, cx + sz / 2
+        out[1], out[3] = cy - sz / 2, cy + sz / 2
+    if H is not None and W is not None:
+        out[0:2] = torch.maximum(out[0:2], torch.as_tensor(0))
+        out[2] = torch.minimum(out[2], torch.as_tensor(W - 1))
+        out[3] = torch.minimum(out[3], torch.as_tensor(H - 1))
+    return out
+
+
+_KITTI2NUSC_RX = np.array([[1., 0., 0.], [0., 0., -1.], [0., 1., 0.]], dtype=np.float32)
+
+
+def obj_pose_kitti2nusc(obj_pose_src, obj_h):
+    """src/utils.py:1354-1366, called by src/optimizer_kitti.py:638-639: KITTI object poses (B,3,4) (x front, y down, z left, origin
+    at the box bottom) -> the nuScenes convention the renderer is trained in: the origin moves up by h/2 (T_y -= h/2) and the axes
+    turn by R <- R R_x.  Like the reference it writes the shifted translation back into ``obj_pose_src`` (its ``pose_T`` is a view)."""
+    pose_T = obj_pose_src[:, :, 3:]
+    pose_T[:, 1, 0] -= (obj_h / 2)
+    R_x = torch.from_numpy(_KITTI2NUSC_RX).unsqueeze(0).repeat(obj_pose_src.shape[0], 1, 1)
+    return torch.cat([torch.matmul(obj_pose_src[:, :, :3], R_x), pose_T], dim=-1)
+
+
+def rot_dist(R1, R2):
+    """src/utils.py:713-722: geodesic angle between rotations (B,3,3) -> (B,)."""
+    d = torch.matmul(R1, torch.transpose(R2, -1, -2))
+    trace = d.diagonal(dim1=-2, dim2=-1).sum(-1)
+    return torch.acos((trace.clamp(-1, 3) - 1) / 2)
+
+
+def calc_pose_err(est_poses, tgt_poses):
+    """src/utils.py:675-683: rotation (rad) and translation (m) errors of (B,3,4) poses."""
+    err_R = rot_dist(est_poses[:, :3, :3], tgt_poses[:, :3, :3])
+    err_T = torch.sqrt(torch.sum((est_poses[:, :3, 3] - tgt_poses[:, :3, 3]) ** 2, dim=-1))
+    return err_R, err_T

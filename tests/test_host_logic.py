@@ -371,8 +371,71 @@ def test_reference_file_formats_round_trip(amd, tmp_path):
     assert torch.equal(ms, sc[[0, 2, 3]].mean(0, keepdim=True)) and torch.equal(mt, tc[[0, 2, 3]].mean(0, keepdim=True))
     assert all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), list(m.state_dict().values())[:28]))
     rows = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 12)
-    ps, de, R, T = amd.io.metric_rows_to_eval_dicts(rows, [10, 11])
-    out = amd.io.save_opts_w_pose(str(tmp_path / "res"), 2, {}, {}, {}, ps, de, R, T)
-    d = torch.load(out, weights_only=False)
-    assert d["psnr_eval"]["10_0"] == [0.0, 4.0, 8.0] and d["T_eval"]["11_0"] == [15.0, 19.0, 23.0]
+    ps, de, R, T, cnt = amd.io.metric_rows_to_eval_dicts(rows, [10, 11])
+    out = amd.io.save_opts_w_pose(str(tmp_path / "res"), 2, {}, {}, {}, ps, de, R, T, lidar_pts_cnt=cnt)
+    d = torch.load(out)                  # plain containers + tensors: loads under the default (weights_only) reader, like the reference's call
+    assert d["psnr_eval"]["10_0"] == [0.0, 4.0, 8.0] and [float(t) for t in d["T_eval"]["11_0"]] == [15.0, 19.0, 23.0]
+    assert all(torch.is_tensor(t) and t.dim() == 0 for t in d["R_eval"]["10_0"]) and d["lidar_pts_cnt"]["11_0"] == 64
     assert set(d) >= {"num_obj", "optimized_shapecodes", "optimized_texturecodes", "optimized_poses", "psnr_eval", "depth_err_mean", "R_eval", "T_eval"}
+
+
+def test_file_formats_against_the_reference_reader(amd, golden, tmp_path):
+    """tests/golden/formats.npz holds what the REFERENCE's code made of our files (gen_golden_r2.py): the curves its
+    collect_eval_results (src/utils.py:786) plotted from a codes+poses.pth written by io.save_driver_results, and the mean codes its
+    load_model formulas (src/optimizer_nuscenes.py:1799-1808) derive from a checkpoint built like save_models
+    (src/trainer_unified_nuscenes.py:476-490) with real nn.Embedding state dicts."""
+    g = golden("formats")
+    rows, ids = g["eval_rows"], g["eval_ids"].tolist()
+    path = amd.io.save_driver_results(str(tmp_path / "res"), rows.reshape(rows.shape[0], -1), ids, n_lidar=64)
+    saved = torch.load(path, map_location=torch.device("cpu"))
+    assert sorted(saved["psnr_eval"]) == sorted(f"{i}_0" for i in ids)
+    for a, k in zip(O.eval_curves(saved, rows.shape[1]), ("eval_psnr", "eval_depth", "eval_R_deg", "eval_T")):
+        assert np.allclose(a, g[k].numpy(), rtol=0, atol=1e-12), k
+    # checkpoint in the reference's own shape -> our loader
+    n_inst = g["ck_optimized_idx"].shape[0]
+    torch.manual_seed(int(g["ck_seed"]))
+    shape_codes, texture_codes = torch.nn.Embedding(n_inst, 256), torch.nn.Embedding(n_inst, 256)
+    assert torch.equal(shape_codes.weight[0], g["ck_shape_row0"])
+    ref_like = amd.CodeNeRF(3, 1); ref_like.load_state_dict(O.init_decoder_params())
+    ck = str(tmp_path / "models.pth")
+    torch.save({"model_params": ref_like.state_dict(), "shape_code_params": shape_codes.state_dict(), "texture_code_params": texture_codes.state_dict(),
+                "niter": int(g["ck_niter"]), "nepoch": int(g["ck_nepoch"]), "instoken2idx": {f"tok{i}": i for i in range(n_inst)},
+                "optimized_idx": g["ck_optimized_idx"]}, ck)
+    m = amd.CodeNeRF(3, 1)
+    ms, mt, saved, _ = amd.io.load_checkpoint(ck, m, strict=True)
+    assert torch.equal(ms, g["ck_mean_shape"]) and torch.equal(mt, g["ck_mean_texture"]) and saved["niter"] == 1234
+    with torch.no_grad():      # the decoder those weights + mean codes define (the reference's own forward on our checkpoint)
+        s_or, c_or = O.decoder_forward(dict(m.state_dict()), g["ck_probe_xyz"], g["ck_probe_viewdir"], ms, mt)
+    assert torch.equal(s_or, g["ck_probe_sigma"]) and torch.equal(c_or, g["ck_probe_rgb"])
+
+
+def test_kitti_host_geometry(amd, golden):
+    """utils.obj_pose_kitti2nusc / roi_process / sample_from_rays_v2 / calc_pose_err against the reference's numbers, the KITTI object
+    generator against the fixture, and the shipped hyper-parameters against the values of the reference's json files."""
+    import json
+    g = golden("kitti")
+    src = g["k2n_in"].clone()
+    assert torch.equal(amd.utils.obj_pose_kitti2nusc(src, g["k2n_h"]), g["k2n_out"])
+    assert torch.equal(src, g["k2n_in_after"])                      # same in-place write as the reference
+    for b, H, W, mg, sq, want in zip(g["roi_in"], g["roi_H"], g["roi_W"], g["roi_margin"], g["roi_sq"], g["roi_out"]):
+        got = amd.utils.roi_process(b, None if H < 0 else int(H), None if W < 0 else int(W), int(mg), sq_pad=bool(sq))
+        assert torch.equal(got, want) and got.dtype == want.dtype
+    assert torch.equal(amd.utils.roi_process(g["roi_float_in"], 375, 1242, 15, sq_pad=True), g["roi_float_out"])
+    amd.utils.JITTER_OVERRIDE = g["sfr2_jitter"]
+    try:
+        assert torch.equal(amd.utils.sample_from_rays_v2(g["sfr2_rays"], 16), g["sfr2_z"])
+    finally:
+        amd.utils.JITTER_OVERRIDE = None
+    eR, eT = amd.utils.calc_pose_err(g["perr_est"], g["perr_tgt"])
+    assert float((eR - g["perr_R"]).abs().max()) < 1e-6 and float((eT - g["perr_T"]).abs().max()) < 1e-6
+    ob = amd.driver.make_kitti_objects([int(g["e2e_index"])], amd.driver.load_hpams(dataset="kitti"))[0]
+    assert torch.equal(ob["roi"], g["e2e_roi"]) and torch.equal(ob["cam_pose"], g["e2e_cam_pose"])
+    ref_cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "kitti.json")))
+    for tag in ("kitti", "nusc"):
+        hp = amd.driver.load_hpams(dataset=tag)
+        for k, v in ref_cfg[tag].items():
+            if isinstance(v, dict):
+                assert all(hp[k][kk] == vv for kk, vv in v.items() if kk in hp[k]), (tag, k)
+                assert k != "optimize" or set(v) == set(hp[k])
+            else:
+                assert hp[k] == v, (tag, k, hp[k], v)

@@ -263,3 +263,40 @@ def test_render_api_twins(golden, oracle_params):
     same(vr[0], g["vr_out_rgb"]); same(vr[1], g["vr_out_depth"]); same(vr[2], g["vr_out_acc"])
     vb = O.composite(g["vrb_sig"], g["vrb_rgb"], g["vrb_z"], white_bkgd=False)
     same(vb[0], g["vrb_out_rgb"]); same(vb[1], g["vrb_out_depth"]); same(vb[2], g["vrb_out_acc"])
+
+
+# ------------------------------------------------------------------ round-2 fixtures (tests/golden/gen_golden_r2.py)
+def test_kitti_pose_convention_and_roi(golden):
+    g = golden("kitti")
+    assert torch.equal(O.obj_pose_kitti2nusc(g["k2n_in"], g["k2n_h"]), g["k2n_out"])
+    for b, H, W, m, sq, want in zip(g["roi_in"], g["roi_H"], g["roi_W"], g["roi_margin"], g["roi_sq"], g["roi_out"]):
+        got = O.roi_process(b, None if H < 0 else int(H), None if W < 0 else int(W), int(m), bool(sq))
+        assert torch.equal(got, want), (b.tolist(), int(H), int(W), int(m), int(sq), got.tolist(), want.tolist())
+    assert torch.equal(O.unit_interval_samples(g["sfr2_rays"][:, 6:7], g["sfr2_rays"][:, 7:8], 16, g["sfr2_jitter"]), g["sfr2_z"])
+
+
+def test_kitti_object_end_to_end(golden, oracle_params):
+    """render_rays_v2 on a truncated KITTI car whose crop is not im_sz^2: bilinear resize + int32 mask truncation + render."""
+    g = golden("kitti")
+    import supnerf_amd as A                       # host-side object generator only (no compute)
+    ob = A.driver.make_kitti_objects([int(g["e2e_index"])], A.driver.load_hpams(dataset="kitti"))[0]
+    assert torch.equal(ob["roi"], g["e2e_roi"]) and torch.equal(ob["cam_pose"], g["e2e_cam_pose"])
+    with torch.no_grad():
+        out = O.render_rays_v2(oracle_params, ob["img"], ob["mask"], ob["cam_pose"], ob["obj_diag"], ob["K"], ob["roi"], 64, g["e2e_shapecode"],
+                               g["e2e_texturecode"], True, im_sz=16, jitter=g["e2e_jitter"])
+    for a, k in zip(out, ("e2e_rgb", "e2e_depth", "e2e_acc", "e2e_tgt", "e2e_occ")):
+        assert torch.equal(a, g[k]), k
+
+
+def test_eval_reader_restatement(golden):
+    """O.eval_curves == what the reference's collect_eval_results plotted from a file written by supnerf_amd.io."""
+    g = golden("formats")
+    rows = g["eval_rows"]
+    saved = {"psnr_eval": {}, "depth_err_mean": {}, "lidar_pts_cnt": {}, "R_eval": {}, "T_eval": {}}
+    for r, i in zip(rows, g["eval_ids"].tolist()):
+        k = f"{i}_0"
+        saved["psnr_eval"][k], saved["depth_err_mean"][k] = r[:, 0].tolist(), r[:, 1].tolist()
+        saved["R_eval"][k], saved["T_eval"][k], saved["lidar_pts_cnt"][k] = list(r[:, 2].unbind(0)), list(r[:, 3].unbind(0)), 64
+    for a, k in zip(O.eval_curves(saved, rows.shape[1]), ("eval_psnr", "eval_depth", "eval_R_deg", "eval_T")):
+        assert np.allclose(a, g[k].numpy(), rtol=0, atol=1e-12), k
+
