@@ -1,23 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- rays/s of the fused render hot path at BASELINE.json's configuration.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                 (driver contract; --precision fp32 | bf16x3, --workload c2 | c3)
     (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-One *step* = one fused forward pass (sample -> frame transform -> positional encoding -> decoder -> composite) over
-one object's ray batch: 4096 rays x 64 samples (BASELINE configs[1]: supnerf.nusc.vehicle.car.json hyper-parameters,
-im_sz 64, synthetic nuScenes-like car, random-init decoder with the sigma bias of SURVEY 8d), inputs resident in
-HBM.  Every rank renders its own object (objects are independent: weak scaling, no data-path collective); the only
-collective is the max-reduce of the elapsed time.  Rank 0 prints ONE JSON line.
+Default workload (BASELINE configs[1], "c2"): one *step* = one fused forward pass (sample -> frame transform -> positional encoding ->
+decoder -> composite) over one object's ray batch, 4096 rays x 64 samples (supnerf.nusc.vehicle.car.json hyper-parameters, im_sz 64,
+synthetic nuScenes-like car, random-init decoder with the sigma bias of SURVEY 8d), inputs resident in HBM.  Every rank renders its own
+object (objects are independent: weak scaling, no data-path collective); the only collective is the max-reduce of the elapsed time.
+Rank 0 prints ONE JSON line.
 
-Extra legs that are reported but are NOT `value`:
-  * forward+backward (codes + pose gradients) rays/s, the optimiser's inner iteration;
-  * `roofline`: algorithmic FLOPs (57.56 MFLOP/ray) / kernel time from device events on the
-    launch stream, against the fp32-matrix peak of MI355X_MICROARCH.md (157.3 TFLOP/s);
-  * `cpu_baseline`: the CPU oracle (pure PyTorch restatement of the reference, oracle/) timed on this host's cores
-    over a bounded sample, plus the parity numbers (PSNR delta, depth L1) of the GPU output against it.
+`value` is measured in the REFERENCE's arithmetic: exact fp32 (v_mfma_f32_32x32x2_f32, bit for bit an fp32 fma chain), `--precision fp32`.
+The library's default arithmetic, split-bf16 ("bf16x3": operands carried as bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate)
+is wall-clocked by the SAME loop and reported beside it under `bf16x3` with its own parity numbers and roofline -- it is narrower
+arithmetic than the reference's and therefore not the headline.
+
+Reported beside `value` (never part of it):
+  * `roofline` (forward kernel of the headline precision) and `roofline_bwd` (its backward kernel): algorithmic FLOPs (57.56 MFLOP/ray
+    forward; the same again for the optimise-mode backward, dX only -- BASELINE.md section 4) / kernel time from device events on the
+    launch stream, against the matching MFMA peak of MI355X_MICROARCH.md; `traffic` = HBM bytes per launch from the committed counter
+    profile of the same kernel (profiles/, read at run time; null when no profile of this round exists);
+  * `api`: the public functions end to end (`utils.render_rays_v2`: ray generation, target resize, depths, per-object layers, render),
+    forward and forward + backward to codes and pose;
+  * `optimise_loop`: one object through the fused loop / the API-structured loop / the HIP-graph-replayed loop; `c3_sharded`: BASELINE
+    config 3, 64 objects sharded over the ranks through driver.optimize_objects_batched + the metric all_gather;
+  * `training_step`: BASELINE config 5's per-GPU step (8 objects x 1024 rays x 64 samples, decoder + codes trained);
+  * `cpu_baseline`: the CPU oracle (oracle/, a PyTorch restatement of the reference pinned by the reference's own outputs) on this host's
+    cores over the whole 4096-ray workload, with the parity of both GPU precisions against it.
+
+`--workload c3` makes BASELINE config 3 the timed thing: one step = one optimise iteration (forward + backward + depth render + AdamW)
+over the rank's shard of 64 objects x 4096 rays x 64 samples; value = rays of the training forward per second over all ranks (strong
+scaling: the 64 objects are fixed), the per-object metric rows are all-gathered at the end.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -29,12 +45,29 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_RAY = 57.56e6          # forward, S = 64
-# HBM bytes per 4096x64 forward launch from the committed counter profile (cannot be collected from inside this process)
-HBM_TRAFFIC = {"bf16x3": 16020480.0, "fp32": None}
+FLOP_PER_RAY = 57.56e6          # forward, S = 64; optimise-mode backward (dX only): the same again
 PEAK_TFLOPS = {"fp32": 157.3,    # MI355X_MICROARCH.md "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f32
                "bf16x3": 2500.0}  # dense BF16 MFMA peak; the split-bf16 path issues 3 MFMAs per algorithmic product
+ISSUE_FACTOR = {"fp32": 1.0, "bf16x3": 3.0}
+DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)"}
+FWD_KERNEL = {"fp32": "decoder_fwd_kernel<1>", "bf16x3": "bf16_fwd_kernel<1,false,true>"}
+BWD_KERNEL = {"fp32": "decoder_bwd_kernel<1>", "bf16x3": "bf16_bwd_kernel<1>"}
 N_RAYS, N_SAMPLES, IM_SZ = 4096, 64, 64
+C3_OBJECTS = 64
+
+
+def profile_traffic(precision, which="fwd"):
+    """HBM bytes per launch of the dominant kernel from the newest committed counter profile of this kernel (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes; FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md).  The counters cannot be collected from
+    inside this process; the file is read at run time so the figure follows the profile, and its name is reported with it."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{which}_pmc_{precision}.json")))
+    if not files:
+        return None, None
+    try:
+        c = json.load(open(files[-1]))["counters"]
+        return c["FETCH_SIZE"]["per_dispatch_mean"] * 1024.0 * 2 + c["WRITE_SIZE"]["per_dispatch_mean"] * 1024.0, os.path.relpath(files[-1], ROOT)
+    except (KeyError, ValueError, OSError):
+        return None, None
 
 
 def make_workload(dev, seed):
@@ -54,6 +87,88 @@ def make_workload(dev, seed):
     return dict(model=model, params=params, ob=ob, img=img, mask=mask, sc=sc, tc=tc, jit=jit)
 
 
+class Clock:
+    """The contract's timing: barrier + synchronize on both sides, MAX over ranks."""
+
+    def __init__(self, dist, dev):
+        self.dist, self.dev = dist, dev
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def wall(self, fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    @staticmethod
+    def events(fn, steps):
+        """Average duration from device events on the launch stream (torch's current stream IS the stream the C ABI launches on)."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+
+def roofline(precision, kern_ms, which):
+    achieved = N_RAYS * FLOP_PER_RAY / (kern_ms * 1e-3) / 1e12
+    traffic, src = profile_traffic(precision, which)
+    return {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[precision],
+            "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": src,
+            "kernel": (FWD_KERNEL if which == "fwd" else BWD_KERNEL)[precision], "kernel_ms": kern_ms, "flop_per_launch": N_RAYS * FLOP_PER_RAY,
+            "mfma_pipe_frac": ISSUE_FACTOR[precision] * achieved / PEAK_TFLOPS[precision],
+            "note": "achieved = ALGORITHMIC flops (57.56 MFLOP/ray" + (", optimise-mode backward = dX only: the same count" if which == "bwd" else "")
+                    + ") / kernel time from device events; bf16x3 issues 3x that on the bf16 MFMA pipe (mfma_pipe_frac)"}
+
+
+def c3_leg(model, dev, rank, world, dist, clock, n_it, warm=True):
+    """BASELINE config 3: 64 objects x 4096 x 64, object-sharded (driver.shard_slice), every rank optimises its slice in one launch per
+    iteration, then ONE all_gather of the metric rows (the only collective).  Returns (seconds for n_it iterations [max over ranks], rows)."""
+    from supnerf_amd import driver as D
+    hp = D.load_hpams()
+    hp["render_im_sz"] = IM_SZ
+    mine = list(D.shard_slice(C3_OBJECTS, world, rank))
+    objs = D.make_objects([200 + i for i in mine], IM_SZ)
+    gl = torch.Generator().manual_seed(3)
+    sc_all, tc_all = torch.randn(C3_OBJECTS, 256, generator=gl) * 0.3, torch.randn(C3_OBJECTS, 256, generator=gl) * 0.3
+    sc_l, tc_l = sc_all[mine], tc_all[mine]
+    if warm and objs:
+        hp["optimize"]["num_opts"] = 2
+        D.optimize_objects_batched(model, dev, objs[:2], hp, sc_l[:2], tc_l[:2], mine[:2])
+    hp["optimize"]["num_opts"] = n_it
+    clock.barrier()
+    t0 = time.perf_counter()
+    if objs:
+        m, *_ = D.optimize_objects_batched(model, dev, objs, hp, sc_l, tc_l, mine)
+        local = m.reshape(len(objs), -1)
+    else:
+        local = torch.zeros(0, n_it * 4, device=dev)
+    rows = D.gather_metric_rows(local.to(dev), torch.tensor(mine, device=dev, dtype=torch.float32), C3_OBJECTS)
+    clock.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, rows, len(mine)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,10 +176,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
-                    help="only the headline launches (no other-precision / forward+backward / optimise-loop / HBM-kernel legs): the form "
-                         "profiled for profiles/*_bench_kernel_stats.csv, so the per-kernel average there is the headline kernel alone")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
-                    help="decoder GEMM arithmetic of the headline run (the other mode is timed too and reported under 'extra')")
+                    help="only the headline launches (no other legs): the form profiled for profiles/*_bench_kernel_stats.csv, so the "
+                         "per-kernel average there is the headline kernel alone")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="decoder GEMM arithmetic of the headline `value` (default: the reference's fp32; the other mode is wall-clocked by the "
+                         "same loop and reported beside it)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+                    help="c2: fused forward of one object per GPU (BASELINE configs[1], weak scaling); c3: the optimise iteration over 64 objects "
+                         "sharded across the GPUs (BASELINE configs[2], strong scaling)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,14 +199,33 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+    clock = Clock(dist, dev)
 
     import supnerf_amd as A
     from supnerf_amd import ops, utils as U
     w = make_workload(dev, seed=100 + rank)
     model, ob = w["model"], w["ob"]
+    prec, other = args.precision, ("bf16x3" if args.precision == "fp32" else "fp32")
+
+    if args.workload == "c3":
+        model.precision = prec
+        n_it = max(2, min(args.steps, 8))
+        dt, rows, n_mine = c3_leg(model, dev, rank, world, dist, clock, n_it)
+        res = {"metric": "rays/sec, optimise iteration (fwd + bwd + depth render + AdamW) over 64 objects x 4096 rays x 64 samples, object-sharded",
+               "value": C3_OBJECTS * N_RAYS * n_it / dt, "unit": "rays/s", "n_gpus": world, "steps": n_it, "warmup": 2, "ms_per_step": dt / n_it * 1e3,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE[prec], "data": "synthetic",
+               "config": {"workload": "BASELINE configs[2]: 64 synthetic nuScenes-like cars, 4096 rays x 64 samples each, contiguous object shards "
+                                      "(driver.shard_slice), one launch per iteration and rank, one all_gather of the metric rows at the end",
+                          "objects": C3_OBJECTS, "objects_this_rank": n_mine, "precision": prec},
+               "object_iterations_per_s": C3_OBJECTS * n_it / dt, "metric_rows_finite": bool(torch.isfinite(rows).all())}
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
 
     # ---- device-resident inputs of the hot path (ray generation is outside the path's timed region: it is part of the
-    # caller-side glue and costs microseconds)
+    # caller-side glue and costs microseconds; the `api` leg times it)
     with torch.no_grad():
         rays_o, viewdir = U.get_rays(ob["K"], ob["cam_pose"].to(dev), ob["roi"], uv_steps=[IM_SZ, IM_SZ])
         near, far = U._sphere_bounds(ob["cam_pose"], ob["obj_diag"])
@@ -95,191 +233,182 @@ def main():
         lat = model.latent_terms(w["sc"], w["tc"])
     packed = model.packed_weights()
     div = torch.full((1,), float(ob["obj_diag"]), device=dev)
-    cfg = ops.RenderCfg(N_SAMPLES, ops.Z_SHARED, N_RAYS, 3, 1, frame=U._frame(False, False, True), precision=args.precision)
-    other = "fp32" if args.precision == "bf16x3" else "bf16x3"
-    cfg_other = ops.RenderCfg(N_SAMPLES, ops.Z_SHARED, N_RAYS, 3, 1, frame=U._frame(False, False, True), precision=other)
-    # like model.fused_render: the latent terms also folded into the next layers' biases (prepared beside the latent terms, outside the path)
-    cfg.latent_bias = cfg_other.latent_bias = model.latent_biases(lat)
-    model.precision = args.precision
+    frame = U._frame(False, False, True)
+    cfgs = {p: ops.RenderCfg(N_SAMPLES, ops.Z_SHARED, N_RAYS, 3, 1, frame=frame, precision=p) for p in ("fp32", "bf16x3")}
+    for c in cfgs.values():      # like model.fused_render: the latent terms also folded into the next layers' biases (bf16x3 uses them)
+        c.latent_bias = model.latent_biases(lat)
     assert rays_o.shape[0] == N_RAYS
+    outs = {}
 
-    def step(c=cfg):
-        return ops.render_fwd(rays_o, viewdir, z, div, None, lat, packed, c)
+    def step(p):
+        outs[p] = ops.render_fwd(rays_o, viewdir, z, div, None, lat, packed, cfgs[p])
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- headline: the contract's wall clock around EXACTLY --steps launches, in the reference's arithmetic unless asked otherwise
+    elapsed = clock.wall(lambda: step(prec), args.steps, args.warmup)
     value = world * N_RAYS * args.steps / elapsed
-
-    # ---- kernel time from device events on the launch stream (torch's current stream IS the launch stream)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(args.steps):
-        out = step()
-    e1.record()
-    torch.cuda.synchronize()
-    kern_ms = e0.elapsed_time(e1) / args.steps
-    achieved = N_RAYS * FLOP_PER_RAY / (kern_ms * 1e-3) / 1e12
-    other_ms, other_tf, fwd_bwd_rays, fb_elapsed, n_fb, loop, hbm = None, None, None, None, 1, {}, {}
-    if not args.headline_only:
-        # the other arithmetic mode, same launches (reported, not the headline)
-        for _ in range(5):
-            step(cfg_other)
-        torch.cuda.synchronize()
-        e0.record()
-        n_other = max(10, args.steps // 4)
-        for _ in range(n_other):
-            out_other = step(cfg_other)
-        e1.record()
-        torch.cuda.synchronize()
-        other_ms = e0.elapsed_time(e1) / n_other
-        other_tf = N_RAYS * FLOP_PER_RAY / (other_ms * 1e-3) / 1e12
-
-        # ---- forward + backward leg (the optimiser's inner iteration: gradients wrt codes and pose)
-        sc_g, tc_g = w["sc"].clone().requires_grad_(), w["tc"].clone().requires_grad_()
-        pose_g = ob["cam_pose"].to(dev).requires_grad_()
-        tgt = w["img"].reshape(-1, 3).to(dev)
-
-        def step_fb():
-            ro, vd = U.get_rays(ob["K"], pose_g, ob["roi"], uv_steps=[IM_SZ, IM_SZ])
-            rgb, depth, acc = model.fused_render(ro, vd, z, div, None, sc_g, tc_g, cfg)
-            loss = ((rgb - tgt) ** 2).mean() + 0.1 * acc.mean()
-            sc_g.grad = tc_g.grad = pose_g.grad = None
-            loss.backward()
-
-        for _ in range(3):
-            step_fb()
-        barrier()
-        n_fb = max(10, args.steps // 4)
-        t0 = time.perf_counter()
-        for _ in range(n_fb):
-            step_fb()
-        barrier()
-        fb_elapsed = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([fb_elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            fb_elapsed = float(t.item())
-        fwd_bwd_rays = world * N_RAYS * n_fb / fb_elapsed
-
-        # ---- BASELINE config 3 in one process: the optimise loop over 64 objects, all of them in one launch per iteration
-        loop = {}
-        if rank == 0 and world == 1:      # (single-GPU runs only: at N > 1 every rank does the same work and leaves together)
-            from supnerf_amd import driver as D
-            hp = D.load_hpams()
-            hp["render_im_sz"] = IM_SZ
-            n_obj, n_it = 64, 4
-            hp["optimize"]["num_opts"] = n_it
-            objs = D.make_objects(list(range(200, 200 + n_obj)), IM_SZ)
-            gl = torch.Generator().manual_seed(3)
-            sc_l, tc_l = torch.randn(n_obj, 256, generator=gl) * 0.3, torch.randn(n_obj, 256, generator=gl) * 0.3
-            D.optimize_objects_batched(model, dev, objs[:8], hp, sc_l[:8], tc_l[:8], list(range(8)))          # warm-up
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            D.optimize_objects_batched(model, dev, objs, hp, sc_l, tc_l, list(range(n_obj)))
-            torch.cuda.synchronize()
-            t_b = time.perf_counter() - t0
-            n_it1 = 50                                   # the reference runs 100 iterations per object: amortise the set-up alike
-            hp["optimize"]["num_opts"] = n_it1
-            t0 = time.perf_counter()
-            D.optimize_object(model, dev, objs[0], hp, sc_l[:1], tc_l[:1], seed=0)
-            torch.cuda.synchronize()
-            t_1 = time.perf_counter() - t0
-            t0 = time.perf_counter()                     # the same object through the batched loop replayed as a HIP graph
-            D.optimize_objects_batched(model, dev, objs[:1], hp, sc_l[:1], tc_l[:1], [0], graph=True)
-            torch.cuda.synchronize()
-            t_g = time.perf_counter() - t0
-            loop = {"objects": n_obj, "iterations": n_it, "rays_per_object": N_RAYS,
-                    "batched_ms_per_iteration": t_b / n_it * 1e3, "batched_object_iterations_per_s": n_obj * n_it / t_b,
-                    "batched_rays_per_s_fwd_bwd_plus_depth_render": n_obj * n_it * N_RAYS / t_b,
-                    "one_object_loop_ms_per_iteration": t_1 / n_it1 * 1e3, "one_object_loop_object_iterations_per_s": n_it1 / t_1,
-                    "one_object_loop_iterations": n_it1,
-                    "one_object_hip_graph_ms_per_iteration": t_g / n_it1 * 1e3, "one_object_hip_graph_object_iterations_per_s": n_it1 / t_g,
-                    "note": "iteration = fused forward + backward (codes, pose) + 64-pixel depth render + AdamW; the batched loop runs all objects "
-                            "in one launch each and never syncs with the host; the one-object loop is the reference's structure; 'hip_graph' = the batched loop at one object with the iteration "
-                            "recorded once (two graphs) and replayed (set-up and recording included everywhere)"}
-            del objs
-
-        # ---- the two HBM-bound stand-alone kernels (encode with PE output, composite) at 16 objects x 4096 x 64: achieved GB/s
-        hbm = {}
-        if rank == 0 and world == 1:
-            Bh = 64
-            ro_h, vd_h = rays_o.repeat(Bh, 1), viewdir.repeat(Bh, 1)
-            z_h = z[None].repeat(Bh, 1).contiguous()
-            div_h = div.repeat(Bh)
-            cfg_h = ops.RenderCfg(N_SAMPLES, ops.Z_PER_OBJECT, N_RAYS, 3, 1, frame=U._frame(False, False, True))
-            P_h = Bh * N_RAYS * N_SAMPLES
-
-            def timed(fn, n=10):
-                for _ in range(2):
-                    fn()
-                torch.cuda.synchronize()
-                e0.record()
-                for _ in range(n):
-                    fn()
-                e1.record()
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1) / n * 1e-3
-            t_enc = timed(lambda: ops.encode(ro_h, vd_h, z_h, div_h, None, cfg_h, want_pe=True))
-            enc_bytes = P_h * (12 + 12 + 4 + 63 * 4) + Bh * N_RAYS * (24 + 27 * 4)          # xyz, viewdir, z, PE(xyz) per point; rays in, PE(dir) out
-            sig_h = torch.rand(Bh * N_RAYS, N_SAMPLES, device=dev)
-            rgb_h = torch.rand(Bh * N_RAYS, N_SAMPLES, 3, device=dev)
-            t_cmp = timed(lambda: ops.composite_fwd(sig_h, rgb_h, z_h, ops.Z_PER_OBJECT, False, N_RAYS))
-            cmp_bytes = P_h * 16 + Bh * N_RAYS * 20
-            # scene composite (vis_scene): 131072 pixels x 3 objects x 64 samples, depth merge + composite
-            P_s, n_s = 131072, 3 * N_SAMPLES
-            z_s = (torch.rand(P_s, 3, 1, device=dev) * 20 + 2 + torch.sort(torch.rand(P_s, 3, N_SAMPLES, device=dev), dim=-1)[0] * 4).view(P_s, n_s)
-            sig_s, rgb_s = torch.rand(P_s, n_s, device=dev), torch.rand(P_s, n_s, 3, device=dev)
-            t_scn = timed(lambda: ops.scene_composite(sig_s, rgb_s, z_s, True))
-            scn_bytes = P_s * n_s * 20 + P_s * 20
-            del z_s, sig_s, rgb_s
-            hbm = {"encode": {"GB_per_s": enc_bytes / t_enc / 1e9, "ms": t_enc * 1e3, "bytes": enc_bytes, "frac_of_8TBps": enc_bytes / t_enc / 8e12},
-                   "scene_composite": {"GB_per_s": scn_bytes / t_scn / 1e9, "ms": t_scn * 1e3, "bytes": scn_bytes, "frac_of_8TBps": scn_bytes / t_scn / 8e12,
-                                       "shape": f"{P_s} pixels x 3 objects x {N_SAMPLES} samples"},
-                   "composite_fwd": {"GB_per_s": cmp_bytes / t_cmp / 1e9, "ms": t_cmp * 1e3, "bytes": cmp_bytes, "frac_of_8TBps": cmp_bytes / t_cmp / 8e12},
-                   "shape": f"{Bh} objects x {N_RAYS} rays x {N_SAMPLES} samples"}
-            del sig_h, rgb_h
-
+    kern_ms = clock.events(lambda: step(prec), args.steps)
     result = {
         "metric": "rays/sec at 4096 rays x 64 samples (fused render forward)",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)",
-        "data": "synthetic",
+        "dtype": DTYPE[prec], "data": "synthetic",
         "config": {"workload": "supnerf.nusc.vehicle.car.json decoder (shape_blocks 3, texture_blocks 1, W 256), 1 object per GPU, "
-                               "4096 rays x 64 samples, family-A render (render_rays_v2 tail)", "precision": args.precision,
+                               "4096 rays x 64 samples, family-A render (render_rays_v2 tail)", "precision": prec,
                    "rays": N_RAYS, "samples": N_SAMPLES, "objects_per_gpu": 1, "sharding": "objects across ranks, no data-path collective"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": HBM_TRAFFIC.get(args.precision),
-                     "traffic_unit": "bytes per launch", "traffic_source": "profiles/r01_v7_fwd_pmc.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) "
-                                                                          "+ WRITE_SIZE in separate passes; 8 XCD L2s fetch the 1.74 MB weight stream once each",
-                     "kernel": "bf16_fwd_kernel<1,false,true>" if args.precision == "bf16x3" else "decoder_fwd_kernel<1>",
-                     "kernel_ms": kern_ms, "flop_per_launch": N_RAYS * FLOP_PER_RAY,
-                     "note": "achieved = ALGORITHMIC flops (57.56 MFLOP/ray) / kernel time; bf16x3 issues 3x that on the bf16 MFMA pipe "
-                             "(mfma_pipe_frac), fp32 issues 1x on the fp32 MFMA pipe",
-                     "mfma_pipe_frac": (3.0 if args.precision == "bf16x3" else 1.0) * achieved / PEAK_TFLOPS[args.precision]},
-        "extra": None if args.headline_only else {
-                  other + "_mode": {"rays_per_s": N_RAYS / (other_ms * 1e-3), "kernel_ms": other_ms, "achieved_tflops": other_tf,
-                                    "frac_of_peak": other_tf / PEAK_TFLOPS[other]},
-                  "hbm_bound_kernels": hbm, "optimise_loop": loop,
-                  "fwd_bwd_rays_per_s": fwd_bwd_rays, "fwd_bwd_ms_per_iter": fb_elapsed / n_fb * 1e3,
-                  "fwd_bwd_note": "forward + backward to shape/texture codes and camera pose, incl. ray generation and loss in torch"},
+        "roofline": roofline(prec, kern_ms, "fwd"),
     }
+    if args.headline_only:
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
+
+    # ---- the other arithmetic, wall-clocked by the same loop
+    o_elapsed = clock.wall(lambda: step(other), args.steps, args.warmup)
+    o_kern_ms = clock.events(lambda: step(other), args.steps)
+    result[other] = {"value": world * N_RAYS * args.steps / o_elapsed, "unit": "rays/s", "ms_per_step": o_elapsed / args.steps * 1e3,
+                     "steps": args.steps, "dtype": DTYPE[other], "roofline": roofline(other, o_kern_ms, "fwd"),
+                     "note": "same launches, same loop and clock as `value`; " + ("the library's default arithmetic (model.precision = 'auto')"
+                                                                                 if other == "bf16x3" else "the reference's arithmetic")}
+
+    # ---- backward kernels alone (optimise mode: gradients wrt latent terms, ray origins and directions), device events
+    def bwd_ms(p):
+        fw = ops.render_fwd(rays_o, viewdir, z, div, None, lat, packed, cfgs[p], save_for_bwd=True)
+        d_rgb, d_depth, d_acc = torch.rand_like(fw[0]), torch.zeros_like(fw[1]), torch.rand_like(fw[2])
+        fn = lambda: ops.render_bwd(rays_o, viewdir, z, div, None, lat, packed, cfgs[p], fw[3], fw[4], fw[5], d_rgb, d_depth, d_acc)
+        for _ in range(5):
+            fn()
+        n = max(20, args.steps // 4)
+        # the launch is followed by the 2-step reduction of the latent partials and preceded by two memsets; the kernel dominates (>97 %)
+        return clock.events(fn, n)
+    result["roofline_bwd"] = roofline(prec, bwd_ms(prec), "bwd")
+    result[other]["roofline_bwd"] = roofline(other, bwd_ms(other), "bwd")
+    for r in (result["roofline_bwd"], result[other]["roofline_bwd"]):
+        r["kernel_ms_includes"] = "backward kernel + two d_rays memsets + the reduction of the per-tile latent-gradient partials (one timed call of ops.render_bwd)"
+
+    extra = {}
+    # ---- the public API end to end: what a caller of the reference's render_rays_v2 pays per call
+    def api_leg(p):
+        model.precision = p
+        sc_g, tc_g = w["sc"].clone().requires_grad_(), w["tc"].clone().requires_grad_()
+        pose_g = ob["cam_pose"].to(dev).requires_grad_()
+
+        def fwd():
+            with torch.no_grad():
+                return U.render_rays_v2(model, dev, w["img"], w["mask"], pose_g, ob["obj_diag"], ob["K"], ob["roi"], N_SAMPLES, sc_g, tc_g, 1, 0, im_sz=IM_SZ)
+
+        def fwd_bwd():
+            out = U.render_rays_v2(model, dev, w["img"], w["mask"], pose_g, ob["obj_diag"], ob["K"], ob["roi"], N_SAMPLES, sc_g, tc_g, 1, 0, im_sz=IM_SZ)
+            loss, _ = ops.LossTail.apply(out[0], out[2], out[3], out[4], 0.1, N_RAYS)
+            sc_g.grad = tc_g.grad = pose_g.grad = None
+            loss.sum().backward()
+        n = max(20, args.steps // 4)
+        t_f = clock.wall(fwd, n, 3)
+        t_fb = clock.wall(fwd_bwd, n, 3)
+        return {"render_rays_v2_fwd_rays_per_s": world * N_RAYS * n / t_f, "render_rays_v2_fwd_ms": t_f / n * 1e3,
+                "render_rays_v2_fwd_bwd_rays_per_s": world * N_RAYS * n / t_fb, "render_rays_v2_fwd_bwd_ms": t_fb / n * 1e3, "calls": n}
+    extra["api"] = {p: api_leg(p) for p in (prec, other)}
+    extra["api"]["note"] = ("utils.render_rays_v2 with the reference's signature, every call: ray generation from the pose, bilinear target resize "
+                            "on the host + upload, depth vector, per-object latent layers, fused render; fwd_bwd adds the loss tail and the backward to both "
+                            "codes and the camera pose")
+    model.precision = "auto"
+
+    # ---- the optimise loop (f1): one object
+    from supnerf_amd import driver as D
+    loop = {}
+    if rank == 0 and world == 1:      # (single-GPU runs only: at N > 1 the c3 leg below is the loop measurement)
+        hp = D.load_hpams()
+        hp["render_im_sz"] = IM_SZ
+        objs = D.make_objects([200], IM_SZ)
+        gl = torch.Generator().manual_seed(3)
+        sc_l, tc_l = torch.randn(1, 256, generator=gl) * 0.3, torch.randn(1, 256, generator=gl) * 0.3
+        n_it1 = 50                                   # the reference runs 100 iterations per object: amortise the set-up alike
+        hp["optimize"]["num_opts"] = n_it1
+
+        def timed(fn):
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        for p in ("fp32", "auto"):
+            model.precision = p
+            t_f = timed(lambda: D.optimize_object(model, dev, objs[0], hp, sc_l, tc_l, seed=0))
+            loop[f"fused_eager_{p}"] = {"ms_per_iteration": t_f / n_it1 * 1e3, "object_iterations_per_s": n_it1 / t_f}
+        t_a = timed(lambda: D.optimize_object_api(model, dev, objs[0], hp, sc_l, tc_l, seed=0))
+        t_g = timed(lambda: D.optimize_objects_batched(model, dev, objs, hp, sc_l, tc_l, [0], graph=True))
+        loop.update({"api_structured_auto": {"ms_per_iteration": t_a / n_it1 * 1e3, "object_iterations_per_s": n_it1 / t_a},
+                     "hip_graph_auto": {"ms_per_iteration": t_g / n_it1 * 1e3, "object_iterations_per_s": n_it1 / t_g},
+                     "iterations": n_it1, "rays_per_object": N_RAYS,
+                     "note": "iteration = forward + backward (codes, pose) + 64-pixel depth render + metric row + AdamW at 4096 x 64; fused_eager = driver.optimize_object "
+                             "(~30 launches per iteration, no graph); api_structured = the same loop on the public functions, call for call like the reference (~350 launches); "
+                             "hip_graph = the torch-op iteration recorded once and replayed; set-up (and recording) included everywhere"})
+    extra["optimise_loop"] = loop
+
+    # ---- BASELINE config 3 through the driver: 64 objects sharded over the ranks, one all_gather at the end
+    model.precision = "auto"
+    n_it3 = 4
+    dt3, rows3, n_mine = c3_leg(model, dev, rank, world, dist, clock, n_it3)
+    extra["c3_sharded"] = {"objects": C3_OBJECTS, "objects_this_rank": n_mine, "iterations": n_it3, "seconds": dt3,
+                           "ms_per_iteration": dt3 / n_it3 * 1e3, "object_iterations_per_s": C3_OBJECTS * n_it3 / dt3,
+                           "rays_per_s_fwd_bwd_plus_depth_render": C3_OBJECTS * n_it3 * N_RAYS / dt3, "precision": "auto (bf16x3)",
+                           "metric_rows_finite": bool(torch.isfinite(rows3).all()),
+                           "note": "strong scaling of BASELINE configs[2]: the 64 objects are fixed, each rank optimises its contiguous slice in one launch per "
+                                   "iteration; includes the per-object host set-up and the final all_gather of the metric rows (RCCL)"}
+
+    # ---- BASELINE config 5's per-GPU step: decoder + codes trained (weak scaling across ranks; the gradient bucket is all-reduced)
+    if True:
+        from supnerf_amd import trainer as T
+        Bt, nt = 8, 1024
+        m_t = A.CodeNeRF(3, 1); m_t.load_state_dict(w["params"]); m_t = m_t.to(dev); m_t.train_decoder_weights = True
+        codes = T.CodeTables(64, 256, seed=1).to(dev)
+        gt = torch.Generator().manual_seed(rank)
+        batch = dict(code_idx=torch.arange(Bt), xyz=torch.rand(Bt, nt, N_SAMPLES, 3, generator=gt) - 0.5,
+                     viewdir=torch.nn.functional.normalize(torch.randn(Bt, nt, 1, 3, generator=gt), dim=-1).repeat(1, 1, N_SAMPLES, 1),
+                     z_vals=torch.sort(torch.rand(Bt, N_SAMPLES, generator=gt) * 4 + 9, dim=-1)[0], rgb_tgt=torch.rand(Bt, nt, 3, generator=gt),
+                     occ_pixels=(torch.randint(0, 3, (Bt, nt, 1), generator=gt) - 1).float())
+        batch = {k: v.to(dev) for k, v in batch.items()}
+        hp_t = dict(lr_schedule=[dict(lr=1e-4, interval=40000), dict(lr=1e-4, interval=40000)])
+        bucket = T.GradBucket(list(m_t.parameters()) + list(codes.parameters()))
+        opt_t = T.make_optimizer(m_t, codes, hp_t)
+        n_t = 10
+        t_t = clock.wall(lambda: T.train_step(m_t, codes, opt_t, bucket, batch, 0.1), n_t, 3)
+        extra["training_step"] = {"ms_per_step": t_t / n_t * 1e3, "rays_per_s": world * Bt * nt * n_t / t_t, "objects_per_gpu": Bt, "rays_per_object": nt,
+                                  "samples": N_SAMPLES, "steps": n_t, "dtype": "f32",
+                                  "note": "trainer.train_step: forward + backward incl. every decoder weight gradient + one all-reduce of the flat gradient bucket + AdamW"}
+        del m_t, codes, batch, bucket, opt_t
+
+    # ---- the HBM-bound stand-alone kernels (encode with PE output, composite, scene composite): achieved GB/s
+    hbm = {}
+    if rank == 0 and world == 1:
+        Bh = 64
+        ro_h, vd_h = rays_o.repeat(Bh, 1), viewdir.repeat(Bh, 1)
+        z_h = z[None].repeat(Bh, 1).contiguous()
+        div_h = div.repeat(Bh)
+        cfg_h = ops.RenderCfg(N_SAMPLES, ops.Z_PER_OBJECT, N_RAYS, 3, 1, frame=frame)
+        P_h = Bh * N_RAYS * N_SAMPLES
+
+        def timed_ev(fn, n=10):
+            for _ in range(2):
+                fn()
+            return clock.events(fn, n) * 1e-3
+        t_enc = timed_ev(lambda: ops.encode(ro_h, vd_h, z_h, div_h, None, cfg_h, want_pe=True))
+        enc_bytes = P_h * (12 + 12 + 4 + 63 * 4) + Bh * N_RAYS * (24 + 27 * 4)          # xyz, viewdir, z, PE(xyz) per point; rays in, PE(dir) out
+        sig_h = torch.rand(Bh * N_RAYS, N_SAMPLES, device=dev)
+        rgb_h = torch.rand(Bh * N_RAYS, N_SAMPLES, 3, device=dev)
+        t_cmp = timed_ev(lambda: ops.composite_fwd(sig_h, rgb_h, z_h, ops.Z_PER_OBJECT, False, N_RAYS))
+        cmp_bytes = P_h * 16 + Bh * N_RAYS * 20
+        # scene composite (vis_scene): 131072 pixels x 3 objects x 64 samples, depth merge + composite
+        P_s, n_s = 131072, 3 * N_SAMPLES
+        z_s = (torch.rand(P_s, 3, 1, device=dev) * 20 + 2 + torch.sort(torch.rand(P_s, 3, N_SAMPLES, device=dev), dim=-1)[0] * 4).view(P_s, n_s)
+        sig_s, rgb_s = torch.rand(P_s, n_s, device=dev), torch.rand(P_s, n_s, 3, device=dev)
+        t_scn = timed_ev(lambda: ops.scene_composite(sig_s, rgb_s, z_s, True))
+        scn_bytes = P_s * n_s * 20 + P_s * 20
+        del z_s, sig_s, rgb_s, sig_h, rgb_h
+        mk = lambda b, t: {"GB_per_s": b / t / 1e9, "ms": t * 1e3, "bytes": b, "frac_of_8TBps": b / t / 8e12}
+        hbm = {"encode": mk(enc_bytes, t_enc), "composite_fwd": mk(cmp_bytes, t_cmp), "scene_composite": dict(mk(scn_bytes, t_scn), shape=f"{P_s} pixels x 3 objects x {N_SAMPLES} samples"),
+               "shape": f"{Bh} objects x {N_RAYS} rays x {N_SAMPLES} samples"}
+    extra["hbm_bound_kernels"] = hbm
+    result["extra"] = extra
 
     # ---- CPU baseline + parity (rank 0, N = 1 only): the oracle is the checker and the baseline, never the product
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -287,8 +416,7 @@ def main():
         # the box's CPU share for one GPU is 16 cores whatever os.cpu_count() says; more threads only thrash
         cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
         torch.set_num_threads(cores)
-        n_cpu = 1024                       # a quarter of the workload: same rays, same codes, same weights
-        ro_c, vd_c, z_c = rays_o[:n_cpu].cpu(), viewdir[:n_cpu].cpu(), z.cpu()
+        ro_c, vd_c, z_c = rays_o.cpu(), viewdir.cpu(), z.cpu()
         sc_c, tc_c = w["sc"].cpu(), w["tc"].cpu()
 
         def cpu_pass():
@@ -301,19 +429,22 @@ def main():
         ref = cpu_pass()
         times = []
         t_start = time.perf_counter()
-        while len(times) < 3 or (time.perf_counter() - t_start < 10 and len(times) < 30):
+        while len(times) < 3 or (time.perf_counter() - t_start < 12 and len(times) < 20):
             t0 = time.perf_counter(); ref = cpu_pass(); times.append(time.perf_counter() - t0)
-        cpu_rays = n_cpu / float(np.median(times))
-        rgb_g, depth_g, acc_g = [t[:n_cpu].cpu() for t in out[:3]]
-        tgt_c, occ_c = w["img"].reshape(-1, 3)[:n_cpu], w["mask"].reshape(-1, 1)[:n_cpu]
+        result["cpu_baseline"] = {"value": N_RAYS / float(np.median(times)), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": f"the whole workload: 4096 rays x 64 samples, forward, oracle/supnerf_oracle.py (PyTorch {torch.__version__} CPU), "
+                                            f"median of {len(times)} passes ({sum(times):.1f} s of CPU work)"}
+        tgt_c, occ_c = w["img"].reshape(-1, 3), w["mask"].reshape(-1, 1)
         fg = occ_c.clone(); fg[occ_c < 0] = 0
         ps = lambda rgb: float(-10 * torch.log10(((rgb - tgt_c) ** 2 * fg).sum() / (fg.sum() + 1e-9)))
-        result["cpu_baseline"] = {"value": cpu_rays, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-                                  "sample": f"{n_cpu} of the 4096 rays x 64 samples, forward, oracle/supnerf_oracle.py "
-                                            f"(PyTorch {torch.__version__} CPU), median of {len(times)} passes"}
-        result["parity"] = {"psnr_delta_db": abs(ps(rgb_g) - ps(ref[0])), "depth_l1_mean_m": float((depth_g - ref[1]).abs().mean()),
-                            "rgb_max_abs": float((rgb_g - ref[0]).abs().max()), "acc_max_abs": float((acc_g - ref[2]).abs().max()),
-                            "bound": "north_star: PSNR delta <= 0.01 dB, depth L1 <= 1e-4"}
+
+        def parity(p):
+            rgb_g, depth_g, acc_g = [t.cpu() for t in outs[p][:3]]
+            return {"psnr_delta_db": abs(ps(rgb_g) - ps(ref[0])), "depth_l1_mean_m": float((depth_g - ref[1]).abs().mean()),
+                    "rgb_max_abs": float((rgb_g - ref[0]).abs().max()), "acc_max_abs": float((acc_g - ref[2]).abs().max()), "rays": N_RAYS,
+                    "bound": "north_star: PSNR delta <= 0.01 dB, depth L1 <= 1e-4"}
+        result["parity"] = parity(prec)
+        result[other]["parity"] = parity(other)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

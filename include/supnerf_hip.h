@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SNR_ABI_VERSION 4
+#define SNR_ABI_VERSION 5
 
 enum {
     SNR_OK = 0,
@@ -195,6 +195,50 @@ int snr_composite_bwd(const float* sigmas, const float* rgbs, const float* z_val
  * ---------------------------------------------------------------------------------- */
 int snr_encode_fwd(const snr_render_args* a, float* xyz, float* viewdir, float* z_out,
                    float* pe_xyz, float* pe_dir, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Loss / metric tail of one optimise iteration: replaces the three masked reductions the callers run right after the render
+ * (src/optimizer_nuscenes.py:729-744 == src/optimizer_kitti.py:792-812; per object of a batch:
+ * src/trainer_unified_nuscenes.py:133-140).  Rays are object-major, rays_per_obj per object, B = n_rays / rays_per_obj:
+ *   a = |occ|, den = sum(a) + 1e-9
+ *   loss_rgb = sum((rgb - rgb_tgt)^2 a) / den        loss_occ = sum(exp(-occ (0.5 - acc_trans)) a) / den
+ *   loss     = loss_rgb + loss_occ_coef * loss_occ   mse_fg   = sum((rgb - rgb_tgt)^2 max(occ, 0)) / (sum(max(occ, 0)) + 1e-9)
+ * rgb, rgb_tgt (N,3); acc, occ (N) -> out (B,4) = [loss, loss_rgb, loss_occ, mse_fg]  (PSNR = -10 log10 mse_fg, :743).
+ * snr_loss_tail_bwd writes the gradient seeds of the render backward, d(sum_b upstream_b loss_b)/d rgb (N,3) and /d acc (N)
+ * [each nullable]; upstream (B,) nullable = ones.  One launch each, no host synchronisation.
+ * ---------------------------------------------------------------------------------- */
+int snr_loss_tail_fwd(const float* rgb, const float* acc, const float* rgb_tgt, const float* occ, int64_t n_rays, int64_t rays_per_obj,
+                      float loss_occ_coef, float* out, void* stream);
+int snr_loss_tail_bwd(const float* rgb, const float* acc, const float* rgb_tgt, const float* occ, int64_t n_rays, int64_t rays_per_obj,
+                      float loss_occ_coef, const float* upstream, float* d_rgb, float* d_acc, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * The rest of one iteration of the test-time optimisation loop (src/optimizer_nuscenes.py:674-783 == src/optimizer_kitti.py:731-866),
+ * one launch each, B objects per launch (one workgroup per object), nothing synchronises with the host.
+ *
+ * snr_pose_rays_fwd: the optimised parameters rot_vec (B,3) [axis-angle; pytorch3d axis_angle_to_matrix in the reference, :666,:686] and
+ *   trans_vec (B,3) -> camera-in-object pose cam2opt (B,3,4) [= the inverse of the object pose unless opt_cam_pose, :690-699], then what
+ *   render_rays_v2 derives from it: rays_o / unit viewdir (B*n,3) of the object's pixels (get_rays, src/utils.py:107-135; cam_dirs (B,n,3) =
+ *   [(px-cx)/fx, (py-cy)/fy, 1] is constant over the loop), near/far = |camera centre| -/+ half_diag (:468-469) and the stratified depth
+ *   vector z_vals (B,S) of sample_from_rays (:159-164) with the given jitter (B,S) [nullable = 0].  cam2opt / z_vals nullable.
+ * snr_pose_rays_bwd: d_rays_o, d_viewdir (B*n,3), d_cam2opt (B,3,4) [each nullable] -> d_rot_vec, d_trans_vec (B,3).  The depths are
+ *   detached from the pose like the reference's .tolist().
+ * ---------------------------------------------------------------------------------- */
+int snr_pose_rays_fwd(const float* rot_vec, const float* trans_vec, const float* cam_dirs, const float* half_diag, const float* jitter,
+                      int64_t n_objects, int64_t rays_per_obj, int n_samples, int opt_cam_pose,
+                      float* cam2opt, float* rays_o, float* viewdir, float* z_vals, void* stream);
+int snr_pose_rays_bwd(const float* rot_vec, const float* trans_vec, const float* cam_dirs, int64_t n_objects, int64_t rays_per_obj,
+                      int opt_cam_pose, const float* d_rays_o, const float* d_viewdir, const float* d_cam2opt,
+                      float* d_rot_vec, float* d_trans_vec, void* stream);
+/* The metric row the loop logs every iteration (:739-765): row (B,4) = [PSNR = -10 log10(loss_out[:,3]), mean |depth_pred - depth0| over
+ * n_lidar pixels, rotation error rot_dist(pred_R, gt_R) (src/utils.py:713-722), translation error |pred_t - gt_T|]; gt_R (B,3,3), gt_T (B,3)
+ * are the true OBJECT pose, cam2opt the current camera-in-object pose.  first != 0: depth0 <- depth_pred. */
+int snr_metric_row(const float* loss_out, const float* depth_pred, float* depth0, int n_lidar, int first, const float* cam2opt,
+                   const float* gt_R, const float* gt_T, int64_t n_objects, int opt_cam_pose, float* row, void* stream);
+/* torch.optim.AdamW's update (amsgrad off) of up to 4 parameter groups in one launch (:1762-1769): HOST arrays of n_groups device
+ * pointers / element counts / learning rates; step = 1 for the first update. */
+int snr_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                   const float* lr, int n_groups, int64_t step, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,13 @@ _SIGS = {
     "snr_composite_fwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P]),
     "snr_composite_bwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "snr_encode_fwd": (C.c_int, [C.POINTER(RenderArgs), _P, _P, _P, _P, _P, _P]),
+    "snr_loss_tail_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, _P, _P]),
+    "snr_loss_tail_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, _P, _P, _P, _P]),
+    "snr_pose_rays_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "snr_pose_rays_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "snr_metric_row": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int64, C.c_int, _P, _P]),
+    "snr_adamw_step": (C.c_int, [C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_float),
+                                 C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
 }
 
 

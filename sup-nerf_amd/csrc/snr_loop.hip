@@ -1,0 +1,318 @@
+// The small per-iteration pieces of the test-time optimisation loop (src/optimizer_nuscenes.py:674-783 == src/optimizer_kitti.py:731-866)
+// that surround the render, as single launches for gfx950 -- one object of the batch per workgroup -- so that an iteration is ~30
+// launches instead of ~350 and neither the host nor a train of 3-microsecond kernels bounds it:
+//   * pose_rays:  pose parameters (axis-angle, translation) -> camera-in-object pose, ray origins / unit directions of the pixel
+//                 grid, stratified depths (src/optimizer_nuscenes.py:685-699 + get_rays src/utils.py:107-135 + the sphere bounds and
+//                 sample_from_rays' depth vector src/utils.py:159-164,468-469), and its backward to the pose parameters;
+//   * metric_row: PSNR / depth change / rotation / translation errors of the iteration (:739-765);
+//   * adamw_step: the AdamW update of the four parameter groups (:1762-1769), torch.optim.AdamW's arithmetic.
+// All HBM-/latency-bound and tiny; the wave reductions use DPP row sums and permlane swaps (snr_device.hpp).
+#include "snr_device.hpp"
+#include "snr_host.hpp"
+
+namespace snr {
+
+struct Pose { float Rc[9]; float tc[3]; };
+
+// R = I + a K + b K^2 (Rodrigues), a = sin(t)/t, b = (1 - cos t)/t^2, series below t^2 = 1e-8 (driver.axis_angle_to_matrix)
+__device__ __forceinline__ void rodrigues(const float v[3], float R[9], float* a_, float* b_, float* t2_) {
+    const float x = v[0], y = v[1], z = v[2];
+    const float t2 = x * x + y * y + z * z;
+    const float t = sqrtf(fmaxf(t2, 1e-24f));
+    const bool small = t2 < 1e-8f;
+    const float a = small ? 1.f - t2 / 6.f : sinf(t) / t;
+    const float b = small ? 0.5f - t2 / 24.f : (1.f - cosf(t)) / fmaxf(t2, 1e-24f);
+    const float K[9] = {0.f, -z, y, z, 0.f, -x, -y, x, 0.f};
+    float K2[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.f : 0.f) + a * K[i] + b * K2[i];
+    *a_ = a; *b_ = b; *t2_ = t2;
+}
+
+// camera-in-object pose from the optimised parameters: object pose (R, t) inverted unless the camera pose itself is optimised
+__device__ __forceinline__ Pose make_pose(const float* rot_vec, const float* trans_vec, int opt_cam_pose) {
+    float R[9], a, b, t2;
+    const float v[3] = {rot_vec[0], rot_vec[1], rot_vec[2]};
+    rodrigues(v, R, &a, &b, &t2);
+    const float t[3] = {trans_vec[0], trans_vec[1], trans_vec[2]};
+    Pose p;
+    if (opt_cam_pose) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) p.Rc[i] = R[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) p.tc[i] = t[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) p.Rc[3 * i + j] = R[3 * j + i];
+            p.tc[i] = -(R[i] * t[0] + R[3 + i] * t[1] + R[6 + i] * t[2]);
+        }
+    }
+    return p;
+}
+
+// one workgroup per object.  cam_dirs (B, n, 3) = [(px - cx)/fx, (py - cy)/fy, 1] of the object's pixels (constant over the loop).
+__global__ void __launch_bounds__(256) pose_rays_fwd_kernel(const float* __restrict__ rot_vec, const float* __restrict__ trans_vec,
+                                                            const float* __restrict__ cam_dirs, const float* __restrict__ half_diag,
+                                                            const float* __restrict__ jitter, long long n, int S, int opt_cam_pose,
+                                                            float* __restrict__ cam2opt, float* __restrict__ rays_o,
+                                                            float* __restrict__ viewdir, float* __restrict__ z_vals) {
+    const long long b = blockIdx.x;
+    const Pose p = make_pose(rot_vec + 3 * b, trans_vec + 3 * b, opt_cam_pose);
+    if (threadIdx.x < 12 && cam2opt) {
+        const int i = threadIdx.x / 4, j = threadIdx.x % 4;
+        cam2opt[b * 12 + threadIdx.x] = j < 3 ? p.Rc[3 * i + j] : p.tc[i];
+    }
+    if (z_vals && threadIdx.x < S) {     // S <= 256 (checked by the launcher)
+        // near / far = |camera centre| -/+ diag/2, detached; two-sided linspace like torch.linspace (utils._linspace)
+        const float dist = sqrtf(p.tc[0] * p.tc[0] + p.tc[1] * p.tc[1] + p.tc[2] * p.tc[2]);
+        const float hd = half_diag[b];
+        const float near = dist - hd, far = dist + hd;
+        const float hw = (far - near) / (2.f * S);
+        const float start = near + hw, end = far - hw;
+        const float step = (end - start) / (float)(S > 1 ? S - 1 : 1);
+        const int k = threadIdx.x;
+        const float lin = (k < S / 2) ? start + step * (float)k : end - step * (float)(S - 1 - k);
+        z_vals[b * S + k] = lin + (jitter ? jitter[b * S + k] : 0.f) * hw;
+    }
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        const float* c = cam_dirs + (b * n + i) * 3;
+        const float cx = c[0], cy = c[1], cz = c[2];
+        float w[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) w[r] = __fadd_rn(__fadd_rn(__fmul_rn(cx, p.Rc[3 * r]), __fmul_rn(cy, p.Rc[3 * r + 1])), __fmul_rn(cz, p.Rc[3 * r + 2]));
+        const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(w[0], w[0]), __fmul_rn(w[1], w[1])), __fmul_rn(w[2], w[2])));
+        float* vo = viewdir + (b * n + i) * 3;
+        float* oo = rays_o + (b * n + i) * 3;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { vo[r] = __fdiv_rn(w[r], nrm); oo[r] = p.tc[r]; }
+    }
+}
+
+__device__ __forceinline__ float block_sum256(float v, float* slot) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float s = (slot[0] + slot[1]) + (slot[2] + slot[3]);
+    __syncthreads();
+    return s;
+}
+
+// d(rays_o), d(viewdir) -> d(rot_vec), d(trans_vec); the depths are detached from the pose like the reference's .tolist() (src/utils.py:468)
+__global__ void __launch_bounds__(256) pose_rays_bwd_kernel(const float* __restrict__ rot_vec, const float* __restrict__ trans_vec,
+                                                            const float* __restrict__ cam_dirs, long long n, int opt_cam_pose,
+                                                            const float* __restrict__ d_rays_o, const float* __restrict__ d_viewdir,
+                                                            const float* __restrict__ d_cam2opt,
+                                                            float* __restrict__ d_rot_vec, float* __restrict__ d_trans_vec) {
+    __shared__ float red[4];
+    const long long b = blockIdx.x;
+    const Pose p = make_pose(rot_vec + 3 * b, trans_vec + 3 * b, opt_cam_pose);
+    float gR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gt[3] = {0.f, 0.f, 0.f};
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        const float* c = cam_dirs + (b * n + i) * 3;
+        const float cd[3] = {c[0], c[1], c[2]};
+        float w[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) w[r] = cd[0] * p.Rc[3 * r] + cd[1] * p.Rc[3 * r + 1] + cd[2] * p.Rc[3 * r + 2];
+        const float inv = 1.f / sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        const float u[3] = {w[0] * inv, w[1] * inv, w[2] * inv};
+        float gu[3] = {0.f, 0.f, 0.f};
+        if (d_viewdir) { const float* g = d_viewdir + (b * n + i) * 3; gu[0] = g[0]; gu[1] = g[1]; gu[2] = g[2]; }
+        const float dot = u[0] * gu[0] + u[1] * gu[1] + u[2] * gu[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float gw = (gu[r] - u[r] * dot) * inv;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) gR[3 * r + j] += gw * cd[j];
+        }
+        if (d_rays_o) { const float* g = d_rays_o + (b * n + i) * 3; gt[0] += g[0]; gt[1] += g[1]; gt[2] += g[2]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gR[i] = block_sum256(gR[i], red);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gt[i] = block_sum256(gt[i], red);
+    if (threadIdx.x != 0) return;
+    if (d_cam2opt) {      // a caller that also used the (3,4) pose itself
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) gR[3 * i + j] += d_cam2opt[b * 12 + 4 * i + j];
+            gt[i] += d_cam2opt[b * 12 + 4 * i + 3];
+        }
+    }
+    // gradient wrt the object-pose rotation R and translation t
+    float R[9], a, bq, t2;
+    const float v[3] = {rot_vec[3 * b], rot_vec[3 * b + 1], rot_vec[3 * b + 2]};
+    rodrigues(v, R, &a, &bq, &t2);
+    const float t[3] = {trans_vec[3 * b], trans_vec[3 * b + 1], trans_vec[3 * b + 2]};
+    float G[9], dt[3];
+    if (opt_cam_pose) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) G[i] = gR[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dt[i] = gt[i];
+    } else {        // Rc = R^T, tc = -R^T t
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) G[3 * j + i] = gR[3 * i + j] - gt[i] * t[j];
+            dt[j] = -(R[3 * j] * gt[0] + R[3 * j + 1] * gt[1] + R[3 * j + 2] * gt[2]);
+        }
+    }
+    // R = I + a K + b K^2:  dL/dv_k = a'_k <G,K> + a <G,E_k> + b'_k <G,K^2> + b <G K^T + K^T G, E_k>
+    const float x = v[0], y = v[1], z = v[2];
+    const float K[9] = {0.f, -z, y, z, 0.f, -x, -y, x, 0.f};
+    float K2[9], M[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+            // (G K^T)_ij = sum_m G_im K_jm ; (K^T G)_ij = sum_m K_mi G_mj
+            M[3 * i + j] = (G[3 * i] * K[3 * j] + G[3 * i + 1] * K[3 * j + 1] + G[3 * i + 2] * K[3 * j + 2])
+                         + (K[i] * G[j] + K[3 + i] * G[3 + j] + K[6 + i] * G[6 + j]);
+        }
+    float gk = 0.f, gk2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { gk += G[i] * K[i]; gk2 += G[i] * K2[i]; }
+    const bool small = t2 < 1e-8f;
+    const float th = sqrtf(fmaxf(t2, 1e-24f));
+    const float da = small ? -1.f / 3.f : (th * cosf(th) - sinf(th)) / (th * t2);                      // (da/dv_k) / v_k
+    const float db = small ? -1.f / 12.f : (th * sinf(th) - 2.f * (1.f - cosf(th))) / (t2 * t2);       // (db/dv_k) / v_k
+    const float e[3] = {G[7] - G[5], G[2] - G[6], G[3] - G[1]};
+    const float m[3] = {M[7] - M[5], M[2] - M[6], M[3] - M[1]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (d_rot_vec) d_rot_vec[3 * b + k] = v[k] * (da * gk + db * gk2) + a * e[k] + bq * m[k];
+        if (d_trans_vec) d_trans_vec[3 * b + k] = dt[k];
+    }
+}
+
+// metrics (B,4) of one iteration: [PSNR of the foreground MSE, mean |depth - depth0| over the lidar pixels, rotation error, translation error]
+__global__ void __launch_bounds__(64) metric_row_kernel(const float* __restrict__ loss_out /* (B,4): mse_fg in column 3 */,
+                                                        const float* __restrict__ d_vec, float* __restrict__ depth0, int n_lidar, int first,
+                                                        const float* __restrict__ cam2opt, const float* __restrict__ gt_R,
+                                                        const float* __restrict__ gt_T, int opt_cam_pose, float* __restrict__ row) {
+    const long long b = blockIdx.x;
+    const int lane = threadIdx.x;
+    float s = 0.f;
+    for (int i = lane; i < n_lidar; i += 64) {
+        const float d = d_vec[b * n_lidar + i];
+        if (first) depth0[b * n_lidar + i] = d;
+        s += fabsf(d - (first ? d : depth0[b * n_lidar + i]));
+    }
+    s = wave_sum(s);
+    if (lane != 0) return;
+    const float* c = cam2opt + b * 12;
+    float pR[9], pt[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) pR[3 * i + j] = opt_cam_pose ? c[4 * i + j] : c[4 * j + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pt[i] = opt_cam_pose ? c[4 * i + 3] : -(pR[3 * i] * c[3] + pR[3 * i + 1] * c[7] + pR[3 * i + 2] * c[11]);
+    // geodesic angle (src/utils.py:713-722): trace(pR gR^T) = sum_ij pR_ij gR_ij
+    float tr = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tr += pR[i] * gt_R[b * 9 + i];
+    tr = fminf(fmaxf(tr, -1.f), 3.f);
+    const float ang = acosf(fminf(fmaxf((tr - 1.f) * 0.5f, -1.f), 1.f));
+    const float ex = pt[0] - gt_T[b * 3], ey = pt[1] - gt_T[b * 3 + 1], ez = pt[2] - gt_T[b * 3 + 2];
+    row[b * 4 + 0] = -10.f * log10f(loss_out[b * 4 + 3]);
+    row[b * 4 + 1] = n_lidar > 0 ? s / (float)n_lidar : 0.f;
+    row[b * 4 + 2] = ang;
+    row[b * 4 + 3] = sqrtf(ex * ex + ey * ey + ez * ez);
+}
+
+// torch.optim.AdamW (single-tensor arithmetic, amsgrad off) over up to 4 parameter groups in one launch
+struct AdamGroups {
+    float* p[4]; const float* g[4]; float* m[4]; float* v[4];
+    long long n[4];
+    float decay[4];        // 1 - lr * weight_decay
+    float step_size[4];    // lr / (1 - beta1^step)
+    int count;
+};
+__global__ void __launch_bounds__(256) adamw_kernel(AdamGroups a, float beta1, float beta2, float eps, float bias2_sqrt) {
+    const int gi = blockIdx.y;
+    if (gi >= a.count) return;
+    const float step_size = a.step_size[gi];
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < a.n[gi]; i += (long long)gridDim.x * 256) {
+        const float g = a.g[gi][i];
+        float p = a.p[gi][i] * a.decay[gi];
+        const float m = a.m[gi][i] + (g - a.m[gi][i]) * (1.f - beta1);                  // lerp
+        const float v = a.v[gi][i] * beta2 + (1.f - beta2) * g * g;
+        const float denom = sqrtf(v) / bias2_sqrt + eps;
+        p -= step_size * (m / denom);
+        a.p[gi][i] = p; a.m[gi][i] = m; a.v[gi][i] = v;
+    }
+}
+
+}  // namespace snr
+
+using namespace snr;
+
+extern "C" {
+
+int snr_pose_rays_fwd(const float* rot_vec, const float* trans_vec, const float* cam_dirs, const float* half_diag, const float* jitter,
+                      int64_t n_objects, int64_t rays_per_obj, int n_samples, int opt_cam_pose,
+                      float* cam2opt, float* rays_o, float* viewdir, float* z_vals, void* stream) {
+    if (n_objects == 0) return SNR_OK;
+    if (!rot_vec || !trans_vec || !cam_dirs || !rays_o || !viewdir) return SNR_E_ARG;
+    if (n_objects < 0 || rays_per_obj < 0) return SNR_E_ARG;
+    if (z_vals && (!half_diag || n_samples < 1 || n_samples > 256)) return SNR_E_ARG;
+    pose_rays_fwd_kernel<<<(unsigned)n_objects, 256, 0, (hipStream_t)stream>>>(rot_vec, trans_vec, cam_dirs, half_diag, jitter, rays_per_obj,
+                                                                               n_samples, opt_cam_pose, cam2opt, rays_o, viewdir, z_vals);
+    return snr_check_launch_();
+}
+
+int snr_pose_rays_bwd(const float* rot_vec, const float* trans_vec, const float* cam_dirs, int64_t n_objects, int64_t rays_per_obj,
+                      int opt_cam_pose, const float* d_rays_o, const float* d_viewdir, const float* d_cam2opt,
+                      float* d_rot_vec, float* d_trans_vec, void* stream) {
+    if (n_objects == 0) return SNR_OK;
+    if (!rot_vec || !trans_vec || !cam_dirs || (!d_rot_vec && !d_trans_vec)) return SNR_E_ARG;
+    if (n_objects < 0 || rays_per_obj < 0) return SNR_E_ARG;
+    pose_rays_bwd_kernel<<<(unsigned)n_objects, 256, 0, (hipStream_t)stream>>>(rot_vec, trans_vec, cam_dirs, rays_per_obj, opt_cam_pose,
+                                                                               d_rays_o, d_viewdir, d_cam2opt, d_rot_vec, d_trans_vec);
+    return snr_check_launch_();
+}
+
+int snr_metric_row(const float* loss_out, const float* depth_pred, float* depth0, int n_lidar, int first, const float* cam2opt,
+                   const float* gt_R, const float* gt_T, int64_t n_objects, int opt_cam_pose, float* row, void* stream) {
+    if (n_objects == 0) return SNR_OK;
+    if (!loss_out || !cam2opt || !gt_R || !gt_T || !row || n_objects < 0 || n_lidar < 0) return SNR_E_ARG;
+    if (n_lidar > 0 && (!depth_pred || !depth0)) return SNR_E_ARG;
+    metric_row_kernel<<<(unsigned)n_objects, 64, 0, (hipStream_t)stream>>>(loss_out, depth_pred, depth0, n_lidar, first, cam2opt, gt_R, gt_T,
+                                                                           opt_cam_pose, row);
+    return snr_check_launch_();
+}
+
+int snr_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                   const float* lr, int n_groups, int64_t step, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+    if (n_groups == 0) return SNR_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr || n_groups < 0 || n_groups > 4 || step < 1) return SNR_E_ARG;
+    AdamGroups a;
+    long long nmax = 0;
+    // bias corrections and the per-group scalars in double on the host, like torch's python-scalar path (torch/optim/adam.py)
+    const double b1 = 1.0 - pow((double)beta1, (double)step), b2 = 1.0 - pow((double)beta2, (double)step);
+    for (int i = 0; i < 4; ++i) {
+        const bool on = i < n_groups;
+        if (on && (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 0)) return SNR_E_ARG;
+        a.p[i] = on ? params[i] : nullptr; a.g[i] = on ? grads[i] : nullptr; a.m[i] = on ? exp_avg[i] : nullptr; a.v[i] = on ? exp_avg_sq[i] : nullptr;
+        a.n[i] = on ? numel[i] : 0;
+        a.decay[i] = on ? (float)(1.0 - (double)lr[i] * (double)weight_decay) : 1.f;
+        a.step_size[i] = on ? (float)((double)lr[i] / b1) : 0.f;
+        if (a.n[i] > nmax) nmax = a.n[i];
+    }
+    a.count = n_groups;
+    if (nmax == 0) return SNR_OK;
+    long long gx = (nmax + 255) / 256; if (gx > 1024) gx = 1024;
+    adamw_kernel<<<dim3((unsigned)gx, (unsigned)n_groups), 256, 0, (hipStream_t)stream>>>(a, beta1, beta2, eps, (float)sqrt(b2));
+    return snr_check_launch_();
+}
+
+}  // extern "C"

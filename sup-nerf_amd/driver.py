@@ -145,7 +145,26 @@ def losses(rgb_rays, acc_trans_rays, rgb_tgt, occ_pixels, loss_occ_coef):
 def optimize_object(model, device, obj: Dict, hpams: dict, shapecode0, texturecode0, pose_noise=(0.05, 0.3), reg_iters=3,
                     n_lidar=64, seed=0, log=None, jitter=None):
     """Optimise codes and object pose of one object against its (synthetic) target.  Returns a metric tensor
-    (num_opts, 4) = [psnr, depth_err, rot_err, trans_err] per iteration, and the final codes / pose."""
+    (num_opts, 4) = [psnr, depth_err, rot_err, trans_err] per iteration, and the final codes / pose.
+
+    With a native decoder this is the fused iteration of ``optimize_objects_batched`` at one object (about thirty launches, no host
+    round trip), fed with the depth jitter the reference's loop would have drawn: two ``torch.rand(S)`` per iteration from the global
+    CPU generator, in order.  ``optimize_object_api`` is the same loop written against the public functions, call for call like the
+    reference (needed for ``sym_aug``, which flips a python coin inside every render call, for foreign decoders and for ``log``)."""
+    if not U._is_native(model) or hpams.get("sym_aug", 0) or log is not None or not U.ops.fused_supported(hpams["n_samples"]):
+        return optimize_object_api(model, device, obj, hpams, shapecode0, texturecode0, pose_noise, reg_iters, n_lidar, seed, log, jitter)
+    T, S = hpams["optimize"]["num_opts"], hpams["n_samples"]
+    if jitter is None:
+        jitter = torch.stack([torch.stack([torch.rand(S), torch.rand(S)]) for _ in range(T)]) if T else torch.zeros(0, 2, S)
+    m, sc, tc, pose = optimize_objects_batched(model, device, [obj], hpams, shapecode0, texturecode0, [seed], pose_noise, reg_iters, n_lidar,
+                                               jitter=jitter[:, :, None, :])
+    return m[0].cpu(), sc, tc, pose[0]
+
+
+def optimize_object_api(model, device, obj: Dict, hpams: dict, shapecode0, texturecode0, pose_noise=(0.05, 0.3), reg_iters=3,
+                        n_lidar=64, seed=0, log=None, jitter=None):
+    """``optimize_object`` through the public render API, one call per reference call (src/optimizer_nuscenes.py:674-783): ~350 launches
+    per iteration, host-bound at one object."""
     opt = hpams["optimize"]
     S, im_sz = hpams["n_samples"], hpams["render_im_sz"]
     dev = torch.device(device)
@@ -242,6 +261,8 @@ def optimize_objects_batched(model, device, objs: List[Dict], hpams: dict, shape
     B, n = len(objs), im_sz * im_sz
     if hpams.get("sym_aug", 0):
         raise U.SnrError("optimize_objects_batched: sym_aug draws one python coin per object and iteration; use optimize_object")
+    if not graph and not device_optimizer:
+        return _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, pose_noise, reg_iters, n_lidar, jitter)
     rot0, tr0, gtR, gtT, px, py, lx, ly, tgt, occ = [], [], [], [], [], [], [], [], [], []
     for ob, seed in zip(objs, seeds):
         rs = np.random.RandomState(seed)
@@ -374,6 +395,99 @@ def optimize_objects_batched(model, device, objs: List[Dict], hpams: dict, shape
                 lr = {k: v * 2 ** (-halvings) for k, v in lr.items()}
                 optim = make_optimizer(shapecode, texturecode, rot_vec, trans_vec, lr)
     return metrics.permute(1, 0, 2).contiguous(), shapecode.detach(), texturecode.detach(), pose.clone()
+
+
+def _loop_inputs(objs, seeds, hpams, pose_noise, n_lidar, dev):
+    """Per-object constants of the loop, built once on the host and moved to the device: perturbed start pose, ground truth, the pixel
+    direction tables [(px-cx)/fx, (py-cy)/fy, 1] of the render grid and of the "lidar" pixels, resized targets (the reference resizes
+    the same crop again in every iteration, src/utils.py:447-456)."""
+    im_sz = hpams["render_im_sz"]
+    rot0, tr0, gtR, gtT, cam, lid, tgt, occ = [], [], [], [], [], [], [], []
+    for ob, seed in zip(objs, seeds):
+        rs = np.random.RandomState(seed)
+        R_gt = ob["cam_pose"][:, :3].T
+        t_gt = -R_gt @ ob["cam_pose"][:, 3:]
+        rot0.append(matrix_to_axis_angle(R_gt[None]) + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[0])
+        tr0.append(t_gt.T + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[1])
+        gtR.append(R_gt); gtT.append(t_gt.reshape(3))
+        ys, xs = np.where(ob["mask"][:, :, 0].numpy() > 0)
+        pick = rs.permutation(len(ys))[:n_lidar]
+        x0, y0, x1, y1 = [int(v) for v in ob["roi"]]
+        K = ob["K"]
+        cx, cy, fx, fy = K[0, 2], K[1, 2], K[0, 0], K[1, 1]
+        gx, gy = torch.linspace(x0, x1 - 1, im_sz), torch.linspace(y0, y1 - 1, im_sz)
+        px, py = gx[None, :].expand(im_sz, im_sz).reshape(-1), gy[:, None].expand(im_sz, im_sz).reshape(-1)
+        cam.append(torch.stack([(px - cx) / fx, (py - cy) / fy, torch.ones_like(px)], -1))
+        lx, ly = torch.from_numpy(xs[pick] + x0), torch.from_numpy(ys[pick] + y0)         # integer pixels, like get_rays_specified
+        lid.append(torch.stack([(lx - cx) / fx, (ly - cy) / fy, torch.ones_like(lx, dtype=torch.float32)], -1))
+        im, mk = U._resize(ob["img"], ob["mask"], im_sz)
+        tgt.append(im.reshape(-1, 3)); occ.append(mk.reshape(-1))
+    n_l = min(v.shape[0] for v in lid)           # one launch needs the same count for every object: the smallest foreground decides
+    if n_l == 0:
+        raise U.SnrError("optimize_objects_batched: an object has no foreground pixel")
+    st = lambda xs_: torch.stack(xs_).to(dev).contiguous()
+    return dict(rot0=torch.cat(rot0).to(dev), tr0=torch.cat(tr0).to(dev), gtR=st(gtR), gtT=st(gtT), cam=st(cam), lid=st([v[:n_l] for v in lid]),
+                tgt=st(tgt), occ=st(occ), diag=torch.tensor([float(ob["obj_diag"]) for ob in objs], device=dev), n_lidar=n_l)
+
+
+def _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, pose_noise, reg_iters, n_lidar, jitter):
+    """The iteration as ~30 launches for any number of objects: pose -> rays + depths (one launch), the per-object layers (two GEMMs),
+    fused render, loss tail (one launch), backward = their four backward launches, the 64-pixel depth render, the metric row (one
+    launch), AdamW over the four parameter groups (one launch).  Nothing reads back until the loop has finished."""
+    ops = U.ops
+    opt = hpams["optimize"]
+    S, im_sz, T = hpams["n_samples"], hpams["render_im_sz"], opt["num_opts"]
+    B, n = len(objs), im_sz * im_sz
+    c = _loop_inputs(objs, seeds, hpams, pose_noise, n_lidar, dev)
+    n_l = c["n_lidar"]
+    rot_vec, trans_vec = c["rot0"].requires_grad_(), c["tr0"].requires_grad_()
+    shapecode = shapecodes0.detach().clone().to(dev).contiguous().requires_grad_()
+    texturecode = texturecodes0.detach().clone().to(dev).contiguous().requires_grad_()
+    if jitter is None:
+        gens = [torch.Generator().manual_seed(int(s_)) for s_ in seeds]
+        jitter = torch.stack([torch.rand(T, 2, S, generator=g) for g in gens], dim=2)
+    jitter = jitter.to(dev).contiguous()
+    lr = {k: float(opt[k]) for k in ("lr_shape", "lr_texture", "lr_pose")}
+    optim = ops.DeviceAdamW([(shapecode, lr["lr_shape"]), (texturecode, lr["lr_texture"]), (rot_vec, lr["lr_pose"]), (trans_vec, lr["lr_pose"])])
+    frame = U._frame(False, False, hpams["shapenet_obj_cood"])
+    sb, tb = model.shape_blocks, model.texture_blocks
+    half = (c["diag"] / 2).contiguous()
+    opt_cam = int(bool(opt.get("opt_cam_pose", 0)))
+    coef = float(hpams["loss_occ_coef"])
+    metrics = torch.zeros(T, B, 4, device=dev)
+    depth0 = torch.zeros(B, n_l, device=dev)
+    ones = torch.ones(B, device=dev)
+    pose = torch.zeros(B, 3, 4, device=dev)
+    cfg = ops.RenderCfg(S, ops.Z_PER_OBJECT, n, sb, tb, frame=frame, precision=model.precision)
+    cfg_l = ops.RenderCfg(S, ops.Z_PER_OBJECT, n_l, sb, tb, frame=frame, precision=model.precision)
+    packed = model.packed_weights()
+    frozen = [p for p in model.parameters() if p.requires_grad]     # the decoder is a constant of this loop (the reference leaves its
+    for p in frozen:                                                 # weights trainable and pays for unused weight gradients)
+        p.requires_grad_(False)
+    try:
+        for it in range(T):
+            cam2opt, rays_o, viewdir, z = ops.PoseRays.apply(rot_vec, trans_vec, c["cam"], half, jitter[it, 0], S, opt_cam)
+            lat = model.latent_terms(shapecode, texturecode)
+            cfg.latent_bias = cfg_l.latent_bias = model.latent_biases(lat)
+            rgb, depth, acc = ops.FusedRender.apply(rays_o, viewdir, z, c["diag"], None, lat, packed, cfg)
+            loss, lm = ops.LossTail.apply(rgb, acc, c["tgt"], c["occ"], coef, n)
+            torch.autograd.backward(loss, ones)
+            with torch.no_grad():
+                c2o, lo, lv, lz = ops.PoseRays.apply(rot_vec.detach(), trans_vec.detach(), c["lid"], half, jitter[it, 1], S, opt_cam)
+                d_vec = ops.render_fwd(lo, lv, lz, c["diag"], None, lat.detach(), packed, cfg_l)[1]
+                out4 = torch.cat([loss.detach()[:, None], lm], dim=1)
+                ops.metric_row(out4, d_vec.view(B, n_l), depth0, it == 0, c2o, c["gtR"], c["gtT"], opt_cam, metrics[it])
+                if it == T - 1:
+                    pose.copy_(c2o)
+            if it > reg_iters:
+                optim.step()
+            optim.zero_grad()
+            if (it + 1) % opt["lr_half_interval"] == 0:
+                optim.restart(2.0 ** (-((it + 1) // opt["lr_half_interval"])))
+    finally:
+        for p in frozen:
+            p.requires_grad_(True)
+    return metrics.permute(1, 0, 2).contiguous(), shapecode.detach(), texturecode.detach(), pose
 
 
 def make_objects(ids: Sequence[int], im_sz: int) -> List[Dict]:

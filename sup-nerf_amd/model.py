@@ -67,9 +67,46 @@ class _DecoderBase(nn.Module):
             self._packed_key = key
         return self._packed
 
+    # ---- the per-object layers as two GEMMs (one for all latent layers, one for all folded biases) when their weights are constants
+    def _latent_params(self):
+        lat = [getattr(self, f"shape_latent_layer_{j + 1}")[0] for j in range(self.shape_blocks)]
+        lat += [getattr(self, f"texture_latent_layer_{j + 1}")[0] for j in range(self.texture_blocks)]
+        nxt = [getattr(self, f"shape_layer_{j + 1}")[0] for j in range(self.shape_blocks)]
+        nxt += [getattr(self, f"texture_layer_{j + 1}")[0] for j in range(self.texture_blocks)]
+        return lat, nxt
+
+    def _stacked(self):
+        """(W_lat (512, n_lat*256), b_lat, W_next (n_lat*256, n_lat*256) block diagonal, b_next), rebuilt when a weight changed.
+        Row block 0 of W_lat multiplies the shape code, row block 1 the texture code; every latent layer owns one column block."""
+        lat, nxt = self._latent_params()
+        ps = [q for l in lat + nxt for q in (l.weight, l.bias)]
+        key = tuple((q.data_ptr(), q._version, str(q.device)) for q in ps)
+        if getattr(self, "_stack_key", None) != key:
+            n, W = len(lat), 256
+            with torch.no_grad():
+                dev = ps[0].device
+                w_lat = torch.zeros(2 * W, n * W, device=dev)
+                w_nxt = torch.zeros(n * W, n * W, device=dev)
+                for j, (l, m) in enumerate(zip(lat, nxt)):
+                    r0 = 0 if j < self.shape_blocks else W
+                    w_lat[r0:r0 + W, j * W:(j + 1) * W] = l.weight.t()
+                    w_nxt[j * W:(j + 1) * W, j * W:(j + 1) * W] = m.weight.t()
+                self._stack = (w_lat, torch.cat([l.bias for l in lat]).contiguous(), w_nxt, torch.cat([m.bias for m in nxt]).contiguous())
+            self._stack_key = key
+        return self._stack
+
     def latent_terms(self, shape_latent: torch.Tensor, texture_latent: torch.Tensor) -> torch.Tensor:
         """(B, shape_blocks+texture_blocks, 256): z_j = ReLU(Lin_j(code)) (src/model_supnerf.py:253,261), hoisted out
-        of the per-ray loop.  With no blocks at all a dummy (B,1,256) of zeros is returned."""
+        of the per-ray loop.  With no blocks at all a dummy (B,1,256) of zeros is returned.  When the latent layers' weights are
+        constants (optimise / inference: frozen, or no gradient being recorded) all of them are ONE GEMM over [shape code | texture code];
+        gradients still reach the codes."""
+        n_lat = self.shape_blocks + self.texture_blocks
+        if n_lat and shape_latent.is_cuda:
+            lat_layers, _ = self._latent_params()
+            if not torch.is_grad_enabled() or not any(q.requires_grad for l in lat_layers for q in (l.weight, l.bias)):
+                w_lat, b_lat, _, _ = self._stacked()
+                codes = torch.cat([shape_latent, texture_latent], dim=-1)
+                return torch.relu(torch.addmm(b_lat, codes, w_lat)).view(shape_latent.shape[0], n_lat, 256)
         outs = [getattr(self, f"shape_latent_layer_{j + 1}")(shape_latent) for j in range(self.shape_blocks)]
         outs += [getattr(self, f"texture_latent_layer_{j + 1}")(texture_latent) for j in range(self.texture_blocks)]
         if not outs:
@@ -84,6 +121,9 @@ class _DecoderBase(nn.Module):
         if self.shape_blocks + self.texture_blocks == 0:
             return None
         with torch.no_grad():
+            if lat.is_cuda:
+                _, _, w_nxt, b_nxt = self._stacked()
+                return torch.addmm(b_nxt, lat.detach().reshape(lat.shape[0], -1), w_nxt).view(lat.shape)
             lins = [getattr(self, f"shape_layer_{j + 1}")[0] for j in range(self.shape_blocks)]
             lins += [getattr(self, f"texture_layer_{j + 1}")[0] for j in range(self.texture_blocks)]
             return torch.stack([F.linear(lat[:, j].detach(), lin.weight, lin.bias) for j, lin in enumerate(lins)], dim=1).contiguous()

@@ -17,9 +17,9 @@ PRECISIONS = {"fp32": FP32, "bf16x3": BF16X3}
 def resolve_precision(precision, shape_blocks, texture_blocks, points_per_obj) -> int:
     """'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16, ~2^-17 operand error, several times faster) or 'auto'
     (bf16x3 where the kernel supports the configuration, else fp32).  Asking for 'bf16x3' where it is unsupported raises."""
-    if isinstance(precision, int):
+    if isinstance(precision, int) and not isinstance(precision, bool):
         return precision
-    if precision == "auto":
+    if precision is None or precision == "auto":
         ok = _lib.lib().snr_precision_supported(BF16X3, shape_blocks, texture_blocks, int(points_per_obj))
         return BF16X3 if ok else FP32
     if precision not in PRECISIONS:
@@ -164,6 +164,153 @@ class Composite(torch.autograd.Function):
                            "src/utils.py:468-469)")
         d_sig, d_rgbs, d_z = composite_bwd(sigmas, rgbs, z_vals, z_mode, white, rpo, d_rgb, d_depth, d_acc, need_dz)
         return d_sig.view(sigmas.shape), d_rgbs.view(rgbs.shape), (d_z.view(z_vals.shape) if need_dz else None), None, None, None
+
+
+# ------------------------------------------------------------------------------------ loss / metric tail
+def loss_tail_fwd(rgb, acc, rgb_tgt, occ, loss_occ_coef, rays_per_obj):
+    """(B,4) = [loss, loss_rgb, loss_occ, mse_fg] per object (src/optimizer_nuscenes.py:729-744), one launch."""
+    rgb, acc, rgb_tgt, occ = _f32c(rgb), _f32c(acc), _f32c(rgb_tgt), _f32c(occ)
+    _need_gpu(rgb, acc, rgb_tgt, occ)
+    n = acc.numel()
+    if rgb.numel() != 3 * n or rgb_tgt.numel() != 3 * n or occ.numel() != n or rays_per_obj < 1 or n % rays_per_obj:
+        raise SnrError(f"loss_tail: rgb {tuple(rgb.shape)}, acc {tuple(acc.shape)}, rgb_tgt {tuple(rgb_tgt.shape)}, occ {tuple(occ.shape)} "
+                       f"do not describe whole objects of {rays_per_obj} rays")
+    dev = rgb.device
+    out = torch.empty(n // rays_per_obj, 4, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().snr_loss_tail_fwd(_p(rgb), _p(acc), _p(rgb_tgt), _p(occ), n, rays_per_obj, float(loss_occ_coef), _p(out), _stream(dev)),
+              "snr_loss_tail_fwd")
+    return out
+
+
+class LossTail(torch.autograd.Function):
+    """loss (B,) [differentiable wrt rgb and acc_trans] and metrics (B,3) = [loss_rgb, loss_occ, mse_fg] [not differentiable] of the
+    optimise iteration.  Backward is one launch that writes the seeds of the render backward."""
+
+    @staticmethod
+    def forward(ctx, rgb, acc, rgb_tgt, occ, loss_occ_coef, rays_per_obj):
+        rgb, acc, rgb_tgt, occ = _f32c(rgb), _f32c(acc), _f32c(rgb_tgt), _f32c(occ)
+        out = loss_tail_fwd(rgb, acc, rgb_tgt, occ, loss_occ_coef, rays_per_obj)
+        ctx.save_for_backward(rgb, acc, rgb_tgt, occ)
+        ctx.cfg = (float(loss_occ_coef), int(rays_per_obj))
+        loss, metrics = out[:, 0].contiguous(), out[:, 1:].contiguous()
+        ctx.mark_non_differentiable(metrics)
+        return loss, metrics
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_metrics):
+        rgb, acc, rgb_tgt, occ = ctx.saved_tensors
+        coef, rpo = ctx.cfg
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            raise SnrError("loss_tail: the targets and occupancy labels are data, no gradient is provided")
+        dev = rgb.device
+        d_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[0] else None
+        d_acc = torch.empty_like(acc) if ctx.needs_input_grad[1] else None
+        if d_rgb is not None or d_acc is not None:
+            with torch.cuda.device(dev):
+                check(_lib.lib().snr_loss_tail_bwd(_p(rgb), _p(acc), _p(rgb_tgt), _p(occ), acc.numel(), rpo, coef, _p(_f32c(g_loss)),
+                                                   _p(d_rgb), _p(d_acc), _stream(dev)), "snr_loss_tail_bwd")
+        return d_rgb, d_acc, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------ the rest of an optimise iteration
+class PoseRays(torch.autograd.Function):
+    """Pose parameters -> camera-in-object pose, rays of the pixel grid, stratified depths, in one launch for B objects
+    (src/optimizer_nuscenes.py:685-699 + get_rays + the sphere bounds + sample_from_rays' depth vector); backward in one launch.
+    rot_vec, trans_vec (B,3); cam_dirs (B,n,3); half_diag (B,); jitter (B,S) or None
+    -> cam2opt (B,3,4), rays_o (B*n,3), viewdir (B*n,3), z_vals (B,S) [detached from the pose like the reference's]."""
+
+    @staticmethod
+    def forward(ctx, rot_vec, trans_vec, cam_dirs, half_diag, jitter, n_samples, opt_cam_pose):
+        rot_vec, trans_vec, cam_dirs, half_diag, jitter = [_f32c(t) for t in (rot_vec, trans_vec, cam_dirs, half_diag, jitter)]
+        _need_gpu(rot_vec, trans_vec, cam_dirs, half_diag, jitter)
+        B, n = cam_dirs.shape[0], cam_dirs.shape[1]
+        if rot_vec.shape != (B, 3) or trans_vec.shape != (B, 3) or half_diag.numel() != B or (jitter is not None and jitter.shape != (B, n_samples)):
+            raise SnrError("pose_rays: expected rot_vec / trans_vec (B,3), cam_dirs (B,n,3), half_diag (B,), jitter (B,S)")
+        dev = cam_dirs.device
+        cam2opt = torch.empty(B, 3, 4, device=dev)
+        rays_o, viewdir = torch.empty(B * n, 3, device=dev), torch.empty(B * n, 3, device=dev)
+        z = torch.empty(B, n_samples, device=dev)
+        with torch.cuda.device(dev):
+            check(_lib.lib().snr_pose_rays_fwd(_p(rot_vec), _p(trans_vec), _p(cam_dirs), _p(half_diag), _p(jitter), B, n, int(n_samples),
+                                               int(bool(opt_cam_pose)), _p(cam2opt), _p(rays_o), _p(viewdir), _p(z), _stream(dev)), "snr_pose_rays_fwd")
+        ctx.save_for_backward(rot_vec, trans_vec, cam_dirs)
+        ctx.opt_cam_pose = int(bool(opt_cam_pose))
+        ctx.mark_non_differentiable(z)
+        return cam2opt, rays_o, viewdir, z
+
+    @staticmethod
+    def backward(ctx, d_cam2opt, d_rays_o, d_viewdir, _d_z):
+        rot_vec, trans_vec, cam_dirs = ctx.saved_tensors
+        if ctx.needs_input_grad[2]:
+            raise SnrError("pose_rays: the pixel direction table is data, no gradient is provided")
+        B, n = cam_dirs.shape[0], cam_dirs.shape[1]
+        dev = cam_dirs.device
+        d_rot, d_tr = torch.empty_like(rot_vec), torch.empty_like(trans_vec)
+        with torch.cuda.device(dev):
+            check(_lib.lib().snr_pose_rays_bwd(_p(rot_vec), _p(trans_vec), _p(cam_dirs), B, n, ctx.opt_cam_pose, _p(_f32c(d_rays_o)),
+                                               _p(_f32c(d_viewdir)), _p(_f32c(d_cam2opt)), _p(d_rot), _p(d_tr), _stream(dev)), "snr_pose_rays_bwd")
+        return d_rot, d_tr, None, None, None, None, None
+
+
+def metric_row(loss_out, depth_pred, depth0, first, cam2opt, gt_R, gt_T, opt_cam_pose, row):
+    """row (B,4) <- [PSNR, mean |depth_pred - depth0|, rotation error, translation error] (src/optimizer_nuscenes.py:739-765)."""
+    _need_gpu(loss_out, depth_pred, depth0, cam2opt, gt_R, gt_T, row)
+    B = cam2opt.shape[0]
+    n_lidar = depth_pred.shape[-1] if depth_pred is not None else 0
+    for t in (loss_out, depth_pred, depth0, cam2opt, gt_R, gt_T, row):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise SnrError("metric_row: fp32 contiguous tensors expected")
+    dev = cam2opt.device
+    with torch.cuda.device(dev):
+        check(_lib.lib().snr_metric_row(_p(loss_out), _p(depth_pred), _p(depth0), int(n_lidar), int(bool(first)), _p(cam2opt), _p(gt_R), _p(gt_T),
+                                        B, int(bool(opt_cam_pose)), _p(row), _stream(dev)), "snr_metric_row")
+    return row
+
+
+class DeviceAdamW:
+    """torch.optim.AdamW's update (amsgrad off, same defaults) for up to 4 parameter groups as ONE launch per step
+    (src/optimizer_nuscenes.py:1762-1769).  ``groups``: [(parameter tensor, lr), ...]; gradients are read from ``.grad``."""
+
+    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if not 1 <= len(groups) <= 4:
+            raise SnrError("DeviceAdamW: 1 to 4 parameter groups")
+        self.params = [p for p, _ in groups]
+        self.lr = [float(lr) for _, lr in groups]
+        for p in self.params:
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise SnrError("DeviceAdamW: fp32 contiguous parameters on the GPU")
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self.steps = 0
+
+    def restart(self, scale: float = 1.0):
+        """What re-creating the optimiser does (src/optimizer_nuscenes.py:1771-1775): fresh moments and step count, rates times ``scale``."""
+        self.lr = [v * scale for v in self.lr]
+        for t in self.exp_avg + self.exp_avg_sq:
+            t.zero_()
+        self.steps = 0
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self):
+        n = len(self.params)
+        grads = []
+        for p in self.params:
+            if p.grad is None:
+                raise SnrError("DeviceAdamW.step: a parameter has no gradient")
+            grads.append(_f32c(p.grad))
+        self.steps += 1
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        numel = (C.c_int64 * n)(*[p.numel() for p in self.params])
+        lr = (C.c_float * n)(*self.lr)
+        dev = self.params[0].device
+        with torch.cuda.device(dev):
+            check(_lib.lib().snr_adamw_step(arr([p.data for p in self.params]), arr(grads), arr(self.exp_avg), arr(self.exp_avg_sq), numel, lr, n, self.steps,
+                                            self.betas[0], self.betas[1], self.eps, self.weight_decay, _stream(dev)), "snr_adamw_step")
 
 
 # ------------------------------------------------------------------------------------ decoder on points
@@ -324,8 +471,11 @@ class RenderCfg:
     """Per-launch constants of the render operators (not tensors)."""
 
     def __init__(self, n_samples, z_mode, rays_per_obj, shape_blocks, texture_blocks, frame=IDENTITY_FRAME, xyz_mul=1.0,
-                 white_bkgd=False, metric_z=False, precision="fp32"):
+                 white_bkgd=False, metric_z=False, precision=None):
         self.n_samples, self.z_mode, self.rays_per_obj = n_samples, z_mode, rays_per_obj
+        # "fp32" | "bf16x3" | "auto" | None.  None = not chosen here: ``model.fused_render`` substitutes the module's ``precision``; the
+        # bare operators (render_fwd, encode) treat it as "auto", the library default.  (It used to default to "fp32", which made
+        # every caller that did not pass it run the exact kernels whatever the module said.)
         self.precision = precision
         self.shape_blocks, self.texture_blocks = shape_blocks, texture_blocks
         self.frame, self.xyz_mul = tuple(float(v) for v in frame), float(xyz_mul)
@@ -386,21 +536,31 @@ class FusedRender(torch.autograd.Function):
         need_t = ctx.needs_input_grad[2]
         if need_t and cfg.z_mode != Z_PER_RAY:
             raise SnrError("gradient wrt shared / per-object depths is not provided (the reference detaches them)")
-        dev = rays_o.device
-        d_lat = torch.empty_like(latent) if ctx.needs_input_grad[5] else None
-        d_o = torch.zeros_like(rays_o) if ctx.needs_input_grad[0] else None
-        d_d = torch.zeros_like(rays_d) if ctx.needs_input_grad[1] else None
-        d_t = torch.empty_like(t_vals) if need_t else None
-        a = _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg.frame, cfg.xyz_mul, cfg.z_mode, cfg.flags,
-                         cfg.rays_per_obj, cfg.n_samples, cfg.shape_blocks, cfg.texture_blocks,
-                         resolve_precision(cfg.precision, cfg.shape_blocks, cfg.texture_blocks, cfg.rays_per_obj * cfg.n_samples))
-        ws_bytes = _lib.lib().snr_render_bwd_ws_bytes(C.byref(a))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            check(_lib.lib().snr_render_bwd(C.byref(a), _p(sig), _p(rgbs), _p(masks), _p(_f32c(d_rgb)), _p(_f32c(d_depth)),
-                                            _p(_f32c(d_acc)), _p(d_lat), _p(d_o), _p(d_d), _p(d_t), _p(ws), ws_bytes, _stream(dev)),
-                  "snr_render_bwd")
+        d_o, d_d, d_t, d_lat = render_bwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg, sig, rgbs, masks, d_rgb, d_depth, d_acc,
+                                          need_o=ctx.needs_input_grad[0], need_d=ctx.needs_input_grad[1], need_t=need_t,
+                                          need_latent=ctx.needs_input_grad[5])
         return d_o, d_d, d_t, None, None, d_lat, None, None
+
+
+def render_bwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg: RenderCfg, sig, rgbs, masks, d_rgb, d_depth, d_acc,
+               need_o=True, need_d=True, need_t=False, need_latent=True):
+    """Backward of the fused render on what ``render_fwd(..., save_for_bwd=True)`` saved: one launch + the small reduction of the
+    latent-term partials.  Returns (d_rays_o, d_rays_d, d_t, d_latent), None where not asked for."""
+    dev = rays_o.device
+    d_lat = torch.empty_like(latent) if need_latent else None
+    d_o = torch.zeros_like(rays_o) if need_o else None
+    d_d = torch.zeros_like(rays_d) if need_d else None
+    d_t = torch.empty_like(t_vals) if need_t else None
+    a = _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg.frame, cfg.xyz_mul, cfg.z_mode, cfg.flags,
+                     cfg.rays_per_obj, cfg.n_samples, cfg.shape_blocks, cfg.texture_blocks,
+                     resolve_precision(cfg.precision, cfg.shape_blocks, cfg.texture_blocks, cfg.rays_per_obj * cfg.n_samples))
+    ws_bytes = _lib.lib().snr_render_bwd_ws_bytes(C.byref(a))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().snr_render_bwd(C.byref(a), _p(sig), _p(rgbs), _p(masks), _p(_f32c(d_rgb)), _p(_f32c(d_depth)),
+                                        _p(_f32c(d_acc)), _p(d_lat), _p(d_o), _p(d_d), _p(d_t), _p(ws), ws_bytes, _stream(dev)),
+              "snr_render_bwd")
+    return d_o, d_d, d_t, d_lat
 
 
 # ------------------------------------------------------------------------------------ encode

@@ -454,10 +454,10 @@ def test_batched_objects_equal_single_objects(amd, dev, model):
     sc, tc = (torch.randn(B, 256, generator=gen) * 0.3).to(dev), (torch.randn(B, 256, generator=gen) * 0.3).to(dev)
     div = torch.tensor([5.1, 5.6, 4.9], device=dev)
     with torch.no_grad():
-        cfg = ops.RenderCfg(S, ops.Z_PER_OBJECT, N, 3, 1)
+        cfg = ops.RenderCfg(S, ops.Z_PER_OBJECT, N, 3, 1, precision=None)     # None: the fixture's model.precision decides (fp32 | auto)
         full = model.fused_render(ro, vd, z, div, None, sc, tc, cfg)
         for b in range(B):
-            cfg1 = ops.RenderCfg(S, ops.Z_SHARED, N, 3, 1)
+            cfg1 = ops.RenderCfg(S, ops.Z_SHARED, N, 3, 1, precision=None)
             one = model.fused_render(ro[b * N:(b + 1) * N], vd[b * N:(b + 1) * N], z[b], div[b:b + 1], None, sc[b:b + 1], tc[b:b + 1], cfg1)
             for a, c in zip(full, one):
                 assert torch.equal(a[b * N:(b + 1) * N], c)
@@ -474,12 +474,12 @@ def test_full_size_properties(amd, dev, model):
     z = torch.linspace(9.3, 14.7, S).to(dev)
     sc, tc = (torch.randn(1, 256, generator=gen) * 0.3).to(dev), (torch.randn(1, 256, generator=gen) * 0.3).to(dev)
     div = torch.tensor([5.4], device=dev)
-    cfg = ops.RenderCfg(S, ops.Z_SHARED, N, 3, 1)
+    cfg = ops.RenderCfg(S, ops.Z_SHARED, N, 3, 1, precision=None)
     with torch.no_grad():
         a = model.fused_render(ro, vd, z, div, None, sc, tc, cfg)
         b = model.fused_render(ro, vd, z, div, None, sc, tc, cfg)
         idx = torch.randperm(N, generator=gen)[:1000].to(dev)
-        cfg_s = ops.RenderCfg(S, ops.Z_SHARED, 1000, 3, 1)
+        cfg_s = ops.RenderCfg(S, ops.Z_SHARED, 1000, 3, 1, precision=None)
         sub = model.fused_render(ro[idx], vd[idx], z, div, None, sc, tc, cfg_s)
     for x, y in zip(a, b):
         assert torch.equal(x, y)

@@ -1,0 +1,202 @@
+"""The single-launch pieces of the optimise iteration (loss tail, pose -> rays, metric row, AdamW) against plain PyTorch fp32 references of
+the same formulas -- the reference's own lines are cited at each -- and the fused loop against the loop written on the public API."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import supnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import supnerf_amd
+    return supnerf_amd
+
+
+def md(a, b):
+    return float((a.detach().double().cpu() - torch.as_tensor(b).detach().double().cpu()).abs().max())
+
+
+def rel(a, b):
+    b = torch.as_tensor(b).detach().double().cpu()
+    return md(a, b) / (float(b.abs().max()) + 1e-30)
+
+
+# ------------------------------------------------------------------ loss tail (src/optimizer_nuscenes.py:729-744)
+@pytest.mark.parametrize("B,n", [(1, 4096), (3, 1024), (5, 37), (64, 256)])
+def test_loss_tail_forward_backward(amd, dev, B, n):
+    g = torch.Generator().manual_seed(B * 1000 + n)
+    rgb = torch.rand(B * n, 3, generator=g, dtype=torch.float64) * 1.2 - 0.1
+    acc = torch.rand(B * n, generator=g, dtype=torch.float64)
+    tgt = torch.rand(B * n, 3, generator=g, dtype=torch.float64)
+    occ = (torch.randint(0, 3, (B * n, 1), generator=g) - 1).double()
+    up = torch.rand(B, generator=g, dtype=torch.float64) + 0.5
+    rgb_r, acc_r = rgb.clone().requires_grad_(), acc.clone().requires_grad_()
+    rows = []
+    for b in range(B):            # the reference's formulas in float64, object by object
+        sl = slice(b * n, (b + 1) * n)
+        loss, l_rgb, l_occ, psnr = O.optimise_losses(rgb_r[sl], acc_r[sl], tgt[sl], occ[sl], 0.1)
+        rows.append(torch.stack([loss, l_rgb, l_occ, 10 ** (-psnr / 10)]))
+    want = torch.stack(rows)
+    (want[:, 0] * up).sum().backward()
+    rgb_d, acc_d = rgb.float().to(dev).requires_grad_(), acc.float().to(dev).requires_grad_()
+    loss, metrics = amd.ops.LossTail.apply(rgb_d, acc_d, tgt.float().to(dev), occ.float().to(dev), 0.1, n)
+    assert loss.shape == (B,) and metrics.shape == (B, 3) and not metrics.requires_grad
+    assert rel(loss, want[:, 0]) < 2e-6 and rel(metrics, want[:, 1:]) < 2e-6
+    (loss * up.float().to(dev)).sum().backward()
+    assert rel(rgb_d.grad, rgb_r.grad) < 2e-6 and rel(acc_d.grad, acc_r.grad) < 2e-6
+    # an object without any labelled pixel: the 1e-9 in the denominators keeps everything finite (0 / 1e-9)
+    z = torch.zeros(n, 1, device=dev)
+    l0, m0 = amd.ops.LossTail.apply(rgb_d.detach()[:n], acc_d.detach()[:n], tgt.float().to(dev)[:n], z, 0.1, n)
+    assert float(l0) == 0.0 and float(m0.abs().max()) == 0.0
+
+
+def test_loss_tail_rejects_partial_objects(amd, dev):
+    with pytest.raises(amd.SnrError):
+        amd.ops.loss_tail_fwd(torch.rand(10, 3, device=dev), torch.rand(10, device=dev), torch.rand(10, 3, device=dev), torch.rand(10, 1, device=dev), 0.1, 4)
+    with pytest.raises(amd.SnrError):
+        amd.ops.loss_tail_fwd(torch.rand(8, 3), torch.rand(8), torch.rand(8, 3), torch.rand(8, 1), 0.1, 4)       # CPU tensors
+
+
+# ------------------------------------------------------------------ pose -> rays (src/optimizer_nuscenes.py:685-699, src/utils.py:107-135,159-164,468-469)
+def torch_pose_rays(D, U, rot_vec, trans_vec, cam, half, jit, S, opt_cam_pose):
+    R = D.axis_angle_to_matrix(rot_vec)
+    t = trans_vec.unsqueeze(-1)
+    if not opt_cam_pose:
+        Rc = R.transpose(-2, -1)
+        c2o = torch.cat([Rc, -Rc @ t], -1)
+    else:
+        c2o = torch.cat([R, t], -1)
+    world = (cam[:, :, None, :] * c2o[:, None, :3, :3]).sum(-1)
+    unit = world / torch.norm(world, dim=-1, keepdim=True)
+    origin = c2o[:, None, :3, 3].expand(world.shape)
+    dist = c2o[:, :, 3].detach().norm(dim=-1)
+    near, far = (dist - half)[:, None], (dist + half)[:, None]
+    idx = torch.arange(S, dtype=cam.dtype)[None, :]
+    hw = (far - near) / (2 * S)
+    start, end = near + hw, far - hw
+    step = (end - start) / max(S - 1, 1)
+    z = torch.where(idx < S // 2, start + step * idx, end - step * (S - 1 - idx)) + jit * hw
+    return c2o, origin.reshape(-1, 3), unit.reshape(-1, 3), z
+
+
+@pytest.mark.parametrize("opt_cam_pose", [0, 1])
+@pytest.mark.parametrize("B,n,S", [(1, 4096, 64), (3, 100, 32), (2, 1, 7)])
+def test_pose_rays_forward_backward(amd, dev, B, n, S, opt_cam_pose):
+    D, U = amd.driver, amd.utils
+    g = torch.Generator().manual_seed(7 + B + n)
+    rot = torch.randn(B, 3, generator=g, dtype=torch.float64) * 1.2
+    tr = torch.randn(B, 3, generator=g, dtype=torch.float64) * 3 + torch.tensor([0., 1., 15.], dtype=torch.float64)
+    cam = torch.cat([torch.randn(B, n, 2, generator=g, dtype=torch.float64) * 0.2, torch.ones(B, n, 1, dtype=torch.float64)], -1)
+    half = torch.rand(B, generator=g, dtype=torch.float64) + 2
+    jit = torch.rand(B, S, generator=g, dtype=torch.float64)
+    w_o, w_d, w_c = [torch.randn(*s, generator=g, dtype=torch.float64) for s in ((B * n, 3), (B * n, 3), (B, 3, 4))]
+    rot_r, tr_r = rot.clone().requires_grad_(), tr.clone().requires_grad_()
+    ref = torch_pose_rays(D, U, rot_r, tr_r, cam, half, jit, S, opt_cam_pose)         # float64 reference of the driver's formulas
+    ((ref[1] * w_o).sum() + (ref[2] * w_d).sum() + (ref[0] * w_c).sum()).backward()
+    f = lambda t: t.float().to(dev)
+    rot_d, tr_d = f(rot).requires_grad_(), f(tr).requires_grad_()
+    out = amd.ops.PoseRays.apply(rot_d, tr_d, f(cam), f(half), f(jit), S, opt_cam_pose)
+    for a, b, name, tol in zip(out, ref, ("cam2opt", "rays_o", "viewdir", "z"), (2e-6, 2e-6, 5e-7, 5e-6)):
+        assert md(a, b) < tol * max(1.0, float(b.abs().max())), (name, md(a, b))
+    assert not out[3].requires_grad
+    ((out[1] * f(w_o)).sum() + (out[2] * f(w_d)).sum() + (out[0] * f(w_c)).sum()).backward()
+    assert rel(rot_d.grad, rot_r.grad) < 5e-5 and rel(tr_d.grad, tr_r.grad) < 5e-5, (rel(rot_d.grad, rot_r.grad), rel(tr_d.grad, tr_r.grad))
+
+
+def test_pose_rays_small_angle(amd, dev):
+    """Below |v|^2 = 1e-8 the rotation uses its series (driver.axis_angle_to_matrix); value and gradient stay finite and right."""
+    D, U = amd.driver, amd.utils
+    rot = torch.tensor([[2e-5, -1e-5, 3e-5], [0.0, 0.0, 0.0]], dtype=torch.float64)
+    tr = torch.tensor([[0.5, 1.0, 12.0], [1.0, -1.0, 9.0]], dtype=torch.float64)
+    g = torch.Generator().manual_seed(1)
+    cam = torch.cat([torch.randn(2, 50, 2, generator=g, dtype=torch.float64) * 0.2, torch.ones(2, 50, 1, dtype=torch.float64)], -1)
+    half, jit = torch.tensor([2.5, 2.7], dtype=torch.float64), torch.rand(2, 16, generator=g, dtype=torch.float64)
+    w_d = torch.randn(100, 3, generator=g, dtype=torch.float64)
+    rot_r, tr_r = rot.clone().requires_grad_(), tr.clone().requires_grad_()
+    ref = torch_pose_rays(D, U, rot_r, tr_r, cam, half, jit, 16, 0)
+    (ref[2] * w_d).sum().backward()
+    f = lambda t: t.float().to(dev)
+    rot_d, tr_d = f(rot).requires_grad_(), f(tr).requires_grad_()
+    out = amd.ops.PoseRays.apply(rot_d, tr_d, f(cam), f(half), f(jit), 16, 0)
+    (out[2] * f(w_d)).sum().backward()
+    assert md(out[2], ref[2]) < 5e-7 and rel(rot_d.grad, rot_r.grad) < 5e-5 and bool(torch.isfinite(rot_d.grad).all())
+
+
+# ------------------------------------------------------------------ metric row (src/optimizer_nuscenes.py:739-765, src/utils.py:675-722)
+@pytest.mark.parametrize("opt_cam_pose", [0, 1])
+def test_metric_row(amd, dev, opt_cam_pose):
+    D = amd.driver
+    g = torch.Generator().manual_seed(3)
+    B, nl = 4, 37
+    R = D.axis_angle_to_matrix(torch.randn(B, 3, generator=g)); t = torch.randn(B, 3, 1, generator=g) * 5
+    c2o = torch.cat([R, t], -1)
+    gtR = D.axis_angle_to_matrix(torch.randn(B, 3, generator=g)); gtT = torch.randn(B, 3, generator=g) * 5
+    loss_out = torch.rand(B, 4, generator=g) * 0.2 + 0.01
+    d_vec, d0 = torch.rand(B, nl, generator=g) * 20, torch.rand(B, nl, generator=g) * 20
+    pred_R = c2o[:, :, :3] if opt_cam_pose else c2o[:, :, :3].transpose(-2, -1)
+    pred_t = c2o[:, :, 3:] if opt_cam_pose else -pred_R @ c2o[:, :, 3:]
+    want = torch.stack([-10 * torch.log10(loss_out[:, 3]), (d_vec - d0).abs().mean(dim=1), D.rot_dist(pred_R, gtR),
+                        (pred_t - gtT[:, :, None]).flatten(1).norm(dim=1)], dim=1)
+    f = lambda t_: t_.to(dev).contiguous()
+    row, d0_d = torch.zeros(B, 4, device=dev), f(d0)
+    amd.ops.metric_row(f(loss_out), f(d_vec), d0_d, False, f(c2o), f(gtR), f(gtT), opt_cam_pose, row)
+    assert md(row[:, :2], want[:, :2]) < 2e-5 and md(row[:, 2], want[:, 2]) < 1e-3 and md(row[:, 3], want[:, 3]) < 1e-5, (row.cpu(), want)
+    # acos near 0 / pi amplifies the last bits of the trace: compare the cosines there
+    assert md(torch.cos(row[:, 2]), torch.cos(want[:, 2])) < 2e-6
+    amd.ops.metric_row(f(loss_out), f(d_vec), d0_d, True, f(c2o), f(gtR), f(gtT), opt_cam_pose, row)       # first iteration: depth0 <- depth
+    assert float(row[:, 1].abs().max()) == 0.0 and torch.equal(d0_d.cpu(), d_vec)
+
+
+# ------------------------------------------------------------------ AdamW (src/optimizer_nuscenes.py:1762-1769: torch.optim.AdamW defaults)
+def test_device_adamw_matches_torch(amd, dev):
+    g = torch.Generator().manual_seed(11)
+    shapes, lrs = [(2, 256), (2, 256), (2, 3), (2, 3)], [0.02, 0.015, 0.01, 0.01]
+    p_ref = [torch.randn(*s, generator=g).requires_grad_() for s in shapes]
+    p_dev = [p.detach().clone().to(dev).requires_grad_() for p in p_ref]
+    ref = torch.optim.AdamW([{"params": p, "lr": lr} for p, lr in zip(p_ref, lrs)], foreach=False)
+    mine = amd.ops.DeviceAdamW(list(zip(p_dev, lrs)))
+    for step in range(25):
+        for a, b in zip(p_ref, p_dev):
+            gr = torch.randn(*a.shape, generator=g) * (0.1 + step % 3)
+            a.grad, b.grad = gr.clone(), gr.to(dev)
+        ref.step(); mine.step()
+        if step == 11:      # what re-creating the optimiser with halved rates does
+            mine.restart(0.5)
+            ref = torch.optim.AdamW([{"params": p, "lr": lr * 0.5} for p, lr in zip(p_ref, lrs)], foreach=False)
+    for a, b in zip(p_ref, p_dev):
+        assert md(b, a) < 2e-6, md(b, a)
+
+
+# ------------------------------------------------------------------ the fused loop == the loop on the public API
+@pytest.mark.parametrize("precision", ["fp32", "auto"])
+def test_fused_loop_equals_api_loop(amd, dev, oracle_params, precision):
+    """optimize_object (about thirty launches per iteration) against optimize_object_api (the reference's call sequence on the public
+    functions): same jitter, same start -> same traces up to fp32 round-off through Adam."""
+    D = amd.driver
+    model = amd.CodeNeRF(3, 1); model.load_state_dict(oracle_params); model.precision = precision; model = model.to(dev)
+    hp = D.load_hpams(); hp["render_im_sz"] = 16; hp["optimize"]["num_opts"] = 10; hp["optimize"]["lr_half_interval"] = 6
+    obj = D.make_objects([21], 16)[0]
+    g = torch.Generator().manual_seed(5)
+    sc0, tc0 = torch.randn(1, 256, generator=g) * 0.3, torch.randn(1, 256, generator=g) * 0.3
+    jit = torch.rand(10, 2, 64, generator=g)
+    a = D.optimize_object_api(model, dev, obj, hp, sc0, tc0, reg_iters=1, seed=9, jitter=jit)
+    b = D.optimize_object(model, dev, obj, hp, sc0, tc0, reg_iters=1, seed=9, jitter=jit)
+    assert all(p.requires_grad for p in model.parameters())                       # the loop thaws what it froze
+    d = (a[0] - b[0]).abs()
+    print(f"[fused vs api loop, {precision}] max metric differences {d.max(dim=0)[0].tolist()}")
+    assert float(d[:3].max()) < 2e-4, d[:3]                                       # before the first optimiser step
+    assert float(d[:, 0].max()) < 0.05 and float(d[:, 1].max()) < 2e-3 and float(d[:, 2:].max()) < 2e-3, d
+    assert md(a[3], b[3]) < 2e-3 and md(a[1], b[1]) < 2e-2
+    # the global-RNG jitter stream: two torch.rand(S) per iteration, in order, like the reference's loop
+    torch.manual_seed(77); a2 = D.optimize_object_api(model, dev, obj, hp, sc0, tc0, reg_iters=1, seed=9)
+    torch.manual_seed(77); b2 = D.optimize_object(model, dev, obj, hp, sc0, tc0, reg_iters=1, seed=9)
+    assert float((a2[0][:3] - b2[0][:3]).abs().max()) < 2e-4
