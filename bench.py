@@ -56,6 +56,12 @@ N_RAYS, N_SAMPLES, IM_SZ = 4096, 64, 64
 C3_OBJECTS = 64
 
 
+def log(msg):
+    """progress on stderr (stdout carries the one JSON line)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def profile_traffic(precision, which="fwd"):
     """HBM bytes per launch of the dominant kernel from the newest committed counter profile of this kernel (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes; FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md).  The counters cannot be collected from
@@ -243,6 +249,7 @@ def main():
     def step(p):
         outs[p] = ops.render_fwd(rays_o, viewdir, z, div, None, lat, packed, cfgs[p])
 
+    log(f"headline: {args.steps} fused forwards, {prec}")
     # ---- headline: the contract's wall clock around EXACTLY --steps launches, in the reference's arithmetic unless asked otherwise
     elapsed = clock.wall(lambda: step(prec), args.steps, args.warmup)
     value = world * N_RAYS * args.steps / elapsed
@@ -264,6 +271,7 @@ def main():
             dist.barrier(); dist.destroy_process_group()
         return
 
+    log(f"same loop, {other}")
     # ---- the other arithmetic, wall-clocked by the same loop
     o_elapsed = clock.wall(lambda: step(other), args.steps, args.warmup)
     o_kern_ms = clock.events(lambda: step(other), args.steps)
@@ -272,6 +280,7 @@ def main():
                      "note": "same launches, same loop and clock as `value`; " + ("the library's default arithmetic (model.precision = 'auto')"
                                                                                  if other == "bf16x3" else "the reference's arithmetic")}
 
+    log("backward kernels")
     # ---- backward kernels alone (optimise mode: gradients wrt latent terms, ray origins and directions), device events
     def bwd_ms(p):
         fw = ops.render_fwd(rays_o, viewdir, z, div, None, lat, packed, cfgs[p], save_for_bwd=True)
@@ -288,6 +297,7 @@ def main():
         r["kernel_ms_includes"] = "backward kernel + two d_rays memsets + the reduction of the per-tile latent-gradient partials (one timed call of ops.render_bwd)"
 
     extra = {}
+    log("public API legs")
     # ---- the public API end to end: what a caller of the reference's render_rays_v2 pays per call
     def api_leg(p):
         model.precision = p
@@ -314,6 +324,7 @@ def main():
                             "codes and the camera pose")
     model.precision = "auto"
 
+    log("one-object optimise loops")
     # ---- the optimise loop (f1): one object
     from supnerf_amd import driver as D
     loop = {}
@@ -344,6 +355,7 @@ def main():
                              "hip_graph = the torch-op iteration recorded once and replayed; set-up (and recording) included everywhere"})
     extra["optimise_loop"] = loop
 
+    log("config 3: 64 objects sharded")
     # ---- BASELINE config 3 through the driver: 64 objects sharded over the ranks, one all_gather at the end
     model.precision = "auto"
     n_it3 = 4
@@ -355,6 +367,7 @@ def main():
                            "note": "strong scaling of BASELINE configs[2]: the 64 objects are fixed, each rank optimises its contiguous slice in one launch per "
                                    "iteration; includes the per-object host set-up and the final all_gather of the metric rows (RCCL)"}
 
+    log("training step")
     # ---- BASELINE config 5's per-GPU step: decoder + codes trained (weak scaling across ranks; the gradient bucket is all-reduced)
     if True:
         from supnerf_amd import trainer as T
@@ -377,6 +390,7 @@ def main():
                                   "note": "trainer.train_step: forward + backward incl. every decoder weight gradient + one all-reduce of the flat gradient bucket + AdamW"}
         del m_t, codes, batch, bucket, opt_t
 
+    log("HBM-bound kernels")
     # ---- the HBM-bound stand-alone kernels (encode with PE output, composite, scene composite): achieved GB/s
     hbm = {}
     if rank == 0 and world == 1:
@@ -410,6 +424,7 @@ def main():
     extra["hbm_bound_kernels"] = hbm
     result["extra"] = extra
 
+    log("CPU baseline + parity")
     # ---- CPU baseline + parity (rank 0, N = 1 only): the oracle is the checker and the baseline, never the product
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import supnerf_oracle as O

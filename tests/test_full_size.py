@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 
 N_RAYS, S, IM = 4096, 64, 64
 TOL_RGB, TOL_ACC, TOL_DEPTH_MEAN, TOL_DEPTH_MAX, TOL_PSNR = 2e-5, 2e-5, 1e-5, 1e-4, 0.01
-GRAD_REL = {"fp32": 2e-4, "auto": 1e-3}         # relative to the gradient's largest entry; aggregated over 4096 x 64 points
+GRAD_REL = {"fp32": 2e-4, "auto": 2e-4}         # relative to the gradient's largest entry, aggregated over 4096 x 64 points: the same bound for
+                                                 # both arithmetics (measured: fp32 7e-6 / 7e-5, bf16x3 4e-5 / 8e-5 for codes / pose)
 
 
 @pytest.fixture(scope="module")
@@ -151,22 +152,28 @@ def test_config3_64_objects_one_launch(amd, dev, oracle_params, c3_inputs, c3_or
     ro, vd, z, diag = c["ro"].to(dev), c["vd"].to(dev), c["z"].to(dev), c["diag"].to(dev)
     sc, tc = c["sc"].to(dev).requires_grad_(), c["tc"].to(dev).requires_grad_()
     frame = amd.utils._frame(False, False, True)
-    cfg = ops.RenderCfg(S, ops.Z_PER_OBJECT, N_RAYS, 3, 1, frame=frame, precision=None)
-    rgb, depth, acc = model.fused_render(ro, vd, z, diag, None, sc, tc, cfg)
+    prec = ops.resolve_precision(model.precision, 3, 1, N_RAYS * S)
+    assert prec == (ops.FP32 if precision == "fp32" else ops.BF16X3)
+    # the per-object layers once for all 64 objects (two library GEMMs); the launches below all see these very numbers, so that what is
+    # compared bit for bit is OUR batching (object-major latent rows, per-object depth rows), not the BLAS's choice of kernel per batch size
+    lat = model.latent_terms(sc, tc)
+    lat_bias = model.latent_biases(lat)
+    packed = model.packed_weights()
+    cfg = ops.RenderCfg(S, ops.Z_PER_OBJECT, N_RAYS, 3, 1, frame=frame, precision=prec)
+    cfg.latent_bias = lat_bias
+    rgb, depth, acc = ops.FusedRender.apply(ro, vd, z, diag, None, lat, packed, cfg)
     assert rgb.shape == (C3_OBJECTS * N_RAYS, 3)
     tgt = torch.stack([o["img"].reshape(-1, 3) for o in c["objs"]]).to(dev)
-    occ = torch.stack([o["mask"].reshape(-1, 1) for o in c["objs"]]).to(dev)
-    a = occ.abs()
-    den = a.sum(dim=(1, 2)) + 1e-9
-    loss = (((rgb.view(C3_OBJECTS, N_RAYS, 3) - tgt) ** 2 * a).sum(dim=(1, 2)) / den
-            + 0.1 * (torch.exp(-occ * (0.5 - acc.view(C3_OBJECTS, N_RAYS, 1))) * a).sum(dim=(1, 2)) / den).sum()
-    loss.backward()
+    occ = torch.stack([o["mask"].reshape(-1) for o in c["objs"]]).to(dev)
+    loss, _ = ops.LossTail.apply(rgb, acc, tgt, occ, 0.1, N_RAYS)          # the batched loop's loss: one value per object, summed
+    loss.sum().backward()
     # every object of the batched launch == its own single-object launch, bit for bit
     with torch.no_grad():
         for b in range(C3_OBJECTS):
             sl = slice(b * N_RAYS, (b + 1) * N_RAYS)
-            cfg1 = ops.RenderCfg(S, ops.Z_SHARED, N_RAYS, 3, 1, frame=frame, precision=None)
-            one = model.fused_render(ro[sl], vd[sl], z[b], diag[b:b + 1], None, sc[b:b + 1].detach(), tc[b:b + 1].detach(), cfg1)
+            cfg1 = ops.RenderCfg(S, ops.Z_SHARED, N_RAYS, 3, 1, frame=frame, precision=prec)
+            cfg1.latent_bias = lat_bias[b:b + 1].contiguous()
+            one = ops.render_fwd(ro[sl], vd[sl], z[b], diag[b:b + 1], None, lat[b:b + 1].detach(), packed, cfg1)
             assert torch.equal(one[0], rgb[sl]) and torch.equal(one[1], depth[sl]) and torch.equal(one[2], acc[sl]), b
     # sampled objects against the oracle, forward and backward
     for b in C3_SAMPLED:
