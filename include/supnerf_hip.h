@@ -162,12 +162,16 @@ int snr_render_bwd(const snr_render_args* a, const float* sigmas, const float* r
 
 /* ------------------------------------------------------------------------------------
  * Multi-object scene pixels: replaces the per-pixel depth sort + scatter + volume_rendering3(white) of
- * OptimizerDemo.vis_scene (scripts/demo.py:555-565).  Every pixel carries n_per_pixel = Nb * S samples (the S samples of
- * each of Nb objects, any order; depth -1 marks empty space and carries sigma 0); they are merged by depth and composited.
- * Samples of exactly equal depth collapse like the reference's scatter: the last one in memory order survives.  sigmas, z_vals (P, n); rgbs (P, n, 3) -> rgb (P,3), depth (P) [nullable], acc_trans (P) [nullable].
+ * OptimizerDemo.vis_scene (scripts/demo.py:555-565).  Every pixel carries n_per_pixel = Nb * S samples (the S samples of each of Nb
+ * objects; depth -1 marks empty space and carries sigma 0); they are merged by depth and composited.  Samples of exactly equal depth
+ * collapse like the reference's scatter: the last one in memory order survives.
+ * run_length: S when each object's S samples are contiguous and ascending in depth (what vis_scene produces: stratified samples along
+ * the object's ray, or all -1) -- the lists are then MERGED (binary searches, O(n log S Nb) per pixel) instead of rank-sorted (O(n^2));
+ * the order is verified per pixel and a pixel with an unsorted list silently takes the rank sort, so the hint can never change a result.
+ * 0 = no such structure.  sigmas, z_vals (P, n); rgbs (P, n, 3) -> rgb (P,3), depth (P) [nullable], acc_trans (P) [nullable].
  * flags: SNR_WHITE_BKGD.  n_per_pixel <= 1706 (LDS).
  * ---------------------------------------------------------------------------------- */
-int snr_scene_composite_fwd(const float* sigmas, const float* rgbs, const float* z_vals, int64_t n_pixels, int n_per_pixel,
+int snr_scene_composite_fwd(const float* sigmas, const float* rgbs, const float* z_vals, int64_t n_pixels, int n_per_pixel, int run_length,
                             int flags, float* rgb, float* depth, float* acc_trans, void* stream);
 
 /* ------------------------------------------------------------------------------------

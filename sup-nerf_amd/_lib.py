@@ -56,7 +56,7 @@ _SIGS = {
     "snr_render_fwd": (C.c_int, [C.POINTER(RenderArgs), _P, _P, _P, _P, _P, _P, _P]),
     "snr_render_bwd_ws_bytes": (C.c_size_t, [C.POINTER(RenderArgs)]),
     "snr_render_bwd": (C.c_int, [C.POINTER(RenderArgs), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
-    "snr_scene_composite_fwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "snr_scene_composite_fwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "snr_composite_fwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P]),
     "snr_composite_bwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "snr_encode_fwd": (C.c_int, [C.POINTER(RenderArgs), _P, _P, _P, _P, _P, _P]),

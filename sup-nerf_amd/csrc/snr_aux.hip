@@ -76,8 +76,26 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restr
 // One wave per pixel.  The pixel's n = Nb*S samples (Nb per-object lists) are merged by depth with a rank sort in LDS --
 // every lane ranks its own elements against broadcast reads of the depth row -- then composited front to back with the same wave scan as every other composite here.  HBM-bound:
 // 20 B per sample in, 20 B per pixel out; the n^2/64 compares per lane stay below the load time up to n ~ 512.
+// number of elements of the ascending run zr[0..len) that are < v (UPPER: <= v): branch-free halving, at most 1 + log2(len) LDS reads
+template <bool UPPER>
+__device__ __forceinline__ int run_bound(const float* zr, int len, float v) {
+    int lo = 0;
+    while (len > 0) {
+        const int half = len >> 1;
+        const float m = zr[lo + half];
+        const bool go = UPPER ? (m <= v) : (m < v);
+        lo = go ? lo + half + 1 : lo;
+        len = go ? len - half - 1 : half;
+    }
+    return lo;
+}
+
+// `run` > 0: the pixel's n samples are n/run lists of `run` samples each, every list ascending in depth (one object's samples along its
+// ray; a list of an object that does not cover the pixel is all -1).  Then a sample's rank is its position in its own list plus, for every
+// other list, the number of smaller depths there -- two binary searches per list, O(n log(run) Nb) LDS reads per pixel instead of the n^2
+// of the generic rank sort below.  The lists are CHECKED to be ascending; a pixel whose lists are not takes the generic path.
 __global__ void __launch_bounds__(256) scene_composite_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
-                                                              const float* __restrict__ zv, long long n_pixels, int n, int flags,
+                                                              const float* __restrict__ zv, long long n_pixels, int n, int run, int flags,
                                                               float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ acc) {
     extern __shared__ __attribute__((aligned(16))) float scene_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -96,7 +114,35 @@ __global__ void __launch_bounds__(256) scene_composite_kernel(const float* __res
         // memory order wins and the group's other slots keep zero density / zero colour (torch scatter_ on the CPU).  Equal
         // depths are the rule for empty space (-1) and happen for ~1 % of pixels between real samples (fp32 depth grid), so
         // that is reproduced: the sorted depth row is complete, data goes to the group's first slot from its last member.
-        for (int base = 0; base < n; base += 256) {           // up to four own elements per pass
+        bool merged = false;
+        if (run > 1 && n % run == 0) {
+            bool sorted = true;
+            for (int i = lane; i < n; i += 64) sorted = sorted && ((i % run) == run - 1 || zs[i] <= zs[i + 1]);
+            merged = __all(sorted);
+        }
+        if (merged) {
+            const int n_runs = n / run;
+            for (int i = lane; i < n; i += 64) {
+                const int r = i / run, p = i - r * run;
+                const float zi = zs[i];
+                int lt = 0, eb = 0, ea = 0;
+                for (int q = 0; q < n_runs; ++q) {
+                    const float* zr = zs + q * run;
+                    const int lb = run_bound<false>(zr, run, zi);
+                    const bool has_eq = lb < run && zr[lb] == zi;
+                    const int ub = has_eq ? lb + 1 + run_bound<true>(zr + lb + 1, run - lb - 1, zi) : lb;
+                    lt += lb;
+                    if (q < r) eb += ub - lb;
+                    else if (q > r) ea += ub - lb;
+                    else { eb += p - lb; ea += ub - p - 1; }
+                }
+                const int pos = lt + eb;
+                s_z[pos] = zi;
+                if (eb > 0) { s_sig[pos] = 0.f; s_r[pos] = 0.f; s_g[pos] = 0.f; s_b[pos] = 0.f; }
+                if (ea == 0) { s_sig[lt] = srow[i]; s_r[lt] = crow[3 * i]; s_g[lt] = crow[3 * i + 1]; s_b[lt] = crow[3 * i + 2]; }
+            }
+        }
+        for (int base = 0; base < n && !merged; base += 256) {           // generic rank sort: up to four own elements per pass
             float zi[4]; int lt[4], eb[4], ea[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) { const int i = base + 64 * c + lane; zi[c] = (i < n) ? zs[i] : 0.f; lt[c] = eb[c] = ea[c] = 0; }
@@ -410,11 +456,12 @@ int snr_composite_fwd(const float* sigmas, const float* rgbs, const float* z_val
     return snr_check_launch_();
 }
 
-int snr_scene_composite_fwd(const float* sigmas, const float* rgbs, const float* z_vals, int64_t n_pixels, int n_per_pixel, int flags,
-                            float* rgb, float* depth, float* acc, void* stream_) {
+int snr_scene_composite_fwd(const float* sigmas, const float* rgbs, const float* z_vals, int64_t n_pixels, int n_per_pixel, int run_length,
+                            int flags, float* rgb, float* depth, float* acc, void* stream_) {
     if (n_pixels == 0) return SNR_OK;
     if (!sigmas || !rgbs || !z_vals || !rgb) return SNR_E_ARG;
-    if (n_pixels < 0 || n_per_pixel < 1) return SNR_E_ARG;
+    if (n_pixels < 0 || n_per_pixel < 1 || run_length < 0) return SNR_E_ARG;
+    if (run_length > 0 && (n_per_pixel % run_length) != 0) return SNR_E_SHAPE;
     const size_t lds = (size_t)4 * 6 * n_per_pixel * sizeof(float);
     if (lds > 160 * 1024) return SNR_E_UNSUPPORTED;            /* more than 1706 samples per pixel */
     if (lds > 64 * 1024) {
@@ -422,7 +469,7 @@ int snr_scene_composite_fwd(const float* sigmas, const float* rgbs, const float*
         if (e != hipSuccess) return snr_check_launch_();
     }
     const int grid = grid_for(n_pixels * 64, 256, 8192);
-    scene_composite_kernel<<<grid, 256, lds, (hipStream_t)stream_>>>(sigmas, rgbs, z_vals, n_pixels, n_per_pixel, flags, rgb, depth, acc);
+    scene_composite_kernel<<<grid, 256, lds, (hipStream_t)stream_>>>(sigmas, rgbs, z_vals, n_pixels, n_per_pixel, run_length, flags, rgb, depth, acc);
     return snr_check_launch_();
 }
 

@@ -112,9 +112,10 @@ def composite_fwd(sigmas, rgbs, z_vals, z_mode, white_bkgd, rays_per_obj=0):
     return rgb, depth, acc
 
 
-def scene_composite(sigmas, rgbs, z_vals, white_bkgd=True):
+def scene_composite(sigmas, rgbs, z_vals, white_bkgd=True, run_length=0):
     """Per-pixel depth merge of n = Nb*S samples + composite (scripts/demo.py:555-565): sigmas, z_vals (P, n); rgbs (P, n, 3)
-    -> rgb (P,3), depth (P), acc_trans (P).  Inference only (the reference runs it under no_grad)."""
+    -> rgb (P,3), depth (P), acc_trans (P).  Inference only (the reference runs it under no_grad).  ``run_length`` = S tells the kernel that
+    every object's S samples are contiguous and ascending, so it merges the lists instead of rank-sorting (verified per pixel, see the header)."""
     sigmas, rgbs, z_vals = _f32c(sigmas), _f32c(rgbs), _f32c(z_vals)
     _need_gpu(sigmas, rgbs, z_vals)
     if sigmas.dim() != 2 or rgbs.shape != (*sigmas.shape, 3) or z_vals.shape != sigmas.shape:
@@ -123,7 +124,7 @@ def scene_composite(sigmas, rgbs, z_vals, white_bkgd=True):
     dev = sigmas.device
     rgb = torch.empty(P, 3, device=dev); depth = torch.empty(P, device=dev); acc = torch.empty(P, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.lib().snr_scene_composite_fwd(_p(sigmas), _p(rgbs), _p(z_vals), P, n, WHITE_BKGD if white_bkgd else 0,
+        check(_lib.lib().snr_scene_composite_fwd(_p(sigmas), _p(rgbs), _p(z_vals), P, n, int(run_length), WHITE_BKGD if white_bkgd else 0,
                                                  _p(rgb), _p(depth), _p(acc), _stream(dev)), "snr_scene_composite_fwd")
     return rgb, depth, acc
 

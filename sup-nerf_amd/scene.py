@@ -103,7 +103,7 @@ def render_scene_batch(model, device, batch_rays, diags, shapecodes, texturecode
     empty = empty.view(Nr, Nb * n_samples)
     rgb = torch.where(empty[..., None], torch.ones_like(rgb), rgb)                       # empty space: white, zero density
     sig = torch.where(empty, torch.zeros_like(sig), sig)
-    return ops.scene_composite(sig, rgb, z_vals.view(Nr, Nb * n_samples), white_bkgd=True)
+    return ops.scene_composite(sig, rgb, z_vals.view(Nr, Nb * n_samples), white_bkgd=True, run_length=n_samples)
 
 
 def vis_scene(model, device, obj_poses, obj_wlh, shapecodes, texturecodes, K, H, W, n_samples, manipulation=(0.0, 0.0, 0.0),

@@ -193,9 +193,17 @@ def test_fused_loop_equals_api_loop(amd, dev, oracle_params, precision):
     assert all(p.requires_grad for p in model.parameters())                       # the loop thaws what it froze
     d = (a[0] - b[0]).abs()
     print(f"[fused vs api loop, {precision}] max metric differences {d.max(dim=0)[0].tolist()}")
-    assert float(d[:3].max()) < 2e-4, d[:3]                                       # before the first optimiser step
-    assert float(d[:, 0].max()) < 0.05 and float(d[:, 1].max()) < 2e-3 and float(d[:, 2:].max()) < 2e-3, d
-    assert md(a[3], b[3]) < 2e-3 and md(a[1], b[1]) < 2e-2
+    assert float(d[:3].max()) < 2e-4, d[:3]                                       # before the first optimiser step: the same numbers
+    # afterwards fp32 round-off through Adam's normalisation (and its restart at the lr halving); the depth column is the rendered depth of
+    # near-empty space at random-init density, the most sensitive quantity of the four
+    assert float(d[:, 0].max()) < 0.05 and float(d[:, 1].max()) < 5e-2 and float(d[:, 2].max()) < 2e-3 and float(d[:, 3].max()) < 5e-2, d
+    assert md(a[3], b[3]) < 5e-2 and md(a[1], b[1]) < 5e-2
+    # one optimiser step, compared sharply: both loops stopped right after their first AdamW update
+    hp1 = D.load_hpams(); hp1["render_im_sz"] = 16; hp1["optimize"]["num_opts"] = 3
+    a1 = D.optimize_object_api(model, dev, obj, hp1, sc0, tc0, reg_iters=1, seed=9, jitter=jit[:3])
+    b1 = D.optimize_object(model, dev, obj, hp1, sc0, tc0, reg_iters=1, seed=9, jitter=jit[:3])
+    # (Adam's first step is lr * g / (|g| + eps): where |g| ~ eps the two loops' round-off decides the step, hence the 1e-3 of lr = 0.02)
+    assert md(a1[1], b1[1]) < 2e-3 and md(a1[2], b1[2]) < 2e-3 and float((a1[0] - b1[0]).abs().max()) < 2e-4
     # the global-RNG jitter stream: two torch.rand(S) per iteration, in order, like the reference's loop
     torch.manual_seed(77); a2 = D.optimize_object_api(model, dev, obj, hp, sc0, tc0, reg_iters=1, seed=9)
     torch.manual_seed(77); b2 = D.optimize_object(model, dev, obj, hp, sc0, tc0, reg_iters=1, seed=9)
