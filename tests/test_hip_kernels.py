@@ -149,9 +149,12 @@ def test_partial_workgroups_stay_inside_their_buffers(amd, dev, packed, oracle_p
 def test_scene_composite_golden(amd, dev, golden):
     """Per-pixel depth merge + white-background composite (scripts/demo.py:555-565) on the reference's own batch."""
     g = golden("scene")
-    rgb, depth, acc = amd.ops.scene_composite(g["b0_sigmas"].to(dev), g["b0_rgbs"].to(dev), g["b0_z"].to(dev))
-    assert maxdiff(rgb, g["b0_rgb"]) < TOL_RGB and maxdiff(acc, g["b0_acc"]) < TOL_ACC
-    assert float((depth.cpu() - g["b0_depth"]).abs().mean()) < TOL_DEPTH_MEAN and maxdiff(depth, g["b0_depth"]) < TOL_DEPTH_MAX
+    n_obj = int(g["obj_poses"].shape[0])
+    S = g["b0_z"].shape[1] // n_obj
+    for run in (0, S):          # rank sort, and the merge of the per-object sorted lists (what scene.py asks for)
+        rgb, depth, acc = amd.ops.scene_composite(g["b0_sigmas"].to(dev), g["b0_rgbs"].to(dev), g["b0_z"].to(dev), run_length=run)
+        assert maxdiff(rgb, g["b0_rgb"]) < TOL_RGB and maxdiff(acc, g["b0_acc"]) < TOL_ACC
+        assert float((depth.cpu() - g["b0_depth"]).abs().mean()) < TOL_DEPTH_MEAN and maxdiff(depth, g["b0_depth"]) < TOL_DEPTH_MAX
 
 
 @pytest.mark.parametrize("Nb,S,P", [(1, 64, 37), (3, 64, 501), (5, 64, 130), (8, 64, 64), (7, 33, 50), (16, 64, 9), (2, 5, 1000)])
@@ -167,14 +170,29 @@ def test_scene_composite_shapes(amd, dev, Nb, S, P):
     z[empty] = -1; sig[empty] = 0; rgb[empty] = 1
     z, sig, rgb = z.view(P, Nb * S), sig.view(P, Nb * S), rgb.view(P, Nb * S, 3)
     want = O.scene_composite(sig, rgb, z)
-    got = amd.ops.scene_composite(sig.to(dev), rgb.to(dev), z.to(dev))
-    assert maxdiff(got[0], want[0]) < TOL_RGB and maxdiff(got[2], want[2]) < TOL_ACC
-    assert maxdiff(got[1], want[1]) < TOL_DEPTH_MAX
+    generic = amd.ops.scene_composite(sig.to(dev), rgb.to(dev), z.to(dev))
+    for run in (0, S):
+        got = amd.ops.scene_composite(sig.to(dev), rgb.to(dev), z.to(dev), run_length=run)
+        assert maxdiff(got[0], want[0]) < TOL_RGB and maxdiff(got[2], want[2]) < TOL_ACC
+        assert maxdiff(got[1], want[1]) < TOL_DEPTH_MAX
+        assert all(torch.equal(a, b) for a, b in zip(got, generic))             # the merge path places every sample where the rank sort does
     if Nb > 1:      # two objects sharing every depth exactly: the reference keeps the later sample of each pair and drops the other
         z2 = z.clone().view(P, Nb, S); z2[:, 1] = z2[:, 0]; z2 = z2.view(P, Nb * S)
         want2 = O.scene_composite(sig, rgb, z2)
-        got2 = amd.ops.scene_composite(sig.to(dev), rgb.to(dev), z2.to(dev))
-        assert maxdiff(got2[0], want2[0]) < TOL_RGB and maxdiff(got2[1], want2[1]) < TOL_DEPTH_MAX and maxdiff(got2[2], want2[2]) < TOL_ACC
+        for run in (0, S):
+            got2 = amd.ops.scene_composite(sig.to(dev), rgb.to(dev), z2.to(dev), run_length=run)
+            assert maxdiff(got2[0], want2[0]) < TOL_RGB and maxdiff(got2[1], want2[1]) < TOL_DEPTH_MAX and maxdiff(got2[2], want2[2]) < TOL_ACC
+    # repeated depths INSIDE a list (ties within one object and across objects), and a wrong hint: lists that are not ascending must give the
+    # rank sort's answer (the kernel checks the order per pixel)
+    z3 = (z.view(P, Nb, S) * 4).round() / 4
+    z3 = z3.view(P, Nb * S)
+    want3 = O.scene_composite(sig, rgb, z3)
+    got3 = amd.ops.scene_composite(sig.to(dev), rgb.to(dev), z3.to(dev), run_length=S)
+    assert maxdiff(got3[0], want3[0]) < TOL_RGB and maxdiff(got3[1], want3[1]) < TOL_DEPTH_MAX and maxdiff(got3[2], want3[2]) < TOL_ACC
+    zr = z.view(P, Nb, S).flip(-1).reshape(P, Nb * S).contiguous()
+    want4 = O.scene_composite(sig, rgb, zr)
+    got4 = amd.ops.scene_composite(sig.to(dev), rgb.to(dev), zr.to(dev), run_length=S)
+    assert maxdiff(got4[0], want4[0]) < TOL_RGB and maxdiff(got4[1], want4[1]) < TOL_DEPTH_MAX and maxdiff(got4[2], want4[2]) < TOL_ACC
 
 
 def test_scene_composite_limits(amd, dev):
@@ -184,6 +202,8 @@ def test_scene_composite_limits(amd, dev):
         amd.ops.scene_composite(torch.zeros(2, 2000, device=dev), torch.zeros(2, 2000, 3, device=dev), torch.zeros(2, 2000, device=dev))
     with pytest.raises(amd.SnrError):
         amd.ops.scene_composite(torch.zeros(2, 8, device=dev), torch.zeros(2, 8, 3, device=dev), torch.zeros(2, 9, device=dev))
+    with pytest.raises(amd.SnrError):          # a list length that does not divide the samples per pixel
+        amd.ops.scene_composite(torch.zeros(2, 8, device=dev), torch.zeros(2, 8, 3, device=dev), torch.zeros(2, 8, device=dev), run_length=3)
 
 
 # ------------------------------------------------------------------ encode
