@@ -3,6 +3,7 @@
 Everything here requires fp32 tensors on an AMD GPU (``tensor.is_cuda`` under PyTorch-ROCm).
 There is no CPU/eager fallback -- a CPU tensor raises."""
 import ctypes as C
+import warnings
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -10,6 +11,7 @@ import torch
 from . import _lib
 from ._lib import BF16X3, FP32, METRIC_Z, WHITE_BKGD, Z_PER_OBJECT, Z_PER_RAY, Z_SHARED, RenderArgs, SnrError, check
 
+_AUTO_DOWNGRADES = set()
 IDENTITY_FRAME = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
 PRECISIONS = {"fp32": FP32, "bf16x3": BF16X3}
 
@@ -21,6 +23,13 @@ def resolve_precision(precision, shape_blocks, texture_blocks, points_per_obj) -
         return precision
     if precision is None or precision == "auto":
         ok = _lib.lib().snr_precision_supported(BF16X3, shape_blocks, texture_blocks, int(points_per_obj))
+        if not ok:
+            key = (shape_blocks, texture_blocks, int(points_per_obj) % 32 == 0)
+            if key not in _AUTO_DOWNGRADES:          # say it once per configuration: 'auto' is several times slower here
+                _AUTO_DOWNGRADES.add(key)
+                warnings.warn(f"supnerf_amd: precision 'auto' runs the exact fp32 kernels for shape_blocks={shape_blocks}, texture_blocks={texture_blocks}, "
+                              f"{points_per_obj} points per object: the split-bf16 kernels need shape_blocks + texture_blocks <= 4 and whole 32-point tiles "
+                              "per object", RuntimeWarning, stacklevel=3)
         return BF16X3 if ok else FP32
     if precision not in PRECISIONS:
         raise SnrError(f"unknown precision {precision!r}")
@@ -341,6 +350,9 @@ def decoder_bwd(xyz, viewdir, latent, packed, masks, sigmas, d_sig, d_rgb, shape
                 need_latent=True, need_xyz=True, need_dir=True, precision="fp32", layer_grads=None):
     P, B = xyz.shape[0], latent.shape[0]
     dev = xyz.device
+    if need_latent and shape_blocks + texture_blocks > 0 and (P // B) % 32:
+        raise SnrError(f"gradient wrt the latent codes needs whole 32-point wave tiles per object, got {P // B} points per object "
+                       f"({P} points / {B} codes): pad the ray batch of every object to a multiple of 32 / n_samples rays, or detach the codes")
     d_latent = torch.empty_like(latent) if need_latent else None
     d_xyz = torch.empty_like(xyz) if need_xyz else None
     d_dir = torch.empty_like(viewdir) if need_dir else None
@@ -547,7 +559,15 @@ def render_bwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg: Re
                need_o=True, need_d=True, need_t=False, need_latent=True):
     """Backward of the fused render on what ``render_fwd(..., save_for_bwd=True)`` saved: one launch + the small reduction of the
     latent-term partials.  Returns (d_rays_o, d_rays_d, d_t, d_latent), None where not asked for."""
+    # (contiguous fp32 like render_fwd made them: get_rays' origins, for one, are a stride-0 view of the pose's 3 numbers)
+    rays_o, rays_d, t_vals, xyz_div, z_scale, latent = [_f32c(t) for t in (rays_o, rays_d, t_vals, xyz_div, z_scale, latent)]
+    _need_gpu(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, sig, rgbs, masks)
+    if sig is None or rgbs is None or masks is None:
+        raise SnrError("render_bwd needs what render_fwd(..., save_for_bwd=True) saved: per-point sigmas, rgbs and the ReLU bits")
     dev = rays_o.device
+    if need_latent and cfg.shape_blocks + cfg.texture_blocks > 0 and (cfg.rays_per_obj * cfg.n_samples) % 32:
+        raise SnrError(f"gradient wrt the latent codes needs whole 32-point wave tiles per object, got {cfg.rays_per_obj} rays x {cfg.n_samples} "
+                       "samples per object: pad the ray batch of every object so that rays x samples is a multiple of 32, or detach the codes")
     d_lat = torch.empty_like(latent) if need_latent else None
     d_o = torch.zeros_like(rays_o) if need_o else None
     d_d = torch.zeros_like(rays_d) if need_d else None

@@ -25,14 +25,25 @@ constexpr int NL = 6;
 constexpr int LAYER_BYTES = 16 * 8 * 2 * 1024;       // 256 KiB: [s][tile][plane][lane][8 bf16]
 constexpr int ACT_BYTES = 2 * 16 * 4 * 1024;         // 128 KiB: [plane][s][cb][lane][8 bf16]
 
+// timing-experiment switches (outputs of these builds are garbage by design): -DNO_EPI no conversion / LDS write-back, -DNO_BAR no
+// barriers, -DNO_GLOAD the A fragments are loaded once, -DIL_VALU=n VALU ops requested per MFMA (0: no interleave request)
 #ifndef IL_VALU
 #define IL_VALU 2
 #endif
+#if IL_VALU > 0
 #define INTERLEAVE(N_MFMA)                                                                 \
     _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA); ++g_) {                              \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
         __builtin_amdgcn_sched_group_barrier(0x002, IL_VALU, 0);                           \
     }
+#else
+#define INTERLEAVE(N_MFMA)
+#endif
+#ifdef NO_BAR
+#define BARRIER() do {} while (0)
+#else
+#define BARRIER() __syncthreads()
+#endif
 
 __host__ __device__ inline float hash_unit(unsigned a, unsigned b, unsigned c) {     // deterministic value in [-1, 1)
     unsigned x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x165667B1u) * 0xC2B2AE3Du;
@@ -44,7 +55,10 @@ struct Frags { bf16x8 ah[2][2], al[2][2]; };     // the wave's A fragments of HA
 
 // A fragments of half HH of phase Q (steps 4w'+Q, w' = 2*HH, 2*HH+1) of the layer at Wl, for this wave's tiles 2w, 2w+1
 template <int Q, int HH>
-__device__ __forceinline__ void load_frags(Frags& f, const char* __restrict__ Wl, int wave, int lane) {
+__device__ __forceinline__ void load_frags(Frags& f, const char* __restrict__ Wl, int wave, int lane, bool force = false) {
+#ifdef NO_GLOAD
+    if (!force) { asm volatile("" : "+v"(f.ah[0][0]), "+v"(f.al[0][0])); return; }
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int s = 4 * (2 * HH + i) + Q;
@@ -84,6 +98,9 @@ __device__ __forceinline__ void phase_mma(f32x16 (&acc)[2][4], const Frags& f, c
 // into slot 4w+Q
 template <int Q, int HH>
 __device__ __forceinline__ void write_part(const f32x16 (&prev)[2][4], char* lds, int wave, int lane) {
+#ifdef NO_EPI
+    return;
+#endif
     constexpr int T = Q >> 1, HALF = Q & 1;
     const int s = 4 * wave + Q;
 #pragma unroll
@@ -129,16 +146,16 @@ __device__ __forceinline__ void layer(f32x16 (&prev)[2][4], f32x16 (&cur)[2][4],
     init_bias(cur, bias, wave, lane >> 5);
     write_part<0, 0>(prev, lds, wave, lane);
     write_part<0, 1>(prev, lds, wave, lane);
-    __syncthreads();
+    BARRIER();
     HALF_PHASE(0, 0, fa, (load_frags<0, 1>(fb, Wl, wave, lane)), (write_part<1, 0>(prev, lds, wave, lane)))
     HALF_PHASE(0, 1, fb, (load_frags<1, 0>(fa, Wl, wave, lane)), (write_part<1, 1>(prev, lds, wave, lane)))
-    __syncthreads();
+    BARRIER();
     HALF_PHASE(1, 0, fa, (load_frags<1, 1>(fb, Wl, wave, lane)), (write_part<2, 0>(prev, lds, wave, lane)))
     HALF_PHASE(1, 1, fb, (load_frags<2, 0>(fa, Wl, wave, lane)), (write_part<2, 1>(prev, lds, wave, lane)))
-    __syncthreads();
+    BARRIER();
     HALF_PHASE(2, 0, fa, (load_frags<2, 1>(fb, Wl, wave, lane)), (write_part<3, 0>(prev, lds, wave, lane)))
     HALF_PHASE(2, 1, fb, (load_frags<3, 0>(fa, Wl, wave, lane)), (write_part<3, 1>(prev, lds, wave, lane)))
-    __syncthreads();
+    BARRIER();
     HALF_PHASE(3, 0, fa, (load_frags<3, 1>(fb, Wl, wave, lane)), ((void)0))
     HALF_PHASE(3, 1, fb, (load_frags<0, 0>(fa, Wnext, wave, lane)), ((void)0))
 }
@@ -160,7 +177,8 @@ fs_kernel(const char* __restrict__ W, const float* __restrict__ bias, float* __r
             for (int r = 0; r < 16; ++r)
                 X[t][cb][r] = fabsf(hash_unit(blockIdx.x, 32 * cb + n, 64 * wave + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3)));
     Frags fa, fb;
-    load_frags<0, 0>(fa, W, wave, lane);
+    load_frags<0, 0>(fa, W, wave, lane, true);
+    load_frags<0, 1>(fb, W, wave, lane, true);
 #pragma unroll 1
     for (int l = 0; l < NL; l += 2) {
         layer(X, Y, fa, fb, W + (size_t)l * LAYER_BYTES, W + (size_t)(l + 1) * LAYER_BYTES, bias + l * 256, lds, wave, lane);

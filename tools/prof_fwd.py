@@ -7,7 +7,7 @@ from supnerf_amd import ops, synthetic as SY, utils as U
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-bwd = len(sys.argv) > 3 and sys.argv[3] == "bwd"
+bwd = len(sys.argv) > 3 and sys.argv[3] == "bwd"      # "bwd": the forward that saves the ReLU bits + the backward
 dev = torch.device("cuda:0")
 model = A.CodeNeRF(3, 1); model.load_state_dict(SY.init_decoder_params()); model = model.to(dev); model.precision = prec
 N, S = 4096, 64
