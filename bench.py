@@ -415,7 +415,7 @@ def main():
         P_s, n_s = 131072, 3 * N_SAMPLES
         z_s = (torch.rand(P_s, 3, 1, device=dev) * 20 + 2 + torch.sort(torch.rand(P_s, 3, N_SAMPLES, device=dev), dim=-1)[0] * 4).view(P_s, n_s)
         sig_s, rgb_s = torch.rand(P_s, n_s, device=dev), torch.rand(P_s, n_s, 3, device=dev)
-        t_scn = timed_ev(lambda: ops.scene_composite(sig_s, rgb_s, z_s, True))
+        t_scn = timed_ev(lambda: ops.scene_composite(sig_s, rgb_s, z_s, True, run_length=N_SAMPLES))      # as scene.py calls it
         scn_bytes = P_s * n_s * 20 + P_s * 20
         del z_s, sig_s, rgb_s, sig_h, rgb_h
         mk = lambda b, t: {"GB_per_s": b / t / 1e9, "ms": t * 1e3, "bytes": b, "frac_of_8TBps": b / t / 8e12}

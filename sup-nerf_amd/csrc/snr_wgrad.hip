@@ -1,0 +1,188 @@
+// Weight gradients of the per-point decoder layers for gfx950 (training mode, SURVEY 8 a9 mode B / f2):
+//     dW[i][j] = sum_p G[p][i] * X[p][j],      db[i] = sum_p G[p][i]
+// with G (P, n_out) the gradient wrt a layer's pre-activation and X (P, n_in) the layer's input, both row-major fp32 as the training
+// forward / backward kernels wrote them.  This is the weight half of loss_total.mean().backward() (src/trainer_unified_nuscenes.py:334),
+// replacing one library GEMM + one column-sum per layer.
+//
+// Split-K over the points, exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak): a workgroup of 4 waves owns one
+// slice of points and the whole (<= 256 x 256) product, wave (wr, wc) the 128 x 128 quadrant = 16 accumulator tiles (256 AGPRs).
+// The reduction dimension is the POINT index, so the row-major operands need no transpose: lane (n, h) takes G[p + h][4n .. 4n+3] and
+// X[p + h][4n .. 4n+3] with one 16-byte load each and these ARE the A / B operands of a k = 2 step for the four row tiles
+// {4n + e} x four column tiles {4m + e'} (the tiles interleave rows / columns with stride 4; the final store undoes it with 16-byte
+// stores).  Per k-step and wave: 2 loads, 16 MFMAs (1024 cycles) -- matrix-bound; G and X are read from HBM once.
+// The per-slice partial products go to a workspace and are summed over the slices in slice order (deterministic, no atomics).
+#include "snr_device.hpp"
+#include "snr_host.hpp"
+
+namespace snr {
+
+constexpr int WG_DEPTH = 4;            // k-steps of operands in flight per wave
+
+__global__ void __launch_bounds__(256, 1)
+wgrad_mfma_kernel(const float* __restrict__ G, long long ldg, int n_out, const float* __restrict__ X, long long ldx, int n_in,
+                  long long n_points, long long points_per_slice, float* __restrict__ part_w /* [slice][256][256] */,
+                  float* __restrict__ part_b /* [slice][256] or null */) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const long long p_begin = blockIdx.x * points_per_slice;
+    const long long p_end = p_begin + points_per_slice < n_points ? p_begin + points_per_slice : n_points;
+    const int row0 = 128 * wr + 4 * n, col0 = 128 * wc + 4 * n;
+    const bool row_ok = row0 < n_out, col_ok = col0 < n_in;           // n_out, n_in are multiples of 4 (checked by the launcher)
+    const float* gp = G + row0;
+    const float* xp = X + col0;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](long long p, f32x4& a, f32x4& b) {          // the operands of the k-step at points p, p + 1 (this lane: p + h)
+        const long long q = p + h;
+        const bool live = q < p_end;
+        a = (live && row_ok) ? *reinterpret_cast<const f32x4*>(gp + q * ldg) : zero;
+        b = (live && col_ok) ? *reinterpret_cast<const f32x4*>(xp + q * ldx) : zero;
+    };
+    f32x4 a[WG_DEPTH], b[WG_DEPTH];
+#pragma unroll
+    for (int d = 0; d < WG_DEPTH; ++d) load(p_begin + 2 * d, a[d], b[d]);
+    for (long long p = p_begin; p < p_end; p += 2 * WG_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < WG_DEPTH; ++d) {
+            const f32x4 av = a[d], bv = b[d];
+            load(p + 2 * (WG_DEPTH + d), a[d], b[d]);            // past the slice: zeros (no access)
+            bsum += av;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[f], acc[e][f], 0, 0, 0);
+        }
+    }
+    // tile (e, f): D[r][c] = sum_p G[p][128 wr + 4 r + e] X[p][128 wc + 4 c + f];  this lane: c = n, r = (reg & 3) + 8 (reg >> 2) + 4 h
+    float* out = part_w + (long long)blockIdx.x * 256 * 256;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const f32x4 v = {acc[e][0][reg], acc[e][1][reg], acc[e][2][reg], acc[e][3][reg]};
+            *reinterpret_cast<f32x4*>(out + (128 * wr + 4 * r + e) * 256 + 128 * wc + 4 * n) = v;
+        }
+    if (part_b && wc == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bsum[e] = sum_halves(bsum[e]);
+        if (h == 0) *reinterpret_cast<f32x4*>(part_b + (long long)blockIdx.x * 256 + row0) = bsum;
+    }
+}
+
+// sum of the per-slice partials in slice order -> dW (n_out x n_in, leading dimension ld_dw) and db
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b, int n_slices, int n_out,
+                                                           int n_in, float* __restrict__ dW, long long ld_dw, float* __restrict__ db) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // over 256 x 256 (+ 256 for the bias)
+    if (idx < 256 * 256) {
+        const int i = idx >> 8, j = idx & 255;
+        if (i < n_out && j < n_in) {
+            float s0 = 0.f, s1 = 0.f;
+            int k = 0;
+            for (; k + 1 < n_slices; k += 2) { s0 += part_w[(long long)k * 65536 + idx]; s1 += part_w[(long long)(k + 1) * 65536 + idx]; }
+            if (k < n_slices) s0 += part_w[(long long)k * 65536 + idx];
+            dW[i * ld_dw + j] = s0 + s1;
+        }
+    } else if (db && part_b) {
+        const int i = idx - 256 * 256;
+        if (i < n_out) {
+            float s = 0.f;
+            for (int k = 0; k < n_slices; ++k) s += part_b[(long long)k * 256 + i];
+            db[i] = s;
+        }
+    }
+}
+
+// narrow outputs (the density head: 1 row, the colour head: 3 rows): one thread per input column, points strided over the slices;
+// X is streamed once with coalesced loads, the <= 4 gradient values of a point are broadcast loads
+__global__ void __launch_bounds__(256) wgrad_small_kernel(const float* __restrict__ G, long long ldg, int n_out, const float* __restrict__ X, long long ldx,
+                                                          int n_in, long long n_points, long long points_per_slice, float* __restrict__ part_w,
+                                                          float* __restrict__ part_b) {
+    const int j = threadIdx.x;
+    const long long p_begin = blockIdx.x * points_per_slice;
+    const long long p_end = p_begin + points_per_slice < n_points ? p_begin + points_per_slice : n_points;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long p = p_begin; p < p_end; ++p) {
+        const float x = j < n_in ? X[p * ldx + j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float g = i < n_out ? G[p * ldg + i] : 0.f;
+            acc[i] += g * x;
+            bs[i] += g;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part_w[((long long)blockIdx.x * 4 + i) * 256 + j] = acc[i];
+    if (j < 4) part_b[(long long)blockIdx.x * 4 + j] = bs[j];
+}
+__global__ void __launch_bounds__(256) wgrad_small_reduce_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b, int n_slices, int n_out,
+                                                                 int n_in, float* __restrict__ dW, long long ld_dw, float* __restrict__ db) {
+    const int j = threadIdx.x, i = blockIdx.x;       // grid = n_out
+    float s = 0.f;
+    for (int k = 0; k < n_slices; ++k) s += part_w[((long long)k * 4 + i) * 256 + j];
+    if (j < n_in) dW[i * ld_dw + j] = s;
+    if (db && j == 0) {
+        float t = 0.f;
+        for (int k = 0; k < n_slices; ++k) t += part_b[(long long)k * 4 + i];
+        db[i] = t;
+    }
+}
+
+}  // namespace snr
+
+using namespace snr;
+
+static void wgrad_plan(int64_t n_points, int n_out, long long* pps, int* n_slices) {
+    // one slice per compute unit and pass where the points allow it; a slice is a whole number of k-step groups
+    const long long unit = 2 * WG_DEPTH;
+    long long per = (n_points + 255) / 256;
+    const long long min_per = n_out >= 32 ? 512 : 4096;
+    if (per < min_per) per = min_per;
+    per = (per + unit - 1) / unit * unit;
+    *pps = per;
+    *n_slices = (int)((n_points + per - 1) / per);
+}
+
+extern "C" {
+
+size_t snr_weight_grad_ws_bytes(int64_t n_points, int n_out, int n_in) {
+    (void)n_in;
+    if (n_points <= 0 || n_out <= 0) return 256;
+    long long pps; int ns;
+    wgrad_plan(n_points, n_out, &pps, &ns);
+    return (size_t)ns * (n_out >= 32 ? (256 * 256 + 256) : (4 * 256 + 4)) * sizeof(float) + 256;
+}
+
+int snr_weight_grad(const float* G, int64_t ldg, int n_out, const float* X, int64_t ldx, int n_in, int64_t n_points,
+                    float* dW, int64_t ld_dw, float* db, void* workspace, size_t ws_bytes, void* stream_) {
+    if (!G || !X || !dW || n_out < 1 || n_in < 1 || n_out > 256 || n_in > 256 || n_points < 0 || ldg < n_out || ldx < n_in || ld_dw < n_in) return SNR_E_ARG;
+    hipStream_t st = (hipStream_t)stream_;
+    if (!workspace || ws_bytes < snr_weight_grad_ws_bytes(n_points, n_out, n_in)) return SNR_E_WORKSPACE;
+    long long pps; int ns;
+    wgrad_plan(n_points > 0 ? n_points : 1, n_out, &pps, &ns);
+    float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (n_out >= 32) {
+        // 16-byte operand loads: whole groups of 4 rows / columns and aligned rows
+        if ((n_out & 3) || (n_in & 3) || (ldg & 3) || (ldx & 3) || ((uintptr_t)G & 15) || ((uintptr_t)X & 15)) return SNR_E_UNSUPPORTED;
+        float* part_w = ws; float* part_b = ws + (long long)ns * 65536;
+        if (n_points == 0) ns = 0;
+        if (ns) wgrad_mfma_kernel<<<ns, 256, 0, st>>>(G, ldg, n_out, X, ldx, n_in, n_points, pps, part_w, db ? part_b : nullptr);
+        wgrad_reduce_kernel<<<(256 * 256 + 256 + 255) / 256, 256, 0, st>>>(part_w, db ? part_b : nullptr, ns, n_out, n_in, dW, ld_dw, db);
+    } else {
+        if (n_out > 4) return SNR_E_UNSUPPORTED;        /* 5..31 output rows: no such layer in the decoder */
+        float* part_w = ws; float* part_b = ws + (long long)ns * 4 * 256;
+        if (n_points == 0) ns = 0;
+        if (ns) wgrad_small_kernel<<<ns, 256, 0, st>>>(G, ldg, n_out, X, ldx, n_in, n_points, pps, part_w, part_b);
+        wgrad_small_reduce_kernel<<<n_out, 256, 0, st>>>(part_w, part_b, ns, n_out, n_in, dW, ld_dw, db);
+    }
+    return snr_check_launch_();
+}
+
+}  // extern "C"

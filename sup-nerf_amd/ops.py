@@ -390,11 +390,33 @@ class DecoderPoints(torch.autograd.Function):
         return d_xyz, d_dir, d_lat, None, None, None, None
 
 
+def weight_grad(G, n_out, X, n_in, want_bias=True, out=None, ws=None):
+    """dW (n_out, n_in) = G[:, :n_out]^T X[:, :n_in] and db (n_out,) = column sums of G, one split-K MFMA launch + one reduction
+    (include/supnerf_hip.h: snr_weight_grad).  G, X: 2-D fp32 row-major views (a column slice of a wider buffer is fine).  ``out``:
+    optional (dW_view, db) to write into (dW_view may be a column block of a wider matrix)."""
+    _need_gpu(G, X)
+    if G.dim() != 2 or X.dim() != 2 or G.shape[0] != X.shape[0] or G.stride(1) != 1 or X.stride(1) != 1 or G.dtype != torch.float32 or X.dtype != torch.float32:
+        raise SnrError(f"weight_grad: G {tuple(G.shape)} / X {tuple(X.shape)} must be fp32 (P, n) row-major views of the same points")
+    if n_out > G.shape[1] or n_in > X.shape[1]:
+        raise SnrError("weight_grad: n_out / n_in exceed the operands' columns")
+    P, dev = G.shape[0], G.device
+    dW, db = out if out is not None else (torch.empty(n_out, n_in, device=dev), torch.empty(n_out, device=dev) if want_bias else None)
+    if dW.stride(1) != 1:
+        raise SnrError("weight_grad: dW must be row-major")
+    nbytes = _lib.lib().snr_weight_grad_ws_bytes(P, n_out, n_in)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().snr_weight_grad(_p(G), G.stride(0), n_out, _p(X), X.stride(0), n_in, P, _p(dW), dW.stride(0), _p(db), _p(ws), ws.numel(),
+                                         _stream(dev)), "snr_weight_grad")
+    return dW, db
+
+
 class DecoderPointsTrain(torch.autograd.Function):
     """Training-mode decoder (SURVEY 8a9 mode B): like DecoderPoints but the per-point decoder WEIGHTS are inputs too and
     receive gradients.  The fp32 kernels additionally write every layer's input X_l (forward) and pre-activation
-    gradient G_l (backward) to HBM, and the weight gradients are plain GEMMs dW_l = G_l^T X_l, db_l = sum_p G_l on the
-    library BLAS (hipBLASLt through torch.matmul).  ``weights`` = the per-point tensors in per_point_tensor_names order."""
+    gradient G_l (backward) to HBM, and the weight gradients dW_l = G_l^T X_l, db_l = sum_p G_l come from the split-K fp32-MFMA kernel
+    behind ``weight_grad`` (no library BLAS).  ``weights`` = the per-point tensors in per_point_tensor_names order."""
 
     @staticmethod
     def forward(ctx, xyz, viewdir, latent, shape_blocks, texture_blocks, *weights):
@@ -421,29 +443,30 @@ class DecoderPointsTrain(torch.autograd.Function):
         d_lat, d_xyz, d_dir = decoder_bwd(xyz, viewdir, latent, packed, masks, sig, d_sig, d_rgb, sb, tb,
                                           ctx.needs_input_grad[2], ctx.needs_input_grad[0], ctx.needs_input_grad[1], precision="fp32",
                                           layer_grads=G)
-        # ---- weight gradients: one GEMM per layer (X of layer 0 and the direction features are recomputed, they are tiny)
-        def pe(v, L):
+        # ---- weight gradients: dW_l = G_l^T X_l, db_l = sum_p G_l on the split-K MFMA kernel (snr_weight_grad), one launch + one
+        # reduction per layer; X of layer 0 and the direction features are the positional encodings (recomputed: 63 + 27 columns)
+        def pe_padded(v, L, width):
             arg = torch.cat([v * (2.0 ** i) for i in range(L)], -1)
-            return torch.cat([v, torch.sin(arg), torch.cos(arg)], -1)
+            return torch.cat([v, torch.sin(arg), torch.cos(arg), v.new_zeros(v.shape[0], width - 3 - 6 * L)], -1)
         li_view, li_rgb0 = sb + 2, sb + tb + 3
-        grads = []
-        for li in range(n_slots):              # MFMA layers in order; the two small heads are interleaved below
-            g = G[li, :, :128] if li == li_rgb0 else G[li]
+        ws = torch.empty(_lib.lib().snr_weight_grad_ws_bytes(P, 256, 256), dtype=torch.uint8, device=dev)
+        by_layer = {}
+        for li in range(n_slots):              # MFMA layers in order; the two small heads follow
+            n_out = 128 if li == li_rgb0 else 256
             if li == 0:
-                x_in = pe(xyz, 10)
+                by_layer[li] = weight_grad(G[li], n_out, pe_padded(xyz, 10, 64), 64, ws=ws)
+                by_layer[li] = (by_layer[li][0][:, :63].contiguous(), by_layer[li][1])
             elif li == li_view:
-                x_in = torch.cat([act[li - 1], pe(viewdir, 4)], -1)
+                dW = torch.empty(256, 256 + 28, device=dev)
+                _, db = weight_grad(G[li], 256, act[li - 1], 256, out=(dW[:, :256], torch.empty(256, device=dev)), ws=ws)
+                weight_grad(G[li], 256, pe_padded(viewdir, 4, 28), 28, out=(dW[:, 256:], None), ws=ws)
+                by_layer[li] = (dW[:, :283].contiguous(), db)
             else:
-                x_in = act[li - 1]
-            dW, db = g.t() @ x_in, g.sum(0)
-            grads.append((li, dW, db))
-        by_layer = {li: (dW, db) for li, dW, db in grads}
+                by_layer[li] = weight_grad(G[li], n_out, act[li - 1], 256, ws=ws)
         # sigma head: pre = w . y4 + b with y4 = input of enc_viewdir; d pre = d_sig * sigmoid(pre) = d_sig * (1 - exp(-sigma))
-        dpre = d_sig * (1 - torch.exp(-sig))
-        y4 = act[li_view - 1]
-        d_sigma_w, d_sigma_b = (dpre[None, :] @ y4), dpre.sum().reshape(1)
-        h7 = act[n_slots - 1][:, :128]
-        d_rgb2_w, d_rgb2_b = d_rgb.t() @ h7, d_rgb.sum(0)
+        dpre = (d_sig * (1 - torch.exp(-sig))).reshape(P, 1)
+        d_sigma_w, d_sigma_b = weight_grad(dpre, 1, act[li_view - 1], 256, ws=ws)
+        d_rgb2_w, d_rgb2_b = weight_grad(d_rgb.reshape(P, 3), 3, act[n_slots - 1], 128, ws=ws)
         out = []
         order = [0] + list(range(1, sb + 1)) + [sb + 1, "sigma", li_view] + list(range(sb + 3, sb + 3 + tb)) + [li_rgb0, "rgb2"]
         for k in order:

@@ -135,10 +135,17 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[2][4], const float* __re
 
 // one layer: prev (finished sums of the layer before) -> LDS in four parts under this layer's MFMAs -> cur.
 // fa holds the A fragments of the first half of phase 0 on entry and those of the NEXT layer's on exit.
+#ifdef VMEM_FIRST      /* ask for the 8 fragment loads of the next half-phase at the TOP of this one: LLVM otherwise sinks them to the end and the
+                          wait behind the barrier exposes a whole L2 round trip */
+#define VMEM_GROUP() __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+#else
+#define VMEM_GROUP()
+#endif
 #define HALF_PHASE(Q, HH, FUSE, FNEXT_LOAD, WRITE)                                   \
     FNEXT_LOAD;                                                                      \
     phase_mma<Q, HH>(cur, FUSE, lds, lane);                                          \
     WRITE;                                                                           \
+    VMEM_GROUP()                                                                     \
     INTERLEAVE(48)                                                                   \
     __builtin_amdgcn_sched_barrier(0);
 __device__ __forceinline__ void layer(f32x16 (&prev)[2][4], f32x16 (&cur)[2][4], Frags& fa, Frags& fb, const char* __restrict__ Wl,
@@ -179,7 +186,11 @@ fs_kernel(const char* __restrict__ W, const float* __restrict__ bias, float* __r
     Frags fa, fb;
     load_frags<0, 0>(fa, W, wave, lane, true);
     load_frags<0, 1>(fb, W, wave, lane, true);
+#ifdef UNROLL_LAYERS
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int l = 0; l < NL; l += 2) {
         layer(X, Y, fa, fb, W + (size_t)l * LAYER_BYTES, W + (size_t)(l + 1) * LAYER_BYTES, bias + l * 256, lds, wave, lane);
         layer(Y, X, fa, fb, W + (size_t)(l + 1) * LAYER_BYTES, W + (size_t)((l + 2) % NL) * LAYER_BYTES, bias + (l + 1) * 256, lds, wave, lane);
