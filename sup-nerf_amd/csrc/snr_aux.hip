@@ -72,6 +72,64 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restr
     }
 }
 
+// The same composite with 16 lanes per ray and 4 consecutive samples per lane (S <= 64, S a multiple of 4 -- every shipped config):
+// every load is 16 bytes per lane (sigma, z: one each; colour: three), four rays per wave.  In-lane serial products over the lane's
+// four samples, then an exclusive product scan over the 16 lanes of the DPP row (row_shr 1, 2, 4, 8), row sums for the outputs.
+__global__ void __launch_bounds__(256) composite_fwd16_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                              const float* __restrict__ zv, int z_mode, int flags, long long n_rays,
+                                                              long long rays_per_obj, int S, float* __restrict__ rgb,
+                                                              float* __restrict__ depth, float* __restrict__ acc) {
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const bool white = flags & SNR_WHITE_BKGD;
+    const int k0 = 4 * sub;
+    const bool valid = k0 < S;
+    for (long long base = wave0 * 4; base < n_rays; base += n_waves * 4) {
+        const long long ray = base + grp;
+        const bool live = ray < n_rays && valid;
+        const long long rr = ray < n_rays ? ray : n_rays - 1;
+        const float* zrow = zv + (z_mode == SNR_Z_SHARED ? 0 : (z_mode == SNR_Z_PER_OBJECT ? (rr / rays_per_obj) * S : rr * S));
+        f32x4 sg = {0.f, 0.f, 0.f, 0.f}, z4 = sg, c0 = sg, c1 = sg, c2 = sg;
+        if (live) {
+            sg = *reinterpret_cast<const f32x4*>(sigmas + rr * S + k0);
+            z4 = *reinterpret_cast<const f32x4*>(zrow + k0);
+            const f32x4* cp = reinterpret_cast<const f32x4*>(rgbs + (rr * S + k0) * 3);
+            c0 = cp[0]; c1 = cp[1]; c2 = cp[2];
+        }
+        const float zn = dpp_or<0x101>(0.f, z4[0]);              // row_shl:1 -- the next lane's first depth (unused where this lane ends the ray)
+        const float zz[5] = {z4[0], z4[1], z4[2], z4[3], zn};
+        const float cr[4] = {c0[0], c0[3], c1[2], c2[1]}, cg[4] = {c0[1], c1[0], c1[3], c2[2]}, cb[4] = {c0[2], c1[1], c2[0], c2[3]};
+        float alpha[4], Al[4];
+        float prod = 1.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + e;
+            const float delta = (k == S - 1) ? LAST_DELTA : zz[e + 1] - zz[e];
+            alpha[e] = 1.f - expf(-fmaxf(sg[e], 0.f) * delta);
+            Al[e] = prod;
+            prod *= live ? (1.f - alpha[e]) + TRANS_EPS : 1.f;
+        }
+        float incl = prod;
+        incl *= dpp_or<0x111>(1.f, incl); incl *= dpp_or<0x112>(1.f, incl); incl *= dpp_or<0x114>(1.f, incl); incl *= dpp_or<0x118>(1.f, incl);
+        const float excl = dpp_or<0x111>(1.f, incl);
+        float sr = 0.f, sgc = 0.f, sb = 0.f, sd = 0.f, sw = 0.f, al = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float A = excl * Al[e];
+            const float w = live ? alpha[e] * A : 0.f;
+            sr += w * cr[e]; sgc += w * cg[e]; sb += w * cb[e]; sd += w * zz[e]; sw += w;
+            if (live && k0 + e == S - 1) al = A;
+        }
+        sr = row_sum(sr); sgc = row_sum(sgc); sb = row_sum(sb); sd = row_sum(sd); sw = row_sum(sw); al = row_sum(al);
+        if (white) { const float bg = 1.f - sw; sr += bg; sgc += bg; sb += bg; }
+        if (sub == 0 && ray < n_rays) {
+            rgb[ray * 3] = sr; rgb[ray * 3 + 1] = sgc; rgb[ray * 3 + 2] = sb;
+            depth[ray] = sd; acc[ray] = al;
+        }
+    }
+}
+
 // ============================================================================ scene composite (multi-object pixels)
 // One wave per pixel.  The pixel's n = Nb*S samples (Nb per-object lists) are merged by depth with a rank sort in LDS --
 // every lane ranks its own elements against broadcast reads of the depth row -- then composited front to back with the same wave scan as every other composite here.  HBM-bound:
@@ -122,24 +180,37 @@ __global__ void __launch_bounds__(256) scene_composite_kernel(const float* __res
         }
         if (merged) {
             const int n_runs = n / run;
-            for (int i = lane; i < n; i += 64) {
-                const int r = i / run, p = i - r * run;
-                const float zi = zs[i];
-                int lt = 0, eb = 0, ea = 0;
-                for (int q = 0; q < n_runs; ++q) {
-                    const float* zr = zs + q * run;
-                    const int lb = run_bound<false>(zr, run, zi);
-                    const bool has_eq = lb < run && zr[lb] == zi;
-                    const int ub = has_eq ? lb + 1 + run_bound<true>(zr + lb + 1, run - lb - 1, zi) : lb;
-                    lt += lb;
-                    if (q < r) eb += ub - lb;
-                    else if (q > r) ea += ub - lb;
-                    else { eb += p - lb; ea += ub - p - 1; }
+            for (int base = 0; base < n; base += 256) {          // up to four own elements per pass; their payload loads fly under the searches
+                float zi[4], sg[4], cr[4], cg[4], cb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int i = base + 64 * c + lane;
+                    const bool on = i < n;
+                    zi[c] = on ? zs[i] : 0.f;
+                    sg[c] = on ? srow[i] : 0.f;
+                    cr[c] = on ? crow[3 * i] : 0.f; cg[c] = on ? crow[3 * i + 1] : 0.f; cb[c] = on ? crow[3 * i + 2] : 0.f;
                 }
-                const int pos = lt + eb;
-                s_z[pos] = zi;
-                if (eb > 0) { s_sig[pos] = 0.f; s_r[pos] = 0.f; s_g[pos] = 0.f; s_b[pos] = 0.f; }
-                if (ea == 0) { s_sig[lt] = srow[i]; s_r[lt] = crow[3 * i]; s_g[lt] = crow[3 * i + 1]; s_b[lt] = crow[3 * i + 2]; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int i = base + 64 * c + lane;
+                    if (i >= n) continue;
+                    const int r = i / run, p = i - r * run;
+                    int lt = 0, eb = 0, ea = 0;
+                    for (int q = 0; q < n_runs; ++q) {
+                        const float* zr = zs + q * run;
+                        const int lb = run_bound<false>(zr, run, zi[c]);
+                        const bool has_eq = lb < run && zr[lb] == zi[c];
+                        const int ub = has_eq ? lb + 1 + run_bound<true>(zr + lb + 1, run - lb - 1, zi[c]) : lb;
+                        lt += lb;
+                        if (q < r) eb += ub - lb;
+                        else if (q > r) ea += ub - lb;
+                        else { eb += p - lb; ea += ub - p - 1; }
+                    }
+                    const int pos = lt + eb;
+                    s_z[pos] = zi[c];
+                    if (eb > 0) { s_sig[pos] = 0.f; s_r[pos] = 0.f; s_g[pos] = 0.f; s_b[pos] = 0.f; }
+                    if (ea == 0) { s_sig[lt] = sg[c]; s_r[lt] = cr[c]; s_g[lt] = cg[c]; s_b[lt] = cb[c]; }
+                }
             }
         }
         for (int base = 0; base < n && !merged; base += 256) {           // generic rank sort: up to four own elements per pass
@@ -236,19 +307,39 @@ __global__ void __launch_bounds__(256) encode_kernel(RayGeom g, float* __restric
     }
     if (!pe_xyz) return;
     __syncthreads();
-    const long long n_here = (P - base) < 256 ? (P - base) : 256;
-    const int total = (int)n_here * D_XYZ;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int p = i / D_XYZ, f = i - p * D_XYZ;
-        float v;
-        if (f < 3) v = sx[p][f];
-        else {
-            const int q = (f - 3) % (3 * XYZ_FREQ);
+    // Each (point, frequency, axis) angle is evaluated ONCE and gives both its sine and its cosine feature; the block's 256 x 63 features
+    // are assembled in LDS and leave with 16-byte stores in flat output order (the block's slice of pe_xyz is contiguous and starts at a
+    // multiple of 256 * 63 floats, i.e. 16-byte aligned whenever pe_xyz is).
+    // (two passes of 128 points: 31.5 KiB of LDS per block keeps four blocks resident per CU)
+    __shared__ __attribute__((aligned(16))) float pe[128 * D_XYZ];
+    const long long n_blk = (P - base) < 256 ? (P - base) : 256;
+    for (int half = 0; half < 2; ++half) {
+        const int p0 = 128 * half;
+        const int n_here = (int)(n_blk - p0 < 128 ? n_blk - p0 : 128);
+        if (n_here <= 0) break;
+        const int n_pairs = n_here * 3 * XYZ_FREQ;
+        for (int i = threadIdx.x; i < n_pairs; i += 256) {
+            const int p = i / (3 * XYZ_FREQ), q = i - p * (3 * XYZ_FREQ);
             float sn, cs;
-            pe_sincos(ldexpf(sx[p][q % 3], q / 3), &sn, &cs);
-            v = (f < 3 + 3 * XYZ_FREQ) ? sn : cs;
+            pe_sincos(ldexpf(sx[p0 + p][q % 3], q / 3), &sn, &cs);
+            pe[p * D_XYZ + 3 + q] = sn;
+            pe[p * D_XYZ + 3 + 3 * XYZ_FREQ + q] = cs;
         }
-        pe_xyz[base * D_XYZ + i] = v;
+        if (threadIdx.x < n_here) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pe[threadIdx.x * D_XYZ + a] = sx[p0 + threadIdx.x][a];
+        }
+        __syncthreads();
+        const int total = n_here * D_XYZ;
+        float* dst = pe_xyz + (base + p0) * D_XYZ;          // (base + p0) * 63 floats: a multiple of 128 * 63 * 4 bytes = 16-byte aligned with pe_xyz
+        if ((((uintptr_t)dst) & 15) == 0) {
+            const int n4 = total >> 2;
+            for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(pe)[i];
+            for (int i = (n4 << 2) + threadIdx.x; i < total; i += 256) dst[i] = pe[i];
+        } else {
+            for (int i = threadIdx.x; i < total; i += 256) dst[i] = pe[i];
+        }
+        __syncthreads();
     }
 }
 
@@ -451,6 +542,12 @@ int snr_composite_fwd(const float* sigmas, const float* rgbs, const float* z_val
     if (n_rays < 0 || S < 1 || z_mode < 0 || z_mode > 2) return SNR_E_ARG;
     if (z_mode == SNR_Z_PER_OBJECT && (rays_per_obj < 1)) return SNR_E_SHAPE;
     if (rays_per_obj < 1) rays_per_obj = n_rays;
+    const bool aligned = !(((uintptr_t)sigmas | (uintptr_t)rgbs | (uintptr_t)z_vals) & 15);
+    if (S <= 64 && (S & 3) == 0 && aligned) {           /* 16-byte loads, four rays per wave */
+        const int grid = grid_for(n_rays * 16, 256, 16384);
+        composite_fwd16_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(sigmas, rgbs, z_vals, z_mode, flags, n_rays, rays_per_obj, S, rgb, depth, acc);
+        return snr_check_launch_();
+    }
     const int grid = grid_for(n_rays * 64, 256, 8192);
     composite_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(sigmas, rgbs, z_vals, z_mode, flags, n_rays, rays_per_obj, S, rgb, depth, acc);
     return snr_check_launch_();

@@ -16,7 +16,7 @@
 
 namespace snr {
 
-constexpr int WG_DEPTH = 4;            // k-steps of operands in flight per wave
+constexpr int WG_DEPTH = 8;            // k-steps of operands in flight per wave (8 x 1024 MFMA cycles cover an HBM round trip under load)
 
 __global__ void __launch_bounds__(256, 1)
 wgrad_mfma_kernel(const float* __restrict__ G, long long ldg, int n_out, const float* __restrict__ X, long long ldx, int n_in,
@@ -84,11 +84,15 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     if (idx < 256 * 256) {
         const int i = idx >> 8, j = idx & 255;
         if (i < n_out && j < n_in) {
-            float s0 = 0.f, s1 = 0.f;
+            // eight independent partial sums keep eight loads in flight; the association is fixed, so the result is the same bits every run
+            float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             int k = 0;
-            for (; k + 1 < n_slices; k += 2) { s0 += part_w[(long long)k * 65536 + idx]; s1 += part_w[(long long)(k + 1) * 65536 + idx]; }
-            if (k < n_slices) s0 += part_w[(long long)k * 65536 + idx];
-            dW[i * ld_dw + j] = s0 + s1;
+            for (; k + 7 < n_slices; k += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[u] += part_w[(long long)(k + u) * 65536 + idx];
+            }
+            for (; k < n_slices; ++k) s[k & 7] += part_w[(long long)k * 65536 + idx];
+            dW[i * ld_dw + j] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
         }
     } else if (db && part_b) {
         const int i = idx - 256 * 256;
