@@ -113,18 +113,26 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(const float* __restric
     const long long p_begin = blockIdx.x * points_per_slice;
     const long long p_end = p_begin + points_per_slice < n_points ? p_begin + points_per_slice : n_points;
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long long p = p_begin; p < p_end; ++p) {
-        const float x = j < n_in ? X[p * ldx + j] : 0.f;
+    for (long long p = p_begin; p < p_end; p += 8) {           // eight points' loads in flight
+        float x[8], g[8][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float g = i < n_out ? G[p * ldg + i] : 0.f;
-            acc[i] += g * x;
-            bs[i] += g;
+        for (int u = 0; u < 8; ++u) {
+            const bool on = p + u < p_end;
+            x[u] = (on && j < n_in) ? X[(p + u) * ldx + j] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[u][i] = (on && i < n_out) ? G[(p + u) * ldg + i] : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[i] += g[u][i] * x[u]; bs[i] += g[u][i]; }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) part_w[((long long)blockIdx.x * 4 + i) * 256 + j] = acc[i];
-    if (j < 4) part_b[(long long)blockIdx.x * 4 + j] = bs[j];
+    if (j == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part_b[(long long)blockIdx.x * 4 + i] = bs[i];
+    }
 }
 __global__ void __launch_bounds__(256) wgrad_small_reduce_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b, int n_slices, int n_out,
                                                                  int n_in, float* __restrict__ dW, long long ld_dw, float* __restrict__ db) {
@@ -146,8 +154,8 @@ using namespace snr;
 static void wgrad_plan(int64_t n_points, int n_out, long long* pps, int* n_slices) {
     // one slice per compute unit and pass where the points allow it; a slice is a whole number of k-step groups
     const long long unit = 2 * WG_DEPTH;
-    long long per = (n_points + 255) / 256;
-    const long long min_per = n_out >= 32 ? 512 : 4096;
+    long long per = (n_points + (n_out >= 32 ? 255 : 1023)) / (n_out >= 32 ? 256 : 1024);      // narrow heads: memory-bound, 4 blocks per CU
+    const long long min_per = 512;
     if (per < min_per) per = min_per;
     per = (per + unit - 1) / unit * unit;
     *pps = per;
