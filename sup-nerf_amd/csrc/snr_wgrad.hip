@@ -134,16 +134,34 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(const float* __restric
         for (int i = 0; i < 4; ++i) part_b[(long long)blockIdx.x * 4 + i] = bs[i];
     }
 }
-__global__ void __launch_bounds__(256) wgrad_small_reduce_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b, int n_slices, int n_out,
-                                                                 int n_in, float* __restrict__ dW, long long ld_dw, float* __restrict__ db) {
-    const int j = threadIdx.x, i = blockIdx.x;       // grid = n_out
-    float s = 0.f;
-    for (int k = 0; k < n_slices; ++k) s += part_w[((long long)k * 4 + i) * 256 + j];
-    if (j < n_in) dW[i * ld_dw + j] = s;
-    if (db && j == 0) {
+// grid = n_out, 1024 threads: column j = tid & 255, slice group g = tid >> 8 sums the slices k = g (mod 4) with eight loads in flight,
+// the four groups meet in LDS in a fixed order (deterministic)
+__global__ void __launch_bounds__(1024) wgrad_small_reduce_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b, int n_slices, int n_out,
+                                                                  int n_in, float* __restrict__ dW, long long ld_dw, float* __restrict__ db) {
+    __shared__ float red[4][256];
+    const int j = threadIdx.x & 255, g = threadIdx.x >> 8, i = blockIdx.x;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = g;
+    for (; k + 28 < n_slices; k += 32) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += part_w[((long long)(k + 4 * u) * 4 + i) * 256 + j];
+    }
+    for (int u = 0; k < n_slices; k += 4, ++u) s[u & 7] += part_w[((long long)k * 4 + i) * 256 + j];
+    red[g][j] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (g == 0 && j < n_in) dW[i * ld_dw + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+    if (db) {           // the bias: every thread takes the slices q = tid (mod 1024), then a fixed-order sum of the 1024 partials
+        __syncthreads();
         float t = 0.f;
-        for (int k = 0; k < n_slices; ++k) t += part_b[(long long)k * 4 + i];
-        db[i] = t;
+        for (int q = threadIdx.x; q < n_slices; q += 1024) t += part_b[(long long)q * 4 + i];
+        red[g][j] = t;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float u = 0.f;
+            for (int q = threadIdx.x; q < 1024; q += 64) u += red[q >> 8][q & 255];
+            u = wave_sum(u);
+            if (threadIdx.x == 0) db[i] = u;
+        }
     }
 }
 
@@ -192,7 +210,7 @@ int snr_weight_grad(const float* G, int64_t ldg, int n_out, const float* X, int6
         float* part_w = ws; float* part_b = ws + (long long)ns * 4 * 256;
         if (n_points == 0) ns = 0;
         if (ns) wgrad_small_kernel<<<ns, 256, 0, st>>>(G, ldg, n_out, X, ldx, n_in, n_points, pps, part_w, part_b);
-        wgrad_small_reduce_kernel<<<n_out, 256, 0, st>>>(part_w, part_b, ns, n_out, n_in, dW, ld_dw, db);
+        wgrad_small_reduce_kernel<<<n_out, 1024, 0, st>>>(part_w, part_b, ns, n_out, n_in, dW, ld_dw, db);
     }
     return snr_check_launch_();
 }

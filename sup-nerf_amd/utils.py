@@ -25,9 +25,34 @@ from .ops import Z_PER_OBJECT, Z_PER_RAY, Z_SHARED
 
 
 # ------------------------------------------------------------------------------------ rays
-def _pixel_dirs(K, c2w, px, py):
+# Two small caches take the per-call host work out of the optimisers' loops, which call the render functions with the same crop, mask,
+# roi and intrinsics in every iteration (src/optimizer_nuscenes.py:716-726): the camera-frame pixel directions (they do not depend on
+# the pose) and the resized targets (src/utils.py:447-456 redoes the same bilinear resize per call).  Values are what the uncached
+# code computes; entries are keyed by content (K, roi, grid) or by tensor identity + version (crop, mask) and live on the device.
+_CAM_CACHE, _TGT_CACHE, _CACHE_MAX = {}, {}, 32
+
+
+def _cache_put(cache, key, value):
+    if len(cache) >= _CACHE_MAX:
+        cache.pop(next(iter(cache)))
+    cache[key] = value
+    return value
+
+
+def _cam_table(K, px, py, like, key=None):
+    """[(px - cx)/fx, (py - cy)/fy, 1] as ``like``'s dtype on ``like``'s device (the first half of get_rays, src/utils.py:122-131)."""
+    if key is not None:
+        key = key + (tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2])), str(like.device), like.dtype)
+        hit = _CAM_CACHE.get(key)
+        if hit is not None:
+            return hit
     cx, cy, fx, fy = K[0, 2], K[1, 2], K[0, 0], K[1, 1]
-    cam = torch.stack([(px - cx) / fx, (py - cy) / fy, torch.ones_like(px)], -1).type_as(c2w)
+    cam = torch.stack([(px - cx) / fx, (py - cy) / fy, torch.ones_like(px)], -1).type_as(like)
+    return cam if key is None else _cache_put(_CAM_CACHE, key, cam)
+
+
+def _pixel_dirs(K, c2w, px, py, key=None):
+    cam = _cam_table(K, px, py, c2w, key)
     world = (cam[..., None, :] * c2w[..., :3, :3]).sum(-1)
     unit = world / torch.norm(world, dim=-1, keepdim=True)
     origin = c2w[..., :3, -1].expand(world.shape)
@@ -41,7 +66,7 @@ def get_rays(K, c2w, roi, uv_steps=None):
     nx, ny = (int(uv_steps[0]), int(uv_steps[1])) if uv_steps is not None else (x1 - x0, y1 - y0)
     xs = torch.linspace(x0, x1 - 1, nx)
     ys = torch.linspace(y0, y1 - 1, ny)
-    return _pixel_dirs(K, c2w, xs[None, :].expand(ny, nx), ys[:, None].expand(ny, nx))
+    return _pixel_dirs(K, c2w, xs[None, :].expand(ny, nx), ys[:, None].expand(ny, nx), key=("grid", x0, y0, x1, y1, nx, ny))
 
 
 def get_rays_specified(K, c2w, x_vec, y_vec):
@@ -105,8 +130,8 @@ def _shared_depths(near, far, n_samples, device, z_fixed=False, jitter=None):
     if jitter is None:
         jitter = _jitter_override()
         if jitter is None:
-            jitter = torch.rand(n_samples)
-    return z + jitter.to(device) * (far - near) / (2 * n_samples)
+            jitter = torch.rand(n_samples, pin_memory=torch.device(device).type == "cuda")      # same CPU generator, same numbers; async upload
+    return z + jitter.to(device, non_blocking=True) * (far - near) / (2 * n_samples)
 
 
 def sample_from_rays(ro, vd, near, far, N_samples, z_fixed=False):
@@ -180,6 +205,20 @@ def volume_rendering_batch(sigmas, rgbs, z_vals):
 
 
 # ------------------------------------------------------------------------------------ targets
+def _resize_to(img, mask_occ, im_sz, device):
+    """``_resize`` + the move to ``device`` as (n,3) / (n,1) ray targets, cached per (crop, mask, size, device): the optimisers pass the
+    same CPU crop in every iteration."""
+    key = (img.data_ptr(), img._version, tuple(img.shape), mask_occ.data_ptr(), mask_occ._version, tuple(mask_occ.shape), int(im_sz), str(device))
+    hit = _TGT_CACHE.get(key)
+    if hit is not None and hit[0]() is img and hit[1]() is mask_occ:
+        return hit[2], hit[3]
+    im, mk = _resize(img, mask_occ, im_sz)
+    tgt, occ = im.reshape(-1, 3).to(device), mk.reshape(-1, 1).to(device)
+    import weakref
+    _cache_put(_TGT_CACHE, key, (weakref.ref(img), weakref.ref(mask_occ), tgt, occ))
+    return tgt, occ
+
+
 def _resize(img, mask_occ, im_sz):
     """Bilinear, no antialias (torchvision 0.13 tensor ``Resize``); mask truncated through int32
     (src/utils.py:447-456)."""
@@ -238,9 +277,7 @@ def render_rays_v2(model, device, img, mask_occ, cam_pose, obj_diag, K, roi, n_s
                    sym_aug, kitti2nusc=False, im_sz=64, n_rays=None):
     """src/utils.py:435-502: im_sz x im_sz grid over the roi (the optimisers' render call)."""
     rays_o, viewdir = get_rays(K, cam_pose, roi, uv_steps=[im_sz, im_sz])
-    img, mask_occ = _resize(img, mask_occ, im_sz)
-    rgb_tgt = img.reshape(-1, 3).to(device)
-    occ_pixels = mask_occ.reshape(-1, 1).to(device)
+    rgb_tgt, occ_pixels = _resize_to(img, mask_occ, im_sz, device)
     if n_rays is not None:
         n_rays = int(np.minimum(rays_o.shape[0], n_rays))
         ids = np.random.permutation(rays_o.shape[0])[:n_rays]
