@@ -250,13 +250,15 @@ int snr_adamw_step(float* const* params, const float* const* grads, float* const
  *     dW (n_out, n_in; leading dimension ld_dw) = G^T X,   db (n_out) = column sums of G [nullable]
  * G (P, n_out; leading dimension ldg) = gradient wrt the layer's pre-activation = slot l of snr_decoder_bwd's layer_grads;
  * X (P, n_in; leading dimension ldx) = the layer's input = slot l-1 of snr_decoder_fwd's activations (or the positional encoding).
- * Exact fp32 on the matrix cores, split over the points, per-slice partials summed in slice order (deterministic, no atomics).
+ * precision SNR_FP32: exact fp32 on the matrix cores; SNR_BF16X3: the split-bf16 products of the render fast path (operand error ~2^-17,
+ * 5x less matrix time, HBM-bound); the narrow heads and the bias sums are always fp32.  Split over the points, per-slice partials summed
+ * in slice order (deterministic, no atomics).
  * n_out, n_in <= 256.  n_out >= 32: n_out, n_in, ldg, ldx multiples of 4 and G, X 16-byte aligned; n_out <= 4 (density / colour head):
  * no alignment requirement.  workspace: snr_weight_grad_ws_bytes().
  * ---------------------------------------------------------------------------------- */
 size_t snr_weight_grad_ws_bytes(int64_t n_points, int n_out, int n_in);
 int snr_weight_grad(const float* G, int64_t ldg, int n_out, const float* X, int64_t ldx, int n_in, int64_t n_points,
-                    float* dW, int64_t ld_dw, float* db, void* workspace, size_t ws_bytes, void* stream);
+                    float* dW, int64_t ld_dw, float* db, int precision, void* workspace, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -63,7 +63,7 @@ _SIGS = {
     "snr_loss_tail_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, _P, _P]),
     "snr_loss_tail_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, _P, _P, _P, _P]),
     "snr_weight_grad_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
-    "snr_weight_grad": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int, C.c_int64, _P, C.c_int64, _P, _P, C.c_size_t, _P]),
+    "snr_weight_grad": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int, C.c_int64, _P, C.c_int64, _P, C.c_int, _P, C.c_size_t, _P]),
     "snr_pose_rays_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "snr_pose_rays_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P]),
     "snr_metric_row": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int64, C.c_int, _P, _P]),

@@ -28,8 +28,10 @@ wgrad_mfma_kernel(const float* __restrict__ G, long long ldg, int n_out, const f
     const long long p_end = p_begin + points_per_slice < n_points ? p_begin + points_per_slice : n_points;
     const int row0 = 128 * wr + 4 * n, col0 = 128 * wc + 4 * n;
     const bool row_ok = row0 < n_out, col_ok = col0 < n_in;           // n_out, n_in are multiples of 4 (checked by the launcher)
-    const float* gp = G + row0;
-    const float* xp = X + col0;
+    // loads are unconditional (no divergent branches in the stream): addresses clamped into the buffers, dead lanes / points zeroed after
+    const float* gp = G + (row_ok ? row0 : 0);
+    const float* xp = X + (col_ok ? col0 : 0);
+    const long long p_last = p_end - 1;
     f32x16 acc[4][4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -38,12 +40,12 @@ wgrad_mfma_kernel(const float* __restrict__ G, long long ldg, int n_out, const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     auto load = [&](long long p, f32x4& a, f32x4& b) {          // the operands of the k-step at points p, p + 1 (this lane: p + h)
         const long long q = p + h;
-        const bool live = q < p_end;
-        a = (live && row_ok) ? *reinterpret_cast<const f32x4*>(gp + q * ldg) : zero;
-        b = (live && col_ok) ? *reinterpret_cast<const f32x4*>(xp + q * ldx) : zero;
+        const long long qc = q < p_end ? q : p_last;
+        const float ma = (q < p_end && row_ok) ? 1.f : 0.f, mb = (q < p_end && col_ok) ? 1.f : 0.f;
+        a = *reinterpret_cast<const f32x4*>(gp + qc * ldg) * ma;
+        b = *reinterpret_cast<const f32x4*>(xp + qc * ldx) * mb;
     };
     f32x4 a[WG_DEPTH], b[WG_DEPTH];
 #pragma unroll
@@ -71,6 +73,95 @@ wgrad_mfma_kernel(const float* __restrict__ G, long long ldg, int n_out, const f
             *reinterpret_cast<f32x4*>(out + (128 * wr + 4 * r + e) * 256 + 128 * wc + 4 * n) = v;
         }
     if (part_b && wc == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bsum[e] = sum_halves(bsum[e]);
+        if (h == 0) *reinterpret_cast<f32x4*>(part_b + (long long)blockIdx.x * 256 + row0) = bsum;
+    }
+}
+
+// The same product in split-bf16 arithmetic (SNR_BF16X3): every fp32 operand as bf16 hi + lo, three v_mfma_f32_32x32x16_bf16 per
+// product, fp32 accumulate (relative operand error ~2^-17, like the render kernels' fast path).  A k-step is 16 points: lane (n, h)
+// loads G[p + 8h + j][4n .. 4n+3] and X[p + 8h + j][4n .. 4n+3] for j = 0..7 (sixteen 16-byte loads) and holds, for each of the four
+// interleaved row tiles {4n + e}, exactly the A fragment of the 32x32x16 MFMA (row 4n + e, k = 8h + j) -- again no transpose.
+// 48 MFMAs of 32 cycles per 16 points instead of 128 of 64: 5.3x less matrix time, which leaves the kernel bound by reading G and X
+// from HBM once (2 KB per point and layer).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split8(const f32x4 (&v)[8], int e, bf16x8_t& hi, bf16x8_t& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = v[j][e];
+        const __bf16 b = (__bf16)x;
+        hi[j] = b;
+        lo[j] = (__bf16)(x - (float)b);
+    }
+}
+
+__global__ void __launch_bounds__(256, 1)
+wgrad_bf16x3_kernel(const float* __restrict__ G, long long ldg, int n_out, const float* __restrict__ X, long long ldx, int n_in,
+                    long long n_points, long long points_per_slice, float* __restrict__ part_w, float* __restrict__ part_b) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const long long p_begin = blockIdx.x * points_per_slice;
+    const long long p_end = p_begin + points_per_slice < n_points ? p_begin + points_per_slice : n_points;
+    const int row0 = 128 * wr + 4 * n, col0 = 128 * wc + 4 * n;
+    const bool row_ok = row0 < n_out, col_ok = col0 < n_in;
+    const float* gp = G + (row_ok ? row0 : 0);
+    const float* xp = X + (col_ok ? col0 : 0);
+    const long long p_last = p_end - 1;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](long long p, f32x4 (&a)[8], f32x4 (&b)[8]) {        // the 16 points p .. p+15; this lane: p + 8h + j (unconditional loads,
+#pragma unroll                                                          // clamped addresses, dead lanes / points zeroed)
+        for (int j = 0; j < 8; ++j) {
+            const long long q = p + 8 * h + j;
+            const long long qc = q < p_end ? q : p_last;
+            const float ma = (q < p_end && row_ok) ? 1.f : 0.f, mb = (q < p_end && col_ok) ? 1.f : 0.f;
+            a[j] = *reinterpret_cast<const f32x4*>(gp + qc * ldg) * ma;
+            b[j] = *reinterpret_cast<const f32x4*>(xp + qc * ldx) * mb;
+        }
+    };
+    f32x4 a0[8], b0[8], a1[8], b1[8];
+    load(p_begin, a0, b0);
+    auto compute = [&](const f32x4 (&a)[8], const f32x4 (&b)[8]) {
+        bf16x8_t bh[4], bl[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) split8(b, f, bh[f], bl[f]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += a[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bf16x8_t ah, al;
+            split8(a, e, ah, al);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[f], acc[e][f], 0, 0, 0);
+                acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[f], acc[e][f], 0, 0, 0);
+                acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[f], acc[e][f], 0, 0, 0);
+            }
+        }
+    };
+    for (long long p = p_begin; p < p_end; p += 32) {        // two k-steps per trip: one set of operands in flight while the other is used
+        load(p + 16, a1, b1);
+        compute(a0, b0);
+        load(p + 32, a0, b0);
+        compute(a1, b1);
+    }
+    float* out = part_w + (long long)blockIdx.x * 256 * 256;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const f32x4 v = {acc[e][0][reg], acc[e][1][reg], acc[e][2][reg], acc[e][3][reg]};
+            *reinterpret_cast<f32x4*>(out + (128 * wr + 4 * r + e) * 256 + 128 * wc + 4 * n) = v;
+        }
+    if (part_b && wc == 0) {           // (the bias gradient stays an exact fp32 sum)
 #pragma unroll
         for (int e = 0; e < 4; ++e) bsum[e] = sum_halves(bsum[e]);
         if (h == 0) *reinterpret_cast<f32x4*>(part_b + (long long)blockIdx.x * 256 + row0) = bsum;
@@ -171,7 +262,7 @@ using namespace snr;
 
 static void wgrad_plan(int64_t n_points, int n_out, long long* pps, int* n_slices) {
     // one slice per compute unit and pass where the points allow it; a slice is a whole number of k-step groups
-    const long long unit = 2 * WG_DEPTH;
+    const long long unit = 32;      // whole k-step groups of both arithmetics (fp32: 2 x WG_DEPTH points, split-bf16: 2 x 16)
     long long per = (n_points + (n_out >= 32 ? 255 : 1023)) / (n_out >= 32 ? 256 : 1024);      // narrow heads: memory-bound, 4 blocks per CU
     const long long min_per = 512;
     if (per < min_per) per = min_per;
@@ -191,7 +282,8 @@ size_t snr_weight_grad_ws_bytes(int64_t n_points, int n_out, int n_in) {
 }
 
 int snr_weight_grad(const float* G, int64_t ldg, int n_out, const float* X, int64_t ldx, int n_in, int64_t n_points,
-                    float* dW, int64_t ld_dw, float* db, void* workspace, size_t ws_bytes, void* stream_) {
+                    float* dW, int64_t ld_dw, float* db, int precision, void* workspace, size_t ws_bytes, void* stream_) {
+    if (precision != SNR_FP32 && precision != SNR_BF16X3) return SNR_E_ARG;
     if (!G || !X || !dW || n_out < 1 || n_in < 1 || n_out > 256 || n_in > 256 || n_points < 0 || ldg < n_out || ldx < n_in || ld_dw < n_in) return SNR_E_ARG;
     hipStream_t st = (hipStream_t)stream_;
     if (!workspace || ws_bytes < snr_weight_grad_ws_bytes(n_points, n_out, n_in)) return SNR_E_WORKSPACE;
@@ -203,7 +295,8 @@ int snr_weight_grad(const float* G, int64_t ldg, int n_out, const float* X, int6
         if ((n_out & 3) || (n_in & 3) || (ldg & 3) || (ldx & 3) || ((uintptr_t)G & 15) || ((uintptr_t)X & 15)) return SNR_E_UNSUPPORTED;
         float* part_w = ws; float* part_b = ws + (long long)ns * 65536;
         if (n_points == 0) ns = 0;
-        if (ns) wgrad_mfma_kernel<<<ns, 256, 0, st>>>(G, ldg, n_out, X, ldx, n_in, n_points, pps, part_w, db ? part_b : nullptr);
+        if (ns && precision == SNR_BF16X3) wgrad_bf16x3_kernel<<<ns, 256, 0, st>>>(G, ldg, n_out, X, ldx, n_in, n_points, pps, part_w, db ? part_b : nullptr);
+        else if (ns) wgrad_mfma_kernel<<<ns, 256, 0, st>>>(G, ldg, n_out, X, ldx, n_in, n_points, pps, part_w, db ? part_b : nullptr);
         wgrad_reduce_kernel<<<(256 * 256 + 256 + 255) / 256, 256, 0, st>>>(part_w, db ? part_b : nullptr, ns, n_out, n_in, dW, ld_dw, db);
     } else {
         if (n_out > 4) return SNR_E_UNSUPPORTED;        /* 5..31 output rows: no such layer in the decoder */

@@ -390,10 +390,13 @@ class DecoderPoints(torch.autograd.Function):
         return d_xyz, d_dir, d_lat, None, None, None, None
 
 
-def weight_grad(G, n_out, X, n_in, want_bias=True, out=None, ws=None):
+def weight_grad(G, n_out, X, n_in, want_bias=True, out=None, ws=None, precision="fp32"):
     """dW (n_out, n_in) = G[:, :n_out]^T X[:, :n_in] and db (n_out,) = column sums of G, one split-K MFMA launch + one reduction
     (include/supnerf_hip.h: snr_weight_grad).  G, X: 2-D fp32 row-major views (a column slice of a wider buffer is fine).  ``out``:
-    optional (dW_view, db) to write into (dW_view may be a column block of a wider matrix)."""
+    optional (dW_view, db) to write into (dW_view may be a column block of a wider matrix).  ``precision``: "fp32" (exact) or "bf16x3"
+    (split-bf16 products, ~2^-17 operand error, several times faster; bias sums and narrow heads stay fp32)."""
+    if precision not in PRECISIONS:
+        raise SnrError(f"weight_grad: precision must be 'fp32' or 'bf16x3', got {precision!r}")
     _need_gpu(G, X)
     if G.dim() != 2 or X.dim() != 2 or G.shape[0] != X.shape[0] or G.stride(1) != 1 or X.stride(1) != 1 or G.dtype != torch.float32 or X.dtype != torch.float32:
         raise SnrError(f"weight_grad: G {tuple(G.shape)} / X {tuple(X.shape)} must be fp32 (P, n) row-major views of the same points")
@@ -407,8 +410,8 @@ def weight_grad(G, n_out, X, n_in, want_bias=True, out=None, ws=None):
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.lib().snr_weight_grad(_p(G), G.stride(0), n_out, _p(X), X.stride(0), n_in, P, _p(dW), dW.stride(0), _p(db), _p(ws), ws.numel(),
-                                         _stream(dev)), "snr_weight_grad")
+        check(_lib.lib().snr_weight_grad(_p(G), G.stride(0), n_out, _p(X), X.stride(0), n_in, P, _p(dW), dW.stride(0), _p(db), PRECISIONS[precision],
+                                         _p(ws), ws.numel(), _stream(dev)), "snr_weight_grad")
     return dW, db
 
 
@@ -416,11 +419,14 @@ class DecoderPointsTrain(torch.autograd.Function):
     """Training-mode decoder (SURVEY 8a9 mode B): like DecoderPoints but the per-point decoder WEIGHTS are inputs too and
     receive gradients.  The fp32 kernels additionally write every layer's input X_l (forward) and pre-activation
     gradient G_l (backward) to HBM, and the weight gradients dW_l = G_l^T X_l, db_l = sum_p G_l come from the split-K fp32-MFMA kernel
-    behind ``weight_grad`` (no library BLAS).  ``weights`` = the per-point tensors in per_point_tensor_names order."""
+    behind ``weight_grad`` (no library BLAS), in exact fp32 or -- ``wgrad_precision = "bf16x3"`` -- as split-bf16 products.  ``weights`` =
+    the per-point tensors in per_point_tensor_names order."""
 
     @staticmethod
-    def forward(ctx, xyz, viewdir, latent, shape_blocks, texture_blocks, *weights):
+    def forward(ctx, xyz, viewdir, latent, shape_blocks, texture_blocks, wgrad_precision, *weights):
         xyz, viewdir, latent = _f32c(xyz), _f32c(viewdir), _f32c(latent)
+        if wgrad_precision not in PRECISIONS:
+            raise SnrError(f"DecoderPointsTrain: weight-gradient precision must be 'fp32' or 'bf16x3', got {wgrad_precision!r}")
         names = per_point_tensor_names(shape_blocks, texture_blocks)
         packed = pack_weights(dict(zip(names, weights)), shape_blocks, texture_blocks)
         P, dev = xyz.shape[0], xyz.device
@@ -429,13 +435,13 @@ class DecoderPointsTrain(torch.autograd.Function):
         sig, rgb, masks = decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=True, precision="fp32",
                                       activations=act)
         ctx.save_for_backward(xyz, viewdir, latent, packed, masks, sig, act, *weights)
-        ctx.cfg = (shape_blocks, texture_blocks)
+        ctx.cfg = (shape_blocks, texture_blocks, wgrad_precision)
         return sig, rgb
 
     @staticmethod
     def backward(ctx, d_sig, d_rgb):
         xyz, viewdir, latent, packed, masks, sig, act, *weights = ctx.saved_tensors
-        sb, tb = ctx.cfg
+        sb, tb, wprec = ctx.cfg
         P, dev = xyz.shape[0], xyz.device
         n_slots = sb + tb + 4
         G = torch.empty(n_slots, P, 256, device=dev)
@@ -454,15 +460,15 @@ class DecoderPointsTrain(torch.autograd.Function):
         for li in range(n_slots):              # MFMA layers in order; the two small heads follow
             n_out = 128 if li == li_rgb0 else 256
             if li == 0:
-                by_layer[li] = weight_grad(G[li], n_out, pe_padded(xyz, 10, 64), 64, ws=ws)
+                by_layer[li] = weight_grad(G[li], n_out, pe_padded(xyz, 10, 64), 64, ws=ws, precision=wprec)
                 by_layer[li] = (by_layer[li][0][:, :63].contiguous(), by_layer[li][1])
             elif li == li_view:
                 dW = torch.empty(256, 256 + 28, device=dev)
-                _, db = weight_grad(G[li], 256, act[li - 1], 256, out=(dW[:, :256], torch.empty(256, device=dev)), ws=ws)
-                weight_grad(G[li], 256, pe_padded(viewdir, 4, 28), 28, out=(dW[:, 256:], None), ws=ws)
+                _, db = weight_grad(G[li], 256, act[li - 1], 256, out=(dW[:, :256], torch.empty(256, device=dev)), ws=ws, precision=wprec)
+                weight_grad(G[li], 256, pe_padded(viewdir, 4, 28), 28, out=(dW[:, 256:], None), ws=ws, precision=wprec)
                 by_layer[li] = (dW[:, :283].contiguous(), db)
             else:
-                by_layer[li] = weight_grad(G[li], n_out, act[li - 1], 256, ws=ws)
+                by_layer[li] = weight_grad(G[li], n_out, act[li - 1], 256, ws=ws, precision=wprec)
         # sigma head: pre = w . y4 + b with y4 = input of enc_viewdir; d pre = d_sig * sigmoid(pre) = d_sig * (1 - exp(-sigma))
         dpre = (d_sig * (1 - torch.exp(-sig))).reshape(P, 1)
         d_sigma_w, d_sigma_b = weight_grad(dpre, 1, act[li_view - 1], 256, ws=ws)
@@ -476,7 +482,7 @@ class DecoderPointsTrain(torch.autograd.Function):
                 out += [d_rgb2_w, d_rgb2_b]
             else:
                 out += list(by_layer[k])
-        return (d_xyz, d_dir, d_lat, None, None, *out)
+        return (d_xyz, d_dir, d_lat, None, None, None, *out)
 
 
 # ------------------------------------------------------------------------------------ fused render
