@@ -18,20 +18,28 @@ namespace snr {
 
 constexpr int WG_DEPTH = 8;            // k-steps of operands in flight per wave (8 x 1024 MFMA cycles cover an HBM round trip under load)
 
+// Operand addressing shared by both arithmetics: a wave-uniform base (SGPRs, advanced per k-step) + a loop-invariant 32-bit lane offset,
+// so a load is one instruction with no address arithmetic.  Loads are unconditional and unmasked in the main loop: lanes whose rows /
+// columns lie outside the layer (n_out < 256, n_in < 256) read in-bounds neighbours and fill partial rows / columns nobody reads, and the
+// prefetch that runs past the slice is pointed back at its start and discarded.  Only the last, ragged k-step of a slice masks.
+struct WgLane {
+    unsigned g_off, x_off;      // bytes: (lane's point row within a k-step) * ld + lane's 4 columns
+};
+
 __global__ void __launch_bounds__(256, 1)
 wgrad_mfma_kernel(const float* __restrict__ G, long long ldg, int n_out, const float* __restrict__ X, long long ldx, int n_in,
                   long long n_points, long long points_per_slice, float* __restrict__ part_w /* [slice][256][256] */,
                   float* __restrict__ part_b /* [slice][256] or null */) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, h = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
+    if (128 * wr >= n_out || 128 * wc >= n_in) return;                 // this wave's quadrant lies outside the layer (wave-uniform)
     const long long p_begin = blockIdx.x * points_per_slice;
     const long long p_end = p_begin + points_per_slice < n_points ? p_begin + points_per_slice : n_points;
     const int row0 = 128 * wr + 4 * n, col0 = 128 * wc + 4 * n;
-    const bool row_ok = row0 < n_out, col_ok = col0 < n_in;           // n_out, n_in are multiples of 4 (checked by the launcher)
-    // loads are unconditional (no divergent branches in the stream): addresses clamped into the buffers, dead lanes / points zeroed after
-    const float* gp = G + (row_ok ? row0 : 0);
-    const float* xp = X + (col_ok ? col0 : 0);
-    const long long p_last = p_end - 1;
+    const int row_c = row0 < n_out ? row0 : 0, col_c = col0 < n_in ? col0 : 0;
+    const unsigned g_off = (unsigned)((h * ldg + row_c) * 4), x_off = (unsigned)((h * ldx + col_c) * 4);
+    const char* Gb = reinterpret_cast<const char*>(G);
+    const char* Xb = reinterpret_cast<const char*>(X);
     f32x16 acc[4][4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -40,27 +48,42 @@ wgrad_mfma_kernel(const float* __restrict__ G, long long ldg, int n_out, const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    auto load = [&](long long p, f32x4& a, f32x4& b) {          // the operands of the k-step at points p, p + 1 (this lane: p + h)
-        const long long q = p + h;
-        const long long qc = q < p_end ? q : p_last;
-        const float ma = (q < p_end && row_ok) ? 1.f : 0.f, mb = (q < p_end && col_ok) ? 1.f : 0.f;
-        a = *reinterpret_cast<const f32x4*>(gp + qc * ldg) * ma;
-        b = *reinterpret_cast<const f32x4*>(xp + qc * ldx) * mb;
+    constexpr int TRIP = 2 * WG_DEPTH;                                 // points per trip of the main loop
+    const long long full_end = p_begin + (p_end - p_begin) / TRIP * TRIP;
+    auto load = [&](long long p, f32x4& a, f32x4& b) {                 // k-step at points p, p + 1 (this lane: p + h); p is wave-uniform
+        const long long pc = p + 2 <= p_end ? p : p_begin;             // past the slice: any valid k-step, the values are dropped
+        a = *reinterpret_cast<const f32x4*>(Gb + pc * ldg * 4 + g_off);
+        b = *reinterpret_cast<const f32x4*>(Xb + pc * ldx * 4 + x_off);
+    };
+    auto mma = [&](const f32x4& av, const f32x4& bv) {
+        bsum += av;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[f], acc[e][f], 0, 0, 0);
     };
     f32x4 a[WG_DEPTH], b[WG_DEPTH];
+    if (p_begin < full_end) {
 #pragma unroll
-    for (int d = 0; d < WG_DEPTH; ++d) load(p_begin + 2 * d, a[d], b[d]);
-    for (long long p = p_begin; p < p_end; p += 2 * WG_DEPTH) {
+        for (int d = 0; d < WG_DEPTH; ++d) load(p_begin + 2 * d, a[d], b[d]);
+    }
+    for (long long p = p_begin; p < full_end; p += TRIP) {
 #pragma unroll
         for (int d = 0; d < WG_DEPTH; ++d) {
             const f32x4 av = a[d], bv = b[d];
-            load(p + 2 * (WG_DEPTH + d), a[d], b[d]);            // past the slice: zeros (no access)
-            bsum += av;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int f = 0; f < 4; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[f], acc[e][f], 0, 0, 0);
+            load(p + TRIP + 2 * d < full_end ? p + TRIP + 2 * d : p_begin, a[d], b[d]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(av, bv);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    for (long long p = full_end; p < p_end; p += 2) {                  // ragged tail: fewer than TRIP points, masked per lane
+        const long long q = p + h;
+        const long long qc = q < p_end ? q : p_end - 1;
+        const float m = q < p_end ? 1.f : 0.f;
+        const f32x4 av = *reinterpret_cast<const f32x4*>(Gb + qc * ldg * 4 + (unsigned)(row_c * 4)) * m;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(Xb + qc * ldx * 4 + (unsigned)(col_c * 4)) * m;
+        mma(av, bv);
     }
     // tile (e, f): D[r][c] = sum_p G[p][128 wr + 4 r + e] X[p][128 wc + 4 c + f];  this lane: c = n, r = (reg & 3) + 8 (reg >> 2) + 4 h
     float* out = part_w + (long long)blockIdx.x * 256 * 256;
@@ -101,13 +124,16 @@ wgrad_bf16x3_kernel(const float* __restrict__ G, long long ldg, int n_out, const
                     long long n_points, long long points_per_slice, float* __restrict__ part_w, float* __restrict__ part_b) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, h = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
+    if (128 * wr >= n_out || 128 * wc >= n_in) return;
     const long long p_begin = blockIdx.x * points_per_slice;
     const long long p_end = p_begin + points_per_slice < n_points ? p_begin + points_per_slice : n_points;
     const int row0 = 128 * wr + 4 * n, col0 = 128 * wc + 4 * n;
-    const bool row_ok = row0 < n_out, col_ok = col0 < n_in;
-    const float* gp = G + (row_ok ? row0 : 0);
-    const float* xp = X + (col_ok ? col0 : 0);
-    const long long p_last = p_end - 1;
+    const int row_c = row0 < n_out ? row0 : 0, col_c = col0 < n_in ? col0 : 0;
+    unsigned g_off[8], x_off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { g_off[j] = (unsigned)(((8 * h + j) * ldg + row_c) * 4); x_off[j] = (unsigned)(((8 * h + j) * ldx + col_c) * 4); }
+    const char* Gb = reinterpret_cast<const char*>(G);
+    const char* Xb = reinterpret_cast<const char*>(X);
     f32x16 acc[4][4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -116,18 +142,16 @@ wgrad_bf16x3_kernel(const float* __restrict__ G, long long ldg, int n_out, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    auto load = [&](long long p, f32x4 (&a)[8], f32x4 (&b)[8]) {        // the 16 points p .. p+15; this lane: p + 8h + j (unconditional loads,
-#pragma unroll                                                          // clamped addresses, dead lanes / points zeroed)
+    const long long full_end = p_begin + (p_end - p_begin) / 32 * 32;
+    auto load = [&](long long p, f32x4 (&a)[8], f32x4 (&b)[8]) {        // the 16 points p .. p+15 (p wave-uniform); this lane: p + 8h + j
+        const char* gb = Gb + p * ldg * 4;
+        const char* xb = Xb + p * ldx * 4;
+#pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const long long q = p + 8 * h + j;
-            const long long qc = q < p_end ? q : p_last;
-            const float ma = (q < p_end && row_ok) ? 1.f : 0.f, mb = (q < p_end && col_ok) ? 1.f : 0.f;
-            a[j] = *reinterpret_cast<const f32x4*>(gp + qc * ldg) * ma;
-            b[j] = *reinterpret_cast<const f32x4*>(xp + qc * ldx) * mb;
+            a[j] = *reinterpret_cast<const f32x4*>(gb + g_off[j]);
+            b[j] = *reinterpret_cast<const f32x4*>(xb + x_off[j]);
         }
     };
-    f32x4 a0[8], b0[8], a1[8], b1[8];
-    load(p_begin, a0, b0);
     auto compute = [&](const f32x4 (&a)[8], const f32x4 (&b)[8]) {
         bf16x8_t bh[4], bl[4];
 #pragma unroll
@@ -146,11 +170,30 @@ wgrad_bf16x3_kernel(const float* __restrict__ G, long long ldg, int n_out, const
             }
         }
     };
-    for (long long p = p_begin; p < p_end; p += 32) {        // two k-steps per trip: one set of operands in flight while the other is used
+    f32x4 a0[8], b0[8], a1[8], b1[8];
+    if (p_begin < full_end) load(p_begin, a0, b0);
+    for (long long p = p_begin; p < full_end; p += 32) {        // two k-steps per trip: one set of operands in flight while the other is used
+        // (sched_barrier: LLVM otherwise hoists the conversion of the set just requested above the MFMAs of the current one and waits
+        //  for the loads it has only just issued)
         load(p + 16, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
         compute(a0, b0);
-        load(p + 32, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        load(p + 32 < full_end ? p + 32 : p_begin, a0, b0);     // past the last trip: a valid k-step, dropped
+        __builtin_amdgcn_sched_barrier(0);
         compute(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (long long p = full_end; p < p_end; p += 16) {          // ragged tail (< 32 points): masked per lane
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long q = p + 8 * h + j;
+            const long long qc = q < p_end ? q : p_end - 1;
+            const float m = q < p_end ? 1.f : 0.f;
+            a0[j] = *reinterpret_cast<const f32x4*>(Gb + qc * ldg * 4 + (unsigned)(row_c * 4)) * m;
+            b0[j] = *reinterpret_cast<const f32x4*>(Xb + qc * ldx * 4 + (unsigned)(col_c * 4)) * m;
+        }
+        compute(a0, b0);
     }
     float* out = part_w + (long long)blockIdx.x * 256 * 256;
 #pragma unroll
