@@ -91,8 +91,8 @@ int snr_unpack_weight_grads(const float* packed_grad, float* const* tensors, int
  *   relu_masks   : NULL, or snr_mask_bytes(P,...) bytes that the backward pass needs
  *   activations  : NULL, or (shape_blocks+texture_blocks+4, P, 256) floats: training mode, receives the INPUT of every
  *                  MFMA layer after the first (slot l = input of layer l+1; the last slot = input of rgb.2, 128 columns
- *                  used).  SNR_FP32 only.  Together with `layer_grads` of snr_decoder_bwd it turns the weight gradients
- *                  into plain GEMMs dW_l = G_l^T X_l for the caller's BLAS (the weight half of the backward of
+ *                  used).  Needs relu_masks; both precisions.  Together with `layer_grads` of snr_decoder_bwd it turns the weight gradients
+ *                  into the products dW_l = G_l^T X_l of snr_weight_grad (the weight half of the backward of
  *                  src/trainer_unified_nuscenes.py:334).
  * ---------------------------------------------------------------------------------- */
 size_t snr_mask_bytes(int64_t n_points, int shape_blocks, int texture_blocks);
@@ -101,7 +101,7 @@ int snr_decoder_fwd(const float* xyz, const float* viewdir, const float* latent,
                     float* sigmas, float* rgbs, void* relu_masks, float* activations, int precision, void* stream);
 /* gradients wrt latent (B,NLAT,256), xyz (P,3), viewdir (P,3) [each nullable] given d_sigmas (P) and d_rgbs (P,3).
  * layer_grads: NULL, or (shape_blocks+texture_blocks+4, P, 256) floats receiving the gradient wrt the pre-activation of
- * every MFMA layer (slot l = layer l; rgb.0 uses 128 columns), SNR_FP32 only.  workspace: snr_decoder_bwd_ws_bytes(). */
+ * every MFMA layer (slot l = layer l; rgb.0 uses 128 columns), both precisions.  workspace: snr_decoder_bwd_ws_bytes(). */
 size_t snr_decoder_bwd_ws_bytes(int64_t n_points, int64_t points_per_obj, int shape_blocks, int texture_blocks);
 int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent, const float* packed,
                     const void* relu_masks, const float* sigmas, const float* d_sigmas, const float* d_rgbs,

@@ -199,6 +199,7 @@ struct FwdEpi {
     int floor;            // ReLU as an integer max on the bit pattern: 0 for a ReLU layer, INT_MIN for none
     const float* bias;    // LDS: bias of the layer being accumulated (its accumulators start from it)
     const float* zl;      // LDS: latent term added after the activation (a block of zeros if none)
+    float* dump;          // DUMP (training): this lane's row of the activation dump, [point][256] + 4h, or null for a point past the end
 };
 // pin an operand step where it is produced: without this LLVM sinks the whole epilogue down to its use in the next
 // step (behind the barrier), which serialises it with that step's MFMAs instead of hiding it under this step's
@@ -216,12 +217,13 @@ __device__ __forceinline__ void fwd_quarter_load(EpiVec& v, const FwdEpi& c, int
     const int j = 2 * HALF + JJ;
     if constexpr (ZADD) v.z = *reinterpret_cast<const f32x4*>(c.zl + 32 * T + 8 * j + 4 * h);
 }
-template <int T, int HALF, int JJ, bool MASKS, bool ZADD = true>
+template <int T, int HALF, int JJ, bool MASKS, bool ZADD = true, bool DUMP = false>
 __device__ __forceinline__ void fwd_quarter(const f32x16& acc, XOp& out, const FwdEpi& c, const EpiVec& v, uint32_t (&mask)[4]) {
 #ifdef SNR_EXP_NOEPI
     return;
 #endif
     const int j = 2 * HALF + JJ;
+    f32x4 dv;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int r = 4 * j + e;
@@ -234,18 +236,22 @@ __device__ __forceinline__ void fwd_quarter(const f32x16& acc, XOp& out, const F
         // Plain C++ on purpose: the same epilogue on v_pk_add_f32 through inline asm has a quarter fewer VALU ops and is 2-4 % SLOWER,
         // the scheduler cannot place asm statements under the MFMAs (sched_group_barrier does not see them as VALU).
         const float y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, a), c.floor));
-        split_store(ZADD ? y + v.z[e] : y, out, r & 7);
+        const float xv = ZADD ? y + v.z[e] : y;
+        split_store(xv, out, r & 7);
+        if (DUMP) dv[e] = xv;
     }
+    // training: the next layer's fp32 input (features 32T + 8j + 4h .. +3 of this lane's point) goes to HBM for the weight-gradient product
+    if (DUMP) { if (c.dump) *reinterpret_cast<f32x4*>(c.dump + 32 * T + 8 * j) = dv; }
     if (JJ == 1) pin(out);
     if (MASKS) asm volatile("" : "+v"(mask[T >> 1]));      // keep the bit capture here (LLVM otherwise recomputes it at the layer's end)
 }
-template <int T, int HALF, bool MASKS, bool ZADD = true>
+template <int T, int HALF, bool MASKS, bool ZADD = true, bool DUMP = false>
 __device__ __forceinline__ void fwd_half_tile(const f32x16& acc, XOp& out, const FwdEpi& c, int h, uint32_t (&mask)[4]) {
     EpiVec v0, v1;
     fwd_quarter_load<T, HALF, 0, ZADD>(v0, c, h);
     fwd_quarter_load<T, HALF, 1, ZADD>(v1, c, h);
-    fwd_quarter<T, HALF, 0, MASKS, ZADD>(acc, out, c, v0, mask);
-    fwd_quarter<T, HALF, 1, MASKS, ZADD>(acc, out, c, v1, mask);
+    fwd_quarter<T, HALF, 0, MASKS, ZADD, DUMP>(acc, out, c, v0, mask);
+    fwd_quarter<T, HALF, 1, MASKS, ZADD, DUMP>(acc, out, c, v1, mask);
 }
 
 // density head on finished enc_shape accumulators (bias included): this lane's share of w_sigma . y
@@ -296,7 +302,7 @@ __device__ __forceinline__ float sigma_partial(const f32x16 (&acc)[8], const flo
 // Each step is two half-steps of NT/2 tiles.  The A fragments of a half-step are fetched from LDS while the previous
 // half-step's MFMAs run (two fragment buffers), the next chunk is acquired half a step before it is needed, and the
 // previous layer's epilogue for operand step S+1 is split over the two half-steps of step S.
-template <int NT, bool MASKS, bool ZADD>
+template <int NT, bool MASKS, bool ZADD, bool DUMP = false>
 __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], XOp (&x)[16], const char* xdir_lds, Ring& ring, char* lds,
                                           const FwdEpi& c, bool extra, uint32_t (&mask)[4], int tid, int lane) {
     f32x16 accC[8];
@@ -310,7 +316,7 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], XOp (&x)[16], const
 #pragma unroll
     for (int i = 0; i < 4; ++i) mask[i] = 0u;
     acc_bias<NT, 8>(accC, c.bias, h);
-    fwd_half_tile<0, 0, MASKS, ZADD>(accP[0], x[0], c, h, mask);
+    fwd_half_tile<0, 0, MASKS, ZADD, DUMP>(accP[0], x[0], c, h, mask);
     Frags<NTH> fa, fb;
     const char* w = ring_acquire(ring, lds) + lane * 16;
     load_frags<NTH, 0>(fa, w);
@@ -326,7 +332,7 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], XOp (&x)[16], const
         }                                                                                                              \
         if constexpr ((S) == 15) mma_half_to<NTH, 0, 8>(accP, accC, x[S], fa); else mma_half<NTH, 0, 8>(accC, x[S], fa);       \
         ring_pieces_in<(2 * (S) + 1) % (2 * SPC), SPC, (2 * (S) + 1) / (2 * SPC), NCH, TAIL>(ring, voff);              \
-        if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0, MASKS, ZADD>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v0, mask); \
+        if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0, MASKS, ZADD, DUMP>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v0, mask); \
         SNR_INTERLEAVE(3 * NTH)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + STEP_BYTES);                                   \
@@ -334,7 +340,7 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], XOp (&x)[16], const
         if constexpr ((S) == 15) mma_half_to<NTH, NTH, 8>(accP, accC, x[S], fb); else mma_half<NTH, NTH, 8>(accC, x[S], fb);   \
         if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0)                                                \
             ring_pieces_in<(2 * (S) + 2) % (2 * SPC), SPC, (2 * (S) + 2) / (2 * SPC), NCH, TAIL>(ring, voff);          \
-        if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1, MASKS, ZADD>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v1, mask); \
+        if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1, MASKS, ZADD, DUMP>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v1, mask); \
         SNR_INTERLEAVE(3 * NTH)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
@@ -361,8 +367,8 @@ __device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], XOp (&x)[16], const
 #define SNR_STAMP(i) do {} while (0)
 #endif
 
-template <int MODE, bool MASKS, bool EBIAS>      // EBIAS: io.latent_bias holds the latent terms folded into the next layers' biases
-__global__ void __launch_bounds__(256, 1)
+template <int MODE, bool MASKS, bool EBIAS, bool DUMP = false>      // EBIAS: io.latent_bias holds the latent terms folded into the next layers' biases
+__global__ void __launch_bounds__(256, 1)                           // DUMP (training): io.act receives every MFMA layer's fp32 input
 bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom g,
                 float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_acc) {
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
@@ -489,6 +495,12 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         const int la = latent_after(l, sb, tb);
         c.bias = (EBIAS && la >= 0) ? latw + la * 256 : vec + VEC_BIAS + (l + 1) * 256;
         c.zl = (!EBIAS && la >= 0) ? latw + la * 256 : vec + VEC_ZERO;
+        c.dump = nullptr;
+        if (DUMP) {      // slot l = the output of layer l after activation and latent add = the input of layer l + 1
+            int t = threadIdx.x; asm volatile("" : "+v"(t));
+            const long long gpd = tile128 * 128 + wave * 32 + (t & 31);
+            if (gpd < io.n_points) c.dump = io.act + ((long long)l * io.n_points + gpd) * 256 + 4 * ((t & 63) >> 5);
+        }
         return c;
     };
     const bool tile_live = tile32 * 32 < io.n_points;     // the last workgroup may own wave tiles past the end: they store nothing
@@ -502,13 +514,13 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     };
 #pragma unroll 1
     for (int li = 1; li <= li_last; ++li) {
-        layer_fwd<8, MASKS, !EBIAS>(accA, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
+        layer_fwd<8, MASKS, !EBIAS, DUMP>(accA, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
         store_mask(li - 1);
         if (li == li_encshape) sig_dot = sigma_partial(accA, vec + VEC_SIGW, fresh_lane() >> 5);
         SNR_STAMP(3 + li);
     }
     // ---- rgb.0: 256 -> 128 (4 tiles) from the last 256-wide layer's accumulators
-    layer_fwd<4, MASKS, !EBIAS>(accA, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
+    layer_fwd<4, MASKS, !EBIAS, DUMP>(accA, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
     store_mask(li_last);
     SNR_STAMP(12);
 
@@ -522,6 +534,11 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     {
         uint32_t mk[2] = {0u, 0u};
         const float* w2 = vec + VEC_RGBW;
+        float* hdump = nullptr;           // training: ReLU(rgb.0), the input of rgb.2, slot li_last + 1 (128 columns)
+        if (DUMP) {
+            const long long gpd = tile128 * 128 + wave * 32 + p_t;
+            if (gpd < io.n_points) hdump = io.act + ((long long)(li_last + 1) * io.n_points + gpd) * 256 + 4 * h_t;
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -530,13 +547,16 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
                 const f32x4 wr = *reinterpret_cast<const f32x4*>(w2 + n0);
                 const f32x4 wg = *reinterpret_cast<const f32x4*>(w2 + 128 + n0);
                 const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + n0);
+                f32x4 dv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = accA[t][4 * j + e];
                     if (MASKS && v > 0.f) mk[t >> 1] |= 1u << ((t & 1) * 16 + 4 * j + e);
                     v = fmaxf(v, 0.f);
+                    dv[e] = v;
                     pr = fmaf(wr[e], v, pr); pg = fmaf(wg[e], v, pg); pb = fmaf(wb[e], v, pb);
                 }
+                if (DUMP) { if (hdump) *reinterpret_cast<f32x4*>(hdump + 32 * t + 8 * j) = dv; }
             }
         if (MASKS && tile_live) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane_t] = make_uint4(mk[0], mk[1], 0u, 0u);
     }
@@ -645,6 +665,7 @@ struct BwdEpi {
     const float* wsig;    // LDS: density-head weights (only below enc_shape: null otherwise)
     float dpre;           // d loss / d (pre-softplus density) of this lane's point
     float* dzl;           // LDS: where this wave parks the layer's latent-term gradient (256 floats), or null
+    float* dump;          // DUMP (training): this lane's row of the pre-activation gradient dump, [point][256] + 4h, or null
 #ifdef SNR_STAMPS
     unsigned long long* st;   // diagnostics: this wave tile's stamp row (lane 0 of live tiles), or null
 #endif
@@ -654,29 +675,33 @@ struct BwdEpi {
 #else
 #define SNR_LSTAMP(c, i) do {} while (0)
 #endif
-template <int T, int HALF, int JJ>
+template <int T, int HALF, int JJ, bool DUMP = false>
 __device__ __forceinline__ void bwd_quarter(const f32x16& acc, XOp& out, const BwdEpi& c, int lane) {
     const int j = 2 * HALF + JJ;
+    f32x4 dv;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int r = 4 * j + e;
         float v = acc[r];
         v = ((c.m[T >> 1] >> ((T & 1) * 16 + r)) & 1u) ? v : 0.f;
         split_store(v, out, r & 7);
+        if (DUMP) dv[e] = v;
     }
+    // training: the gradient wrt this layer's pre-activation (features 32T + 8j + 4h .. +3) goes to HBM for the weight-gradient product
+    if (DUMP) { if (c.dump) *reinterpret_cast<f32x4*>(c.dump + 32 * T + 8 * j) = dv; }
     if (JJ == 1) pin(out);
 }
-template <int T, int HALF>
+template <int T, int HALF, bool DUMP = false>
 __device__ __forceinline__ void bwd_half_tile(const f32x16& acc, XOp& out, const BwdEpi& c, int h, int lane) {
-    bwd_quarter<T, HALF, 0>(acc, out, c, lane);
-    bwd_quarter<T, HALF, 1>(acc, out, c, lane);
+    bwd_quarter<T, HALF, 0, DUMP>(acc, out, c, lane);
+    bwd_quarter<T, HALF, 1, DUMP>(acc, out, c, lane);
 }
 
 // One transposed layer: 16 operand steps from acc, NT output tiles back into acc (one code instance for the whole chain, like
 // layer_fwd); same half-step pipeline.  With
 // `ninth` (enc_viewdir^T) a ninth output tile, the gradient of the 32 direction features, follows from one more chunk: its 16
 // steps x (hi, lo) KiB are packed behind the layer's 8 regular chunks and multiply the operand steps still held in x.
-template <int NT>
+template <int NT, bool DUMP = false>
 __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16& acc9, XOp (&x)[16], Ring& ring, char* lds,
                                           const BwdEpi& c, bool ninth, int tid, int lane) {
     f32x16 accC[8];
@@ -701,7 +726,7 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16& acc9, XOp (
     }
     if (NT == 2) SNR_LSTAMP(c, 10);
     acc_zero<NT, 8>(accC);
-    bwd_half_tile<0, 0>(accP[0], x[0], c, h, lane);
+    bwd_half_tile<0, 0, DUMP>(accP[0], x[0], c, h, lane);
     Frags<NTH> fa, fb;
     const char* w = ring_acquire<TAIL && NCH == 1>(ring, lds) + lane * 16;
     load_frags<NTH, 0>(fa, w);
@@ -712,7 +737,7 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16& acc9, XOp (
         load_frags<NTH, NTH>(fb, ws);                                                                                  \
         if constexpr ((S) == 15) mma_half_to<NTH, 0, 8>(accP, accC, x[S], fa); else mma_half<NTH, 0, 8>(accC, x[S], fa);       \
         ring_pieces_in<(2 * (S) + 1) % (2 * SPC), SPC, (2 * (S) + 1) / (2 * SPC), NCH, TAIL>(ring, voff);              \
-        if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, lane); \
+        if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0, DUMP>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, lane); \
         SNR_INTERLEAVE_B(3 * NTH)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + step_bytes);                                   \
@@ -720,7 +745,7 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16& acc9, XOp (
         if constexpr ((S) == 15) mma_half_to<NTH, NTH, 8>(accP, accC, x[S], fb); else mma_half<NTH, NTH, 8>(accC, x[S], fb);   \
         if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0)                                                \
             ring_pieces_in<(2 * (S) + 2) % (2 * SPC), SPC, (2 * (S) + 2) / (2 * SPC), NCH, TAIL>(ring, voff);          \
-        if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, lane); \
+        if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1, DUMP>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, lane); \
         SNR_INTERLEAVE_B(3 * NTH)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
@@ -748,7 +773,7 @@ __device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16& acc9, XOp (
 #else
 #define SNR_BSTAMP(i) do {} while (0)
 #endif
-template <int MODE>
+template <int MODE, bool DUMP = false>      // DUMP (training): io.gdump receives the gradient wrt every MFMA layer's pre-activation
 __global__ void __launch_bounds__(256, 1)
 bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom g) {
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
@@ -852,6 +877,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
         uint32_t m[4];
         mask_words(n_relu - 1, m);
         const float* w2 = vec + VEC_RGBW;
+        float* hdump = (DUMP && live) ? io.gdump + ((long long)(li_last + 1) * io.n_points + gp) * 256 + 4 * h : nullptr;   // rgb.0's G, 128 columns
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -860,13 +886,16 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
                 const f32x4 wr = *reinterpret_cast<const f32x4*>(w2 + n0);
                 const f32x4 wg = *reinterpret_cast<const f32x4*>(w2 + 128 + n0);
                 const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + n0);
+                f32x4 dv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * j + e;
                     float v = wr[e] * gr + wg[e] * gg + wb[e] * gb;
                     v = ((m[t >> 1] >> ((t & 1) * 16 + r)) & 1u) ? v : 0.f;
+                    dv[e] = v;
                     split_store(v, x[2 * t + (r >> 3)], r & 7);
                 }
+                if (DUMP) { if (hdump) *reinterpret_cast<f32x4*>(hdump + 32 * t + 8 * j) = dv; }
             }
     }
 
@@ -893,6 +922,12 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
         c.dpre = (l == li_encshape) ? dpre : 0.f;
         const int la = latent_after(l, sb, tb);
         c.dzl = (la >= 0 && io.partial) ? reinterpret_cast<float*>(lds + OFF_LAT) + (wave * MAX_LAT + la) * 256 : nullptr;
+        c.dump = nullptr;
+        if (DUMP) {      // slot l = gradient wrt the pre-activation of MFMA layer l
+            int t = threadIdx.x; asm volatile("" : "+v"(t));
+            const long long gpd = tile128 * 128 + wave * 32 + (t & 31);
+            if (gpd < io.n_points) c.dump = io.gdump + ((long long)l * io.n_points + gpd) * 256 + 4 * ((t & 63) >> 5);
+        }
 #ifdef SNR_STAMPS
         c.st = (io.d_t && lane == 0 && tile32 * 32 < io.n_points) ? reinterpret_cast<unsigned long long*>(io.d_t) + tile32 * 16 : nullptr;
 #endif
@@ -901,12 +936,12 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     SNR_BSTAMP(3);
 #pragma unroll 1
     for (int li = li_last; li >= 1; --li) {
-        layer_bwd<8>(accA, acc9, x, ring, lds, epi_of(li), li == li_view, tid, lane);
+        layer_bwd<8, DUMP>(accA, acc9, x, ring, lds, epi_of(li), li == li_view, tid, lane);
         SNR_BSTAMP(4 + li_last - li);
     }
     SNR_BSTAMP(11);
     // ---- enc_xyz^T : 256 -> 64 positional-encoding features (two tiles, fp32)
-    layer_bwd<2>(accA, acc9, x, ring, lds, epi_of(0), false, tid, lane);
+    layer_bwd<2, DUMP>(accA, acc9, x, ring, lds, epi_of(0), false, tid, lane);
 
     SNR_BSTAMP(12);
     // ---- the parked latent-term gradients of this wave tile -> global partials (the ring is idle now)
@@ -1100,7 +1135,10 @@ int snr_bf16_launch_fwd_(int mode, const DecoderIO& io, const Layout& L, const f
     const unsigned grid = (unsigned)((io.n_points + 127) / 128);
     hipStream_t st = (hipStream_t)stream_;
     const bool ebias = mode == 1 && io.latent_bias && L.n_lat > 0;
-    if (io.masks) {
+    if (io.act) {          // training: points mode, ReLU bits and the per-layer input dump
+        if (mode != 0 || !io.masks) return SNR_E_ARG;
+        bf::bf16_fwd_kernel<0, true, false, true><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
+    } else if (io.masks) {
         if (mode == 0) bf::bf16_fwd_kernel<0, true, false><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
         else if (ebias) bf::bf16_fwd_kernel<1, true, true><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
         else bf::bf16_fwd_kernel<1, true, false><<<grid, 256, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc);
@@ -1114,7 +1152,10 @@ int snr_bf16_launch_fwd_(int mode, const DecoderIO& io, const Layout& L, const f
 
 int snr_bf16_launch_bwd_(int mode, const BwdIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, void* stream_) {
     const unsigned grid = (unsigned)((io.n_points + 127) / 128);
-    if (mode == 0) bf::bf16_bwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
+    if (io.gdump) {
+        if (mode != 0) return SNR_E_ARG;
+        bf::bf16_bwd_kernel<0, true><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
+    } else if (mode == 0) bf::bf16_bwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
     else bf::bf16_bwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
     return snr_check_launch_();
 }

@@ -245,7 +245,7 @@ int snr_decoder_fwd(const float* xyz, const float* viewdir, const float* latent,
                     int64_t points_per_obj, int sb, int tb, float* sigmas, float* rgbs, void* relu_masks, float* activations, int precision,
                     void* stream_) {
     if (!xyz || !viewdir || !latent || !packed) return SNR_E_ARG;
-    if (activations && precision != SNR_FP32) return SNR_E_UNSUPPORTED;      /* training dumps come from the fp32 kernels */
+    if (activations && !relu_masks) return SNR_E_ARG;                         /* training dumps go with the ReLU bits */
     if (sb < 0 || tb < 0 || sb > MAX_BLOCKS || tb > MAX_BLOCKS || n_points < 0) return SNR_E_ARG;
     if (points_per_obj < 1 || (n_points % points_per_obj) != 0) return SNR_E_SHAPE;
     if (n_points == 0) return SNR_OK;

@@ -393,7 +393,6 @@ int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent,
     io.partial = want_lat ? (float*)workspace : nullptr;
     io.d_xyz = d_xyz; io.d_dir = d_viewdir;
     io.gdump = layer_grads;
-    if (layer_grads && precision != SNR_FP32) return SNR_E_UNSUPPORTED;
     RayGeom g{};
     const Layout L = make_layout(sb, tb);
     int rc;

@@ -138,10 +138,9 @@ class _DecoderBase(nn.Module):
         if self.train_decoder_weights and torch.is_grad_enabled():
             # training mode (src/trainer_unified_nuscenes.py:120-129,334): gradients also reach the per-point decoder weights
             w = [p for p in self._per_point_params().values()]
-            # forward / backward to the activations run on the exact fp32 kernels; the weight-gradient products follow ``precision``
-            # ("fp32": exact fp32 MFMA; "auto" / "bf16x3": split-bf16 products, the HBM-bound fast path)
+            # ``precision`` decides the arithmetic of the whole step ("fp32": exact fp32 MFMA; "auto" / "bf16x3": split-bf16 products)
             sig, rgb = ops.DecoderPointsTrain.apply(xyz.reshape(-1, 3), viewdir.reshape(-1, 3), lat, self.shape_blocks,
-                                                    self.texture_blocks, "fp32" if self.precision == "fp32" else "bf16x3", *w)
+                                                    self.texture_blocks, self.precision, *w)
             return sig.view(*lead, 1), rgb.view(*lead, 3)
         sig, rgb = ops.DecoderPoints.apply(xyz.reshape(-1, 3), viewdir.reshape(-1, 3), lat, self.packed_weights(),
                                            self.shape_blocks, self.texture_blocks, self.precision)

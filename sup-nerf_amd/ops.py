@@ -417,37 +417,39 @@ def weight_grad(G, n_out, X, n_in, want_bias=True, out=None, ws=None, precision=
 
 class DecoderPointsTrain(torch.autograd.Function):
     """Training-mode decoder (SURVEY 8a9 mode B): like DecoderPoints but the per-point decoder WEIGHTS are inputs too and
-    receive gradients.  The fp32 kernels additionally write every layer's input X_l (forward) and pre-activation
-    gradient G_l (backward) to HBM, and the weight gradients dW_l = G_l^T X_l, db_l = sum_p G_l come from the split-K fp32-MFMA kernel
-    behind ``weight_grad`` (no library BLAS), in exact fp32 or -- ``wgrad_precision = "bf16x3"`` -- as split-bf16 products.  ``weights`` =
-    the per-point tensors in per_point_tensor_names order."""
+    receive gradients.  The layer-chain kernels additionally write every layer's input X_l (forward) and pre-activation
+    gradient G_l (backward) to HBM, and the weight gradients dW_l = G_l^T X_l, db_l = sum_p G_l come from the split-K MFMA kernels
+    behind ``weight_grad`` (no library BLAS).  ``precision``: "fp32" = exact fp32 MFMA throughout; "bf16x3" / "auto" = split-bf16
+    products in all three (the chains and the weight-gradient product; bias sums and the two narrow heads stay fp32).  ``weights`` = the
+    per-point tensors in per_point_tensor_names order."""
 
     @staticmethod
-    def forward(ctx, xyz, viewdir, latent, shape_blocks, texture_blocks, wgrad_precision, *weights):
+    def forward(ctx, xyz, viewdir, latent, shape_blocks, texture_blocks, precision, *weights):
         xyz, viewdir, latent = _f32c(xyz), _f32c(viewdir), _f32c(latent)
-        if wgrad_precision not in PRECISIONS:
-            raise SnrError(f"DecoderPointsTrain: weight-gradient precision must be 'fp32' or 'bf16x3', got {wgrad_precision!r}")
+        # one arithmetic for the whole step: the forward / backward layer chains and the weight-gradient products
+        prec = resolve_precision(precision, shape_blocks, texture_blocks, xyz.shape[0] // max(latent.shape[0], 1))
+        wgrad_precision = "bf16x3" if prec == BF16X3 else "fp32"
         names = per_point_tensor_names(shape_blocks, texture_blocks)
         packed = pack_weights(dict(zip(names, weights)), shape_blocks, texture_blocks)
         P, dev = xyz.shape[0], xyz.device
         n_slots = shape_blocks + texture_blocks + 4
         act = torch.empty(n_slots, P, 256, device=dev)
-        sig, rgb, masks = decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=True, precision="fp32",
+        sig, rgb, masks = decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=True, precision=prec,
                                       activations=act)
         ctx.save_for_backward(xyz, viewdir, latent, packed, masks, sig, act, *weights)
-        ctx.cfg = (shape_blocks, texture_blocks, wgrad_precision)
+        ctx.cfg = (shape_blocks, texture_blocks, wgrad_precision, prec)
         return sig, rgb
 
     @staticmethod
     def backward(ctx, d_sig, d_rgb):
         xyz, viewdir, latent, packed, masks, sig, act, *weights = ctx.saved_tensors
-        sb, tb, wprec = ctx.cfg
+        sb, tb, wprec, prec = ctx.cfg
         P, dev = xyz.shape[0], xyz.device
         n_slots = sb + tb + 4
         G = torch.empty(n_slots, P, 256, device=dev)
         d_sig, d_rgb = _f32c(d_sig), _f32c(d_rgb)
         d_lat, d_xyz, d_dir = decoder_bwd(xyz, viewdir, latent, packed, masks, sig, d_sig, d_rgb, sb, tb,
-                                          ctx.needs_input_grad[2], ctx.needs_input_grad[0], ctx.needs_input_grad[1], precision="fp32",
+                                          ctx.needs_input_grad[2], ctx.needs_input_grad[0], ctx.needs_input_grad[1], precision=prec,
                                           layer_grads=G)
         # ---- weight gradients: dW_l = G_l^T X_l, db_l = sum_p G_l on the split-K MFMA kernel (snr_weight_grad), one launch + one
         # reduction per layer; X of layer 0 and the direction features are the positional encodings (recomputed: 63 + 27 columns)

@@ -346,13 +346,19 @@ def test_training_shapes_volume_rendering_batch(amd, dev, model, golden):
     assert close_grad(sc.grad, g["d_shapecode"]) and close_grad(tc.grad, g["d_texturecode"])
 
 
-def test_training_step_weight_gradients(amd, dev, oracle_params, golden):
+@pytest.mark.parametrize("precision", ["fp32", "auto"])
+def test_training_step_weight_gradients(amd, dev, oracle_params, golden, precision):
     """Training mode (src/trainer_unified_nuscenes.py:120-129,334): loss.backward() also reaches every decoder weight.
     Checked against the reference's own gradients: every bias and small tensor in full, every weight's first row,
-    and sum / abs-sum of every tensor."""
+    and sum / abs-sum of every tensor.  "fp32": exact fp32 MFMA in the chains and the weight-gradient product; "auto": split-bf16 in all
+    three (2048 points here: a hidden unit whose pre-activation sits within round-off of zero flips its ReLU between the two arithmetics and
+    moves single entries by up to a percent; the aggregated sums stay at 1e-4)."""
     g = golden("train_step")
+    rel = 2e-4 if precision == "fp32" else 2e-2
+    rel_sum = 2e-4 if precision == "fp32" else 1e-3
     m = amd.CodeNeRF(shape_blocks=3, texture_blocks=1)
     m.load_state_dict(oracle_params, strict=True)
+    m.precision = precision
     m = m.to(dev)
     m.train_decoder_weights = True
     B, n, S = g["xyz"].shape[:3]
@@ -363,17 +369,19 @@ def test_training_step_weight_gradients(amd, dev, oracle_params, golden):
     loss = ((out[0] - g["tgt"].to(dev)) ** 2).mean() + 0.1 * out[2].mean()
     loss.backward()
     assert md(out[0], g["rgb"]) < TOL_RGB and abs(float(loss) - float(g["loss"])) < 1e-5
-    assert close_grad(sc.grad, g["d_shapecode"]) and close_grad(tc.grad, g["d_texturecode"])
+    assert close_grad(sc.grad, g["d_shapecode"], rel) and close_grad(tc.grad, g["d_texturecode"], rel)
+    worst = 0.0
     for name, p in m.named_parameters():
         key = name.replace(".", "_")
         assert p.grad is not None, name
         sums = g["dWsum_" + key].double()
         got = torch.stack([p.grad.double().sum(), p.grad.double().abs().sum()]).cpu()
-        assert float((got - sums).abs().max()) <= 2e-4 * float(sums[1]) + 1e-7, (name, got, sums)
-        if "dW_" + key in g:
-            assert close_grad(p.grad, g["dW_" + key]), name
-        if "dWrow0_" + key in g:
-            assert close_grad(p.grad[0], g["dWrow0_" + key]), name
+        assert float((got - sums).abs().max()) <= rel_sum * float(sums[1]) + 1e-7, (name, got, sums)
+        for k, a in (("dW_" + key, p.grad), ("dWrow0_" + key, p.grad[0] if p.grad.dim() == 2 else None)):
+            if k in g and a is not None:
+                worst = max(worst, md(a, g[k]) / (float(g[k].abs().max()) + 1e-30))
+                assert close_grad(a, g[k], rel), (name, k, md(a, g[k]), float(g[k].abs().max()))
+    print(f"[training gradients vs the reference, {precision}] worst relative entry error {worst:.2e}")
 
 
 def test_renderer_twins(amd, dev, model, oracle_params, golden, jitter):

@@ -78,14 +78,18 @@ def test_sharded_objects_single_process():
     assert list(D.shard_slice(3, 2, 1)) == [2]
 
 
-def test_training_step_matches_oracle(oracle_params):
+@pytest.mark.parametrize("precision", ["fp32", "auto"])
+def test_training_step_matches_oracle(oracle_params, precision):
     """supnerf_amd.trainer.train_step on the HIP training path: losses and EVERY gradient of the first
-    iteration against the oracle's autograd on the CPU, then three more iterations must keep lowering the loss."""
+    iteration against the oracle's autograd on the CPU, then three more iterations must keep lowering the loss.  Both arithmetics
+    (fp32: exact; auto: split-bf16 chains and weight-gradient products -- entries move by up to a percent where a ReLU flips)."""
     import supnerf_amd
     T = supnerf_amd.trainer
     dev = torch.device("cuda:0")
+    rel = 2e-4 if precision == "fp32" else 2e-2
     m = supnerf_amd.CodeNeRF(shape_blocks=3, texture_blocks=1)
     m.load_state_dict(oracle_params, strict=True)
+    m.precision = precision
     m = m.to(dev)
     m.train_decoder_weights = True
     codes = T.CodeTables(5, 256, seed=4).to(dev)
@@ -115,7 +119,7 @@ def test_training_step_matches_oracle(oracle_params):
     for (name, p) in list(m.named_parameters()) + [("shape_codes", codes.shape_codes.weight), ("texture_codes", codes.texture_codes.weight)]:
         want = {"shape_codes": w_sc, "texture_codes": w_tc}.get(name, p_cpu.get(name)).grad
         err = float((p.grad.cpu() - want).abs().max())
-        assert err <= 2e-4 * float(want.abs().max()) + 1e-7, (name, err, float(want.abs().max()))
+        assert err <= rel * float(want.abs().max()) + 1e-7, (name, err, float(want.abs().max()))
     bucket.zero()
     hp = dict(lr_schedule=[dict(lr=1e-4, interval=100), dict(lr=1e-3, interval=100)])
     opt = T.make_optimizer(m, codes, hp)
