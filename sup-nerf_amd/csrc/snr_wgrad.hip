@@ -211,31 +211,33 @@ wgrad_bf16x3_kernel(const float* __restrict__ G, long long ldg, int n_out, const
     }
 }
 
-// sum of the per-slice partials in slice order -> dW (n_out x n_in, leading dimension ld_dw) and db
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b, int n_slices, int n_out,
-                                                           int n_in, float* __restrict__ dW, long long ld_dw, float* __restrict__ db) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;          // over 256 x 256 (+ 256 for the bias)
-    if (idx < 256 * 256) {
-        const int i = idx >> 8, j = idx & 255;
-        if (i < n_out && j < n_in) {
-            // eight independent partial sums keep eight loads in flight; the association is fixed, so the result is the same bits every run
-            float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            int k = 0;
-            for (; k + 7 < n_slices; k += 8) {
+// sum of the per-slice partials -> dW (n_out x n_in, leading dimension ld_dw) and db.  Block = 256 outputs x 4 slice groups (1024 threads):
+// group g adds the slices k = g (mod 4) with eight loads in flight, the groups meet in LDS; the association is fixed, so the result is the
+// same bits every run.  Blocks 0..255 cover the 256 x 256 outputs, block 256 the bias.
+__global__ void __launch_bounds__(1024) wgrad_reduce_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b, int n_slices, int n_out,
+                                                            int n_in, float* __restrict__ dW, long long ld_dw, float* __restrict__ db) {
+    __shared__ float red[4][256];
+    const int j = threadIdx.x & 255, g = threadIdx.x >> 8;
+    const bool bias = blockIdx.x == 256;
+    if (bias && !(db && part_b)) return;
+    const int i = blockIdx.x;                                   // output row (weights) -- unused for the bias block
+    const float* src = bias ? part_b : part_w + i * 256;
+    const long long stride = bias ? 256 : 65536;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bias || (i < n_out && j < n_in)) {
+        int k = g;
+        for (; k + 28 < n_slices; k += 32) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s[u] += part_w[(long long)(k + u) * 65536 + idx];
-            }
-            for (; k < n_slices; ++k) s[k & 7] += part_w[(long long)k * 65536 + idx];
-            dW[i * ld_dw + j] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+            for (int u = 0; u < 8; ++u) s[u] += src[(long long)(k + 4 * u) * stride + j];
         }
-    } else if (db && part_b) {
-        const int i = idx - 256 * 256;
-        if (i < n_out) {
-            float s = 0.f;
-            for (int k = 0; k < n_slices; ++k) s += part_b[(long long)k * 256 + i];
-            db[i] = s;
-        }
+        for (int u = 0; k < n_slices; k += 4, ++u) s[u & 7] += src[(long long)k * stride + j];
     }
+    red[g][j] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (g != 0) return;
+    const float v = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+    if (bias) { if (j < n_out) db[j] = v; }
+    else if (i < n_out && j < n_in) dW[i * ld_dw + j] = v;
 }
 
 // narrow outputs (the density head: 1 row, the colour head: 3 rows): one thread per input column, points strided over the slices;
@@ -340,7 +342,7 @@ int snr_weight_grad(const float* G, int64_t ldg, int n_out, const float* X, int6
         if (n_points == 0) ns = 0;
         if (ns && precision == SNR_BF16X3) wgrad_bf16x3_kernel<<<ns, 256, 0, st>>>(G, ldg, n_out, X, ldx, n_in, n_points, pps, part_w, db ? part_b : nullptr);
         else if (ns) wgrad_mfma_kernel<<<ns, 256, 0, st>>>(G, ldg, n_out, X, ldx, n_in, n_points, pps, part_w, db ? part_b : nullptr);
-        wgrad_reduce_kernel<<<(256 * 256 + 256 + 255) / 256, 256, 0, st>>>(part_w, db ? part_b : nullptr, ns, n_out, n_in, dW, ld_dw, db);
+        wgrad_reduce_kernel<<<257, 1024, 0, st>>>(part_w, db ? part_b : nullptr, ns, n_out, n_in, dW, ld_dw, db);
     } else {
         if (n_out > 4) return SNR_E_UNSUPPORTED;        /* 5..31 output rows: no such layer in the decoder */
         float* part_w = ws; float* part_b = ws + (long long)ns * 4 * 256;

@@ -354,7 +354,7 @@ def test_training_step_weight_gradients(amd, dev, oracle_params, golden, precisi
     three (2048 points here: a hidden unit whose pre-activation sits within round-off of zero flips its ReLU between the two arithmetics and
     moves single entries by up to a percent; the aggregated sums stay at 1e-4)."""
     g = golden("train_step")
-    rel = 2e-4 if precision == "fp32" else 2e-2
+    rel = 2e-4 if precision == "fp32" else 5e-3
     rel_sum = 2e-4 if precision == "fp32" else 1e-3
     m = amd.CodeNeRF(shape_blocks=3, texture_blocks=1)
     m.load_state_dict(oracle_params, strict=True)

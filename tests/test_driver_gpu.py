@@ -86,7 +86,7 @@ def test_training_step_matches_oracle(oracle_params, precision):
     import supnerf_amd
     T = supnerf_amd.trainer
     dev = torch.device("cuda:0")
-    rel = 2e-4 if precision == "fp32" else 2e-2
+    rel = 2e-4 if precision == "fp32" else 5e-3
     m = supnerf_amd.CodeNeRF(shape_blocks=3, texture_blocks=1)
     m.load_state_dict(oracle_params, strict=True)
     m.precision = precision
