@@ -134,23 +134,9 @@ __global__ void __launch_bounds__(256) composite_fwd16_kernel(const float* __res
 // One wave per pixel.  The pixel's n = Nb*S samples (Nb per-object lists) are merged by depth with a rank sort in LDS --
 // every lane ranks its own elements against broadcast reads of the depth row -- then composited front to back with the same wave scan as every other composite here.  HBM-bound:
 // 20 B per sample in, 20 B per pixel out; the n^2/64 compares per lane stay below the load time up to n ~ 512.
-// number of elements of the ascending run zr[0..len) that are < v (UPPER: <= v): branch-free halving, at most 1 + log2(len) LDS reads
-template <bool UPPER>
-__device__ __forceinline__ int run_bound(const float* zr, int len, float v) {
-    int lo = 0;
-    while (len > 0) {
-        const int half = len >> 1;
-        const float m = zr[lo + half];
-        const bool go = UPPER ? (m <= v) : (m < v);
-        lo = go ? lo + half + 1 : lo;
-        len = go ? len - half - 1 : half;
-    }
-    return lo;
-}
-
 // `run` > 0: the pixel's n samples are n/run lists of `run` samples each, every list ascending in depth (one object's samples along its
 // ray; a list of an object that does not cover the pixel is all -1).  Then a sample's rank is its position in its own list plus, for every
-// other list, the number of smaller depths there -- two binary searches per list, O(n log(run) Nb) LDS reads per pixel instead of the n^2
+// other list, the number of smaller depths there -- two halving searches per list, O(n log(run) Nb) LDS reads per pixel instead of the n^2
 // of the generic rank sort below.  The lists are CHECKED to be ascending; a pixel whose lists are not takes the generic path.
 __global__ void __launch_bounds__(256) scene_composite_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                                                               const float* __restrict__ zv, long long n_pixels, int n, int run, int flags,
@@ -190,26 +176,40 @@ __global__ void __launch_bounds__(256) scene_composite_kernel(const float* __res
                     sg[c] = on ? srow[i] : 0.f;
                     cr[c] = on ? crow[3 * i] : 0.f; cg[c] = on ? crow[3 * i + 1] : 0.f; cb[c] = on ? crow[3 * i + 2] : 0.f;
                 }
+                // lower and upper bound of the four elements in every list at once: a halving search whose step sequence is the same for
+                // every lane (top = the largest power of two <= run), so the eight LDS reads of a step are independent and in flight together
+                int lt[4] = {0, 0, 0, 0}, eb[4] = {0, 0, 0, 0}, ea[4] = {0, 0, 0, 0}, rr[4], pp[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const int i = base + 64 * c + lane; rr[c] = i / run; pp[c] = i - rr[c] * run; }
+                const int top = 1 << (31 - __builtin_clz(run));
+                for (int q = 0; q < n_runs; ++q) {
+                    const float* zr = zs + q * run;
+                    int lb[4] = {0, 0, 0, 0}, ub[4] = {0, 0, 0, 0};
+                    for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int tl = lb[c] + step, tu = ub[c] + step;
+                            const float ml = zr[(tl <= run ? tl : run) - 1], mu = zr[(tu <= run ? tu : run) - 1];
+                            lb[c] = (tl <= run && ml < zi[c]) ? tl : lb[c];
+                            ub[c] = (tu <= run && mu <= zi[c]) ? tu : ub[c];
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        lt[c] += lb[c];
+                        const int cnt = ub[c] - lb[c];
+                        eb[c] += q < rr[c] ? cnt : (q == rr[c] ? pp[c] - lb[c] : 0);
+                        ea[c] += q > rr[c] ? cnt : (q == rr[c] ? ub[c] - pp[c] - 1 : 0);
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int i = base + 64 * c + lane;
                     if (i >= n) continue;
-                    const int r = i / run, p = i - r * run;
-                    int lt = 0, eb = 0, ea = 0;
-                    for (int q = 0; q < n_runs; ++q) {
-                        const float* zr = zs + q * run;
-                        const int lb = run_bound<false>(zr, run, zi[c]);
-                        const bool has_eq = lb < run && zr[lb] == zi[c];
-                        const int ub = has_eq ? lb + 1 + run_bound<true>(zr + lb + 1, run - lb - 1, zi[c]) : lb;
-                        lt += lb;
-                        if (q < r) eb += ub - lb;
-                        else if (q > r) ea += ub - lb;
-                        else { eb += p - lb; ea += ub - p - 1; }
-                    }
-                    const int pos = lt + eb;
+                    const int pos = lt[c] + eb[c];
                     s_z[pos] = zi[c];
-                    if (eb > 0) { s_sig[pos] = 0.f; s_r[pos] = 0.f; s_g[pos] = 0.f; s_b[pos] = 0.f; }
-                    if (ea == 0) { s_sig[lt] = sg[c]; s_r[lt] = cr[c]; s_g[lt] = cg[c]; s_b[lt] = cb[c]; }
+                    if (eb[c] > 0) { s_sig[pos] = 0.f; s_r[pos] = 0.f; s_g[pos] = 0.f; s_b[pos] = 0.f; }
+                    if (ea[c] == 0) { s_sig[lt[c]] = sg[c]; s_r[lt[c]] = cr[c]; s_g[lt[c]] = cg[c]; s_b[lt[c]] = cb[c]; }
                 }
             }
         }
