@@ -19,11 +19,18 @@ for prec in fp32 bf16x3; do
 done
 # 3. the one-object fused optimise loop (how many launches an iteration is, and what they cost)
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/loop -o loop -- python3 tools/prof_loop.py 30 > $out/loop.log 2>&1
-# 4. counters of the dominant kernels, separate passes (no trace domains mixed in)
+# 3b. the training step (BASELINE config 5's per-GPU shape): chains with dumps + the weight-gradient kernels
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/train -o train -- python3 tools/train_bench.py 8 > $out/train.log 2>&1
+# 4. counters of the dominant kernels, separate passes (no trace domains mixed in).  "fwd" = the headline forward (no ReLU bits saved),
+#    "bwd" = the optimiser's pair (forward that saves the bits + backward); the aggregation below takes the forward kernel's counters from
+#    the first and the backward kernel's from the second
 for prec in fp32 bf16x3; do
-  rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS -d $raw/pmc_sq_$prec -o pmc -- python3 tools/prof_fwd.py $prec 6 bwd > $out/pmc_sq_${prec}.log 2>&1
-  rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $raw/pmc_fetch_$prec -o pmc -- python3 tools/prof_fwd.py $prec 6 bwd > $out/pmc_fetch_${prec}.log 2>&1
-  rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $raw/pmc_write_$prec -o pmc -- python3 tools/prof_fwd.py $prec 6 bwd > $out/pmc_write_${prec}.log 2>&1
+  for which in fwd bwd; do
+    mode=""; [ $which = bwd ] && mode="bwd"
+    rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS -d $raw/pmc_sq_${prec}_$which -o pmc -- python3 tools/prof_fwd.py $prec 6 $mode > $out/pmc_sq_${prec}_$which.log 2>&1
+    rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $raw/pmc_fetch_${prec}_$which -o pmc -- python3 tools/prof_fwd.py $prec 6 $mode > $out/pmc_fetch_${prec}_$which.log 2>&1
+    rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $raw/pmc_write_${prec}_$which -o pmc -- python3 tools/prof_fwd.py $prec 6 $mode > $out/pmc_write_${prec}_$which.log 2>&1
+  done
 done
 find $raw -name "*kernel_stats.csv" | while read f; do cp "$f" $out/$(basename $(dirname "$f"))_$(basename "$f"); done
 find $raw -type f | head -60 > $out/raw_files.txt
@@ -33,7 +40,7 @@ raw, out = sys.argv[1], sys.argv[2]
 for prec, fwd_name, bwd_name in (("fp32", "decoder_fwd_kernel", "decoder_bwd_kernel"), ("bf16x3", "bf16_fwd_kernel", "bf16_bwd_kernel")):
     for which, kname in (("fwd", fwd_name), ("bwd", bwd_name)):
         agg = {}
-        for f in glob.glob(os.path.join(raw, f"pmc_*_{prec}", "**", "*counter_collection.csv"), recursive=True):
+        for f in glob.glob(os.path.join(raw, f"pmc_*_{prec}_{which}", "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 if kname not in row.get("Kernel_Name", ""):
                     continue
