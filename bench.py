@@ -358,7 +358,7 @@ def main():
     log("config 3: 64 objects sharded")
     # ---- BASELINE config 3 through the driver: 64 objects sharded over the ranks, one all_gather at the end
     model.precision = "auto"
-    n_it3 = 4
+    n_it3 = 8
     dt3, rows3, n_mine = c3_leg(model, dev, rank, world, dist, clock, n_it3)
     extra["c3_sharded"] = {"objects": C3_OBJECTS, "objects_this_rank": n_mine, "iterations": n_it3, "seconds": dt3,
                            "ms_per_iteration": dt3 / n_it3 * 1e3, "object_iterations_per_s": C3_OBJECTS * n_it3 / dt3,

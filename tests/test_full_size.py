@@ -5,6 +5,8 @@ exact fp32, against the CPU oracle:
   wrt both codes and the camera pose against the oracle's autograd at the same size;
 * config 3: 64 objects x 4096 x 64 in ONE per-object-depth launch -- all 64 bit-equal to single-object launches, three sampled objects
   against the oracle forward and backward;
+* config 5: the training step at its per-GPU size (6 objects x 1024 rays x 64 samples): loss and every weight / code gradient against the
+  oracle's autograd;
 * config 4: the KITTI cross-domain loop (``supnerf.kitti.car.json``: im_sz 32, roi_margin 15, KITTI intrinsics, ``obj_pose_kitti2nusc``) --
   the reference's own ``render_rays_v2`` numbers on a truncated car (fixture ``kitti``) and the optimise-loop trace against the same loop
   on the oracle renderer;
@@ -184,6 +186,51 @@ def test_config3_64_objects_one_launch(amd, dev, oracle_params, c3_inputs, c3_or
         e = (rel(sc.grad[b:b + 1], ref["g_sc"]), rel(tc.grad[b:b + 1], ref["g_tc"]))
         print(f"[config 3, {precision}] object {b}: rgb {md(rgb[sl], ref['out'][0]):.2e} code grad rel err {e[0]:.2e}/{e[1]:.2e}")
         assert max(e) < GRAD_REL[precision], (b, e)
+
+
+# ------------------------------------------------------------------ config 5 (training step at its per-GPU size)
+C5_OBJECTS, C5_RAYS = 6, 1024            # trainer_unified_nuscenes.py: batch 48 over 8 GPUs = 6 objects per GPU, n_rays 1024, 64 samples
+
+
+@pytest.fixture(scope="module")
+def c5_oracle(oracle_params):
+    """The NeRF half of ParallelModel.forward (src/trainer_unified_nuscenes.py:117-148) + loss_total.backward() on the oracle at
+    6 x 1024 x 64 = 393 216 points: every decoder weight gradient and both code gradients (about 15 s and 10 GB on the CPU)."""
+    g = torch.Generator().manual_seed(55)
+    B, n = C5_OBJECTS, C5_RAYS
+    batch = dict(xyz=torch.rand(B, n, S, 3, generator=g) - 0.5,
+                 viewdir=torch.nn.functional.normalize(torch.randn(B, n, 1, 3, generator=g), dim=-1).repeat(1, 1, S, 1),
+                 z_vals=torch.sort(torch.rand(B, S, generator=g) * 4 + 9, dim=-1)[0], rgb_tgt=torch.rand(B, n, 3, generator=g),
+                 occ_pixels=(torch.randint(0, 3, (B, n, 1), generator=g) - 1).float())
+    sc, tc = (torch.randn(B, 256, generator=g) * 0.3).requires_grad_(), (torch.randn(B, 256, generator=g) * 0.3).requires_grad_()
+    p = {k: v.clone().requires_grad_() for k, v in oracle_params.items()}
+    out = O.training_losses(p, batch["xyz"], batch["viewdir"], sc, tc, batch["z_vals"], batch["rgb_tgt"], batch["occ_pixels"], 0.1)
+    out[0].backward()
+    return dict(batch=batch, sc=sc.detach(), tc=tc.detach(), loss=float(out[0]), g_sc=sc.grad.clone(), g_tc=tc.grad.clone(),
+                g_w={k: v.grad.clone() for k, v in p.items() if v.grad is not None})
+
+
+@pytest.mark.parametrize("precision", ["fp32", "auto"])
+def test_config5_training_step_full_size(amd, dev, oracle_params, c5_oracle, precision):
+    """trainer.nerf_losses + backward on the HIP training path at BASELINE config 5's per-GPU size against the oracle's autograd."""
+    r = c5_oracle
+    T = amd.trainer
+    m = make_model(amd, dev, oracle_params, precision)
+    m.train_decoder_weights = True
+    batch = {k: v.to(dev) for k, v in r["batch"].items()}
+    sc, tc = r["sc"].to(dev).requires_grad_(), r["tc"].to(dev).requires_grad_()
+    losses_all, total = T.nerf_losses(m, batch["xyz"], batch["viewdir"], sc, tc, batch["z_vals"], batch["rgb_tgt"], batch["occ_pixels"], 0.1)
+    total.backward()
+    assert abs(float(total) - r["loss"]) < 2e-6
+    bound = 2e-4 if precision == "fp32" else 1e-3          # aggregated over 393 216 points: ReLU flips average out
+    worst = max(rel(sc.grad, r["g_sc"]), rel(tc.grad, r["g_tc"]))
+    for name, p in m.named_parameters():
+        assert p.grad is not None, name
+        e = rel(p.grad, r["g_w"][name])
+        worst = max(worst, e)
+        assert e < bound, (name, e)
+    print(f"[config 5, {precision}] 6 x 1024 x 64: loss {float(total):.6f}, worst relative gradient error over 28 tensors + codes {worst:.2e}")
+    assert worst < bound
 
 
 # ------------------------------------------------------------------ config 4 (KITTI)

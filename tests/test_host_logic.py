@@ -55,6 +55,35 @@ def test_sample_from_rays_v2_is_the_renderer_method(amd, golden):
     assert list(inspect.signature(amd.utils.sample_from_rays_v2).parameters) == ["rays", "n_samples"]
 
 
+def test_api_caches_follow_their_inputs(amd):
+    """The public render functions cache the camera-frame pixel table per (K, roi, grid) and the resized targets per (crop, mask, size):
+    a changed input must give changed outputs (in-place edits bump the tensor version; new tensors are new keys)."""
+    U = amd.utils
+    g = torch.Generator().manual_seed(0)
+    img, mask = torch.rand(20, 30, 3, generator=g), (torch.randint(0, 3, (20, 30, 1), generator=g) - 1).float()
+    a = U._resize_to(img, mask, 8, "cpu")
+    b = U._resize_to(img, mask, 8, "cpu")
+    assert a[0] is b[0] and a[1] is b[1]                                   # served from the cache
+    ref_t, ref_o = U._resize(img, mask, 8)
+    assert torch.equal(a[0], ref_t.reshape(-1, 3)) and torch.equal(a[1], ref_o.reshape(-1, 1))
+    img.mul_(0.5)                                                          # in-place edit of the caller's crop
+    c = U._resize_to(img, mask, 8, "cpu")
+    assert c[0] is not a[0] and torch.equal(c[0], U._resize(img, mask, 8)[0].reshape(-1, 3))
+    d = U._resize_to(img.clone(), mask, 8, "cpu")                          # another tensor with the same numbers: its own entry
+    assert d[0] is not c[0] and torch.equal(d[0], c[0])
+    assert U._resize_to(img, mask, 4, "cpu")[0].shape == (16, 3)           # another size
+    K = torch.tensor([[1000., 0., 500.], [0., 1000., 300.], [0., 0., 1.]])
+    pose = torch.cat([torch.eye(3), torch.tensor([[0.1], [0.2], [5.0]])], 1)
+    o1, d1 = U.get_rays(K, pose, [100, 50, 164, 114], uv_steps=[8, 8])
+    o2, d2 = U.get_rays(K, pose, [100, 50, 164, 114], uv_steps=[8, 8])
+    assert torch.equal(d1, d2)
+    K2 = K.clone(); K2[0, 2] = 510.
+    assert not torch.equal(U.get_rays(K2, pose, [100, 50, 164, 114], uv_steps=[8, 8])[1], d1)      # other intrinsics: other table
+    assert not torch.equal(U.get_rays(K, pose, [101, 50, 165, 114], uv_steps=[8, 8])[1], d1)       # other roi
+    want = O.pixel_rays(K, pose, torch.tensor([100, 50, 164, 114]), uv_steps=[8, 8])
+    assert torch.equal(o1, want[0]) and torch.equal(d1, want[1])
+
+
 def test_product_path_has_no_cpu_fallback(amd):
     p = O.init_decoder_params()
     with pytest.raises(amd.SnrError):
