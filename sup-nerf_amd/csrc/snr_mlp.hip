@@ -192,11 +192,24 @@ decoder_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const 
         x = sp.x; y = sp.y; z = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc;
     }
     float sg, cr, cg, cb;
+#ifdef SNR_STAMPS   /* diagnostic build (tools/build_diag.sh): the sigma buffer receives {s_memtime, s_memrealtime} at both ends of the workgroup */
+    unsigned long long st_c0 = 0, st_r0 = 0;
+    if (tid == 0) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c0), "=s"(st_r0) :: "memory");
+#endif
     decoder_forward_tile(io, L, lds, gp, live, tile128 * 4 + wave, x, y, z, dx, dy, dz, sg, cr, cg, cb);
+#ifdef SNR_STAMPS
+    if (tid == 0 && io.sigmas) {
+        unsigned long long c1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1) :: "memory");
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(io.sigmas) + tile128 * 4;
+        o[0] = st_c0; o[1] = st_r0; o[2] = c1; o[3] = r1;
+    }
+#else
     if (live && lane < 32) {
         if (io.sigmas) io.sigmas[gp] = sg;
         if (io.rgbs) { io.rgbs[gp * 3] = cr; io.rgbs[gp * 3 + 1] = cg; io.rgbs[gp * 3 + 2] = cb; }
     }
+#endif
     if (MODE == 1) {
         float* comp = lds + LDS_COMP;
         if (lane < 32) {

@@ -222,7 +222,7 @@ def test_config5_training_step_full_size(amd, dev, oracle_params, c5_oracle, pre
     losses_all, total = T.nerf_losses(m, batch["xyz"], batch["viewdir"], sc, tc, batch["z_vals"], batch["rgb_tgt"], batch["occ_pixels"], 0.1)
     total.backward()
     assert abs(float(total) - r["loss"]) < 2e-6
-    bound = 2e-4 if precision == "fp32" else 1e-3          # aggregated over 393 216 points: ReLU flips average out
+    bound = 2e-4 if precision == "fp32" else 3e-3          # per entry, relative to the tensor's largest (measured: fp32 5e-5, split-bf16 1.2e-3)
     worst = max(rel(sc.grad, r["g_sc"]), rel(tc.grad, r["g_tc"]))
     for name, p in m.named_parameters():
         assert p.grad is not None, name
