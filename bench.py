@@ -100,9 +100,10 @@ class Clock:
         self.dist, self.dev = dist, dev
 
     def barrier(self):
+        torch.cuda.synchronize()
         if self.dist is not None:
             self.dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     def wall(self, fn, steps, warmup):
         for _ in range(warmup):
@@ -199,12 +200,18 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SNR_BENCH_BACKEND=gloo: rehearsal of the N > 1 branch on a box with fewer GPUs than ranks (ranks share the cards; the numbers mean nothing)
+    backend = os.environ.get("SNR_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     clock = Clock(dist, dev)
 
     import supnerf_amd as A
