@@ -420,7 +420,11 @@ def main():
         cmp_bytes = P_h * 16 + Bh * N_RAYS * 20
         # scene composite (vis_scene): 131072 pixels x 3 objects x 64 samples, depth merge + composite
         P_s, n_s = 131072, 3 * N_SAMPLES
-        z_s = (torch.rand(P_s, 3, 1, device=dev) * 20 + 2 + torch.sort(torch.rand(P_s, 3, N_SAMPLES, device=dev), dim=-1)[0] * 4).view(P_s, n_s)
+        # per object and pixel: near + (far - near) * (k + u_k) / S, the stratified depths of sample_from_rays (src/utils.py:159-164); the three
+        # objects' depth ranges (4 m each, near in [2, 10) m) overlap for most pixels
+        strat = (torch.arange(N_SAMPLES, device=dev) + torch.rand(P_s, 3, N_SAMPLES, device=dev)) / N_SAMPLES
+        z_s = (torch.rand(P_s, 3, 1, device=dev) * 8 + 2 + strat * 4).view(P_s, n_s)
+        del strat
         sig_s, rgb_s = torch.rand(P_s, n_s, device=dev), torch.rand(P_s, n_s, 3, device=dev)
         t_scn = timed_ev(lambda: ops.scene_composite(sig_s, rgb_s, z_s, True, run_length=N_SAMPLES))      # as scene.py calls it
         scn_bytes = P_s * n_s * 20 + P_s * 20

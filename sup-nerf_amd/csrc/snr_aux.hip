@@ -138,7 +138,87 @@ __global__ void __launch_bounds__(256) composite_fwd16_kernel(const float* __res
 // ray; a list of an object that does not cover the pixel is all -1).  Then a sample's rank is its position in its own list plus, for every
 // other list, the number of smaller depths there -- two halving searches per list, O(n log(run) Nb) LDS reads per pixel instead of the n^2
 // of the generic rank sort below.  The lists are CHECKED to be ascending; a pixel whose lists are not takes the generic path.
-__global__ void __launch_bounds__(256) scene_composite_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+constexpr uint32_t SCENE_MARK = 0x7fc5ce4eu;    // "left to the general kernel": a quiet NaN with a payload
+
+// Fast merge of a pass of up to 4 x 64 own elements into lists of RUN (a power of two) depths each: rank = # smaller elements over all lists.
+// One branch-free halving search per (element, other list) with compile-time probe offsets (4 instructions a step); constant lists (the ray
+// misses that object: -1 everywhere) by formula, ties included; an element's own list gives its place directly.  Returns false (wave-uniform)
+// when an increasing list holds a depth equal to an element's -- the reference's equal-depth collapse then needs both bounds: general path.
+template <int RUN>
+__device__ __forceinline__ bool scene_merge_fast(const float* zs, int n, int n_runs, int base, int lane, const float (&zi)[4], const int (&rr)[4],
+                                                 const int (&pp)[4], int (&lt)[4], int (&eb)[4], int (&ea)[4]) {
+    bool ok = true;
+    const int nc = (n - base + 63) >> 6;                                    // passes of 64 that hold elements (uniform)
+    for (int q = 0; q < n_runs; ++q) {
+        const float* zr = zs + q * RUN;
+        const float z0 = zr[0], z1 = zr[RUN - 1];
+        if (z0 == z1) {                                                     // uniform
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float x = zi[c];
+                const bool eq = z0 == x, own = q == rr[c];
+                lt[c] += (z0 < x) ? RUN : 0;
+                eb[c] += eq ? (q < rr[c] ? RUN : (own ? pp[c] : 0)) : 0;
+                ea[c] += eq ? (q > rr[c] ? RUN : (own ? RUN - 1 - pp[c] : 0)) : 0;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c >= nc) continue;
+            const float x = zi[c];
+            const bool active = base + 64 * c + lane < n;
+            if (RUN == 64 && q == (base >> 6) + c) {                        // uniform: this pass of 64 IS list q
+                const float left = zr[(lane > 0 ? lane : 1) - 1], right = zr[lane < RUN - 1 ? lane + 1 : RUN - 2];
+                ok = ok && (!active || ((lane == 0 || left < x) && (lane == RUN - 1 || right > x)));
+                lt[c] += lane;
+                continue;
+            }
+            const char* zb = reinterpret_cast<const char*>(zr);
+            int off = 0;                                                    // bytes; elements before it are < x
+#pragma unroll
+            for (int step = RUN / 2; step > 0; step >>= 1) {
+                const float m = *reinterpret_cast<const float*>(zb + off + (step - 1) * 4);
+                off += (m < x) ? step * 4 : 0;
+            }
+            const float at = *reinterpret_cast<const float*>(zb + off);     // off <= (RUN - 1) * 4
+            const int lbq = (off >> 2) + ((at < x) ? 1 : 0);
+            const float nxt = *reinterpret_cast<const float*>(zb + (off + 4 < RUN * 4 ? off + 4 : off));
+            const bool hit = (at == x) || (at < x && lbq < RUN && nxt == x);
+            if (RUN == 64) {
+                ok = ok && (!active || !hit);
+                lt[c] += lbq;
+            } else {                                                        // a pass may straddle lists: own list per lane
+                const bool own = q == rr[c];
+                const float left = zr[(pp[c] > 0 ? pp[c] : 1) - 1], right = zr[pp[c] < RUN - 1 ? pp[c] + 1 : RUN - 2];
+                const bool own_ok = (pp[c] == 0 || left < x) && (pp[c] == RUN - 1 || right > x);
+                ok = ok && (!active || (own ? own_ok : !hit));
+                lt[c] += own ? pp[c] : lbq;
+            }
+        }
+    }
+    return __all(ok);
+}
+
+template <bool UPPER>
+__device__ __forceinline__ int run_bound(const float* zr, int len, float v) {
+    int lo = 0;
+    while (len > 0) {
+        const int half = len >> 1;
+        const float m = zr[lo + half];
+        const bool go = UPPER ? (m <= v) : (m < v);
+        lo = go ? lo + half + 1 : lo;
+        len = go ? len - half - 1 : half;
+    }
+    return lo;
+}
+
+// `run` > 0: the pixel's n samples are n/run lists of `run` samples each, every list ascending in depth (one object's samples along its
+// ray; a list of an object that does not cover the pixel is all -1).  Then a sample's rank is its position in its own list plus, for every
+// other list, the number of smaller depths there -- two binary searches per list, O(n log(run) Nb) LDS reads per pixel instead of the n^2
+// of the generic rank sort below.  The lists are CHECKED to be ascending; a pixel whose lists are not takes the generic path.
+template <bool MARKED_ONLY>
+__global__ void __launch_bounds__(256) scene_general_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                                                               const float* __restrict__ zv, long long n_pixels, int n, int run, int flags,
                                                               float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ acc) {
     extern __shared__ __attribute__((aligned(16))) float scene_lds[];
@@ -149,6 +229,7 @@ __global__ void __launch_bounds__(256) scene_composite_kernel(const float* __res
     const long long n_waves = (long long)gridDim.x * 4;
     const bool white = flags & SNR_WHITE_BKGD;
     for (long long pix = wave0; pix < n_pixels; pix += n_waves) {
+        if (MARKED_ONLY && __float_as_uint(rgb[pix * 3]) != SCENE_MARK) continue;     // the fast pass finished this pixel
         const float* zrow = zv + pix * n;
         const float* srow = sigmas + pix * n;
         const float* crow = rgbs + pix * n * 3;
@@ -176,40 +257,26 @@ __global__ void __launch_bounds__(256) scene_composite_kernel(const float* __res
                     sg[c] = on ? srow[i] : 0.f;
                     cr[c] = on ? crow[3 * i] : 0.f; cg[c] = on ? crow[3 * i + 1] : 0.f; cb[c] = on ? crow[3 * i + 2] : 0.f;
                 }
-                // lower and upper bound of the four elements in every list at once: a halving search whose step sequence is the same for
-                // every lane (top = the largest power of two <= run), so the eight LDS reads of a step are independent and in flight together
-                int lt[4] = {0, 0, 0, 0}, eb[4] = {0, 0, 0, 0}, ea[4] = {0, 0, 0, 0}, rr[4], pp[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { const int i = base + 64 * c + lane; rr[c] = i / run; pp[c] = i - rr[c] * run; }
-                const int top = 1 << (31 - __builtin_clz(run));
-                for (int q = 0; q < n_runs; ++q) {
-                    const float* zr = zs + q * run;
-                    int lb[4] = {0, 0, 0, 0}, ub[4] = {0, 0, 0, 0};
-                    for (int step = top; step > 0; step >>= 1) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int tl = lb[c] + step, tu = ub[c] + step;
-                            const float ml = zr[(tl <= run ? tl : run) - 1], mu = zr[(tu <= run ? tu : run) - 1];
-                            lb[c] = (tl <= run && ml < zi[c]) ? tl : lb[c];
-                            ub[c] = (tu <= run && mu <= zi[c]) ? tu : ub[c];
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        lt[c] += lb[c];
-                        const int cnt = ub[c] - lb[c];
-                        eb[c] += q < rr[c] ? cnt : (q == rr[c] ? pp[c] - lb[c] : 0);
-                        ea[c] += q > rr[c] ? cnt : (q == rr[c] ? ub[c] - pp[c] - 1 : 0);
-                    }
-                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int i = base + 64 * c + lane;
                     if (i >= n) continue;
-                    const int pos = lt[c] + eb[c];
+                    const int r = i / run, p = i - r * run;
+                    int lt = 0, eb = 0, ea = 0;
+                    for (int q = 0; q < n_runs; ++q) {
+                        const float* zr = zs + q * run;
+                        const int lb = run_bound<false>(zr, run, zi[c]);
+                        const bool has_eq = lb < run && zr[lb] == zi[c];
+                        const int ub = has_eq ? lb + 1 + run_bound<true>(zr + lb + 1, run - lb - 1, zi[c]) : lb;
+                        lt += lb;
+                        if (q < r) eb += ub - lb;
+                        else if (q > r) ea += ub - lb;
+                        else { eb += p - lb; ea += ub - p - 1; }
+                    }
+                    const int pos = lt + eb;
                     s_z[pos] = zi[c];
-                    if (eb[c] > 0) { s_sig[pos] = 0.f; s_r[pos] = 0.f; s_g[pos] = 0.f; s_b[pos] = 0.f; }
-                    if (ea[c] == 0) { s_sig[lt[c]] = sg[c]; s_r[lt[c]] = cr[c]; s_g[lt[c]] = cg[c]; s_b[lt[c]] = cb[c]; }
+                    if (eb > 0) { s_sig[pos] = 0.f; s_r[pos] = 0.f; s_g[pos] = 0.f; s_b[pos] = 0.f; }
+                    if (ea == 0) { s_sig[lt] = sg[c]; s_r[lt] = cr[c]; s_g[lt] = cg[c]; s_b[lt] = cb[c]; }
                 }
             }
         }
@@ -244,6 +311,82 @@ __global__ void __launch_bounds__(256) scene_composite_kernel(const float* __res
         __builtin_amdgcn_wave_barrier();
         RayOut o = composite_ray_fwd(n, lane, white, [&](int k, float& sg, float& cr, float& cg, float& cb, float& z, float& zn) {
             sg = s_sig[k]; cr = s_r[k]; cg = s_g[k]; cb = s_b[k];
+            z = s_z[k]; zn = (k < n - 1) ? s_z[k + 1] : 0.f;
+        });
+        if (lane == 0) {
+            rgb[pix * 3] = o.r; rgb[pix * 3 + 1] = o.g; rgb[pix * 3 + 2] = o.b;
+            if (depth) depth[pix] = o.depth;
+            if (acc) acc[pix] = o.acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+
+// ---- the fast pass -------------------------------------------------------------------------------------------------------------------
+// Pixels whose n <= 256 samples are lists of 32 / 64 / 128 ascending depths without equal depths inside or across increasing lists (all
+// but ~0.1 % of pixels): ranks by scene_merge_fast, scatter, composite.  Any other pixel is left to scene_general_kernel<true>, marked by a
+// NaN with a payload in rgb[3 pix] (a pixel whose true result carries those bits is recomputed to the same value).  Keeping the general
+// code out of this kernel keeps it at 4 waves per SIMD without spills; the next pixel's 5 x 4 values per lane are requested one pixel ahead
+// so that the memory latency is off the per-pixel chain LDS -> search -> scatter -> composite.
+template <int RUN>
+__global__ void __launch_bounds__(256) scene_fast_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ zv,
+                                                         long long n_pixels, int n, int flags, float* __restrict__ rgb, float* __restrict__ depth,
+                                                         float* __restrict__ acc) {
+    extern __shared__ __attribute__((aligned(16))) float scene_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* zs = scene_lds + (size_t)wave * 6 * n;          // unsorted depths | sorted sigma, r, g, b, z
+    float* s_sig = zs + n; float* s_r = s_sig + n; float* s_g = s_r + n; float* s_b = s_g + n; float* s_z = s_b + n;
+    const long long wave0 = (long long)blockIdx.x * 4 + wave;
+    const long long n_waves = (long long)gridDim.x * 4;
+    const bool white = flags & SNR_WHITE_BKGD;
+    const int n_runs = n / RUN;
+    float zq[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f}, rq[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f}, bq[4] = {0.f, 0.f, 0.f, 0.f};
+    auto request = [&](long long px) {                  // depths, densities and colours of pixel px, four per lane
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long long i = px * n + 64 * c + lane;
+            if (64 * c + lane < n) { zq[c] = zv[i]; sq[c] = sigmas[i]; rq[c] = rgbs[3 * i]; gq[c] = rgbs[3 * i + 1]; bq[c] = rgbs[3 * i + 2]; }
+        }
+    };
+    if (wave0 < n_pixels) request(wave0);
+    for (long long pix = wave0; pix < n_pixels; pix += n_waves) {
+        float zi[4], sg[4], cr[4], cg[4], cb[4];
+        int lt[4] = {0, 0, 0, 0}, eb[4] = {0, 0, 0, 0}, ea[4] = {0, 0, 0, 0}, rr[4], pp[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = 64 * c + lane;
+            zi[c] = zq[c]; sg[c] = sq[c]; cr[c] = rq[c]; cg[c] = gq[c]; cb[c] = bq[c];
+            if (i < n) zs[i] = zi[c];
+            rr[c] = i / RUN; pp[c] = i - rr[c] * RUN;
+        }
+        if (pix + n_waves < n_pixels) request(pix + n_waves);
+        __builtin_amdgcn_wave_barrier();
+        bool sorted = true;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = 64 * c + lane;
+            if (i < n) sorted = sorted && (pp[c] == RUN - 1 || zi[c] <= zs[i + 1]);
+        }
+        bool ranked = __all(sorted);
+        if (ranked) ranked = scene_merge_fast<RUN>(zs, n, n_runs, 0, lane, zi, rr, pp, lt, eb, ea);
+        if (!ranked) {                                   // wave-uniform
+            if (lane == 0) rgb[pix * 3] = __uint_as_float(SCENE_MARK);
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = 64 * c + lane;
+            if (i >= n) continue;
+            const int pos = lt[c] + eb[c];
+            s_z[pos] = zi[c];
+            if (eb[c] > 0) { s_sig[pos] = 0.f; s_r[pos] = 0.f; s_g[pos] = 0.f; s_b[pos] = 0.f; }
+            if (ea[c] == 0) { s_sig[lt[c]] = sg[c]; s_r[lt[c]] = cr[c]; s_g[lt[c]] = cg[c]; s_b[lt[c]] = cb[c]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        RayOut o = composite_ray_fwd(n, lane, white, [&](int k, float& sg_, float& cr_, float& cg_, float& cb_, float& z, float& zn) {
+            sg_ = s_sig[k]; cr_ = s_r[k]; cg_ = s_g[k]; cb_ = s_b[k];
             z = s_z[k]; zn = (k < n - 1) ? s_z[k + 1] : 0.f;
         });
         if (lane == 0) {
@@ -562,11 +705,21 @@ int snr_scene_composite_fwd(const float* sigmas, const float* rgbs, const float*
     const size_t lds = (size_t)4 * 6 * n_per_pixel * sizeof(float);
     if (lds > 160 * 1024) return SNR_E_UNSUPPORTED;            /* more than 1706 samples per pixel */
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scene_composite_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scene_general_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return snr_check_launch_();
     }
     const int grid = grid_for(n_pixels * 64, 256, 8192);
-    scene_composite_kernel<<<grid, 256, lds, (hipStream_t)stream_>>>(sigmas, rgbs, z_vals, n_pixels, n_per_pixel, run_length, flags, rgb, depth, acc);
+    hipStream_t st = (hipStream_t)stream_;
+    const bool fast = n_per_pixel <= 256 && (run_length == 32 || run_length == 64 || run_length == 128);
+    if (fast) {
+        // two launches: the fast pass finishes the pixels it can and marks the rest, the general kernel then takes the marked ones only
+        if (run_length == 32) scene_fast_kernel<32><<<grid, 256, lds, st>>>(sigmas, rgbs, z_vals, n_pixels, n_per_pixel, flags, rgb, depth, acc);
+        else if (run_length == 64) scene_fast_kernel<64><<<grid, 256, lds, st>>>(sigmas, rgbs, z_vals, n_pixels, n_per_pixel, flags, rgb, depth, acc);
+        else scene_fast_kernel<128><<<grid, 256, lds, st>>>(sigmas, rgbs, z_vals, n_pixels, n_per_pixel, flags, rgb, depth, acc);
+        scene_general_kernel<true><<<grid, 256, lds, st>>>(sigmas, rgbs, z_vals, n_pixels, n_per_pixel, run_length, flags, rgb, depth, acc);
+    } else {
+        scene_general_kernel<false><<<grid, 256, lds, st>>>(sigmas, rgbs, z_vals, n_pixels, n_per_pixel, run_length, flags, rgb, depth, acc);
+    }
     return snr_check_launch_();
 }
 

@@ -157,10 +157,12 @@ def test_scene_composite_golden(amd, dev, golden):
         assert float((depth.cpu() - g["b0_depth"]).abs().mean()) < TOL_DEPTH_MEAN and maxdiff(depth, g["b0_depth"]) < TOL_DEPTH_MAX
 
 
-@pytest.mark.parametrize("Nb,S,P", [(1, 64, 37), (3, 64, 501), (5, 64, 130), (8, 64, 64), (7, 33, 50), (16, 64, 9), (2, 5, 1000)])
+@pytest.mark.parametrize("Nb,S,P", [(1, 64, 37), (3, 64, 501), (4, 64, 257), (2, 128, 40), (4, 32, 77), (8, 32, 33), (5, 64, 130), (8, 64, 64), (7, 33, 50),
+                                     (16, 64, 9), (2, 5, 1000)])
 def test_scene_composite_shapes(amd, dev, Nb, S, P):
     """Other object counts incl. samples per pixel that are no multiple of 64, empty objects (depth -1) and exact ties
-    between objects; checked against the oracle's restatement of the reference (sort + searchsorted scatter)."""
+    between objects; checked against the oracle's restatement of the reference (sort + searchsorted scatter).  Up to 256 samples per pixel in
+    lists of 32 / 64 / 128 take the fast kernel + the general kernel for the pixels it marks (ties), everything else the general kernel alone."""
     gen = torch.Generator().manual_seed(Nb * 1000 + S)
     near = torch.rand(P, Nb, 1, generator=gen) * 20 + 2
     z = near + torch.sort(torch.rand(P, Nb, S, generator=gen), dim=-1)[0] * 4
