@@ -168,7 +168,9 @@ int snr_render_bwd(const snr_render_args* a, const float* sigmas, const float* r
  * run_length: S when each object's S samples are contiguous and ascending in depth (what vis_scene produces: stratified samples along
  * the object's ray, or all -1) -- the lists are then MERGED (binary searches, O(n log S Nb) per pixel) instead of rank-sorted (O(n^2));
  * the order is verified per pixel and a pixel with an unsorted list silently takes the rank sort, so the hint can never change a result.
- * 0 = no such structure.  sigmas, z_vals (P, n); rgbs (P, n, 3) -> rgb (P,3), depth (P) [nullable], acc_trans (P) [nullable].
+ * 0 = no such structure.  Lists of 32, 64 or 128 samples with n_per_pixel <= 256 take two launches on the stream: a fast pass for pixels
+ * without equal depths inside or across increasing lists (it marks the others in `rgb`) and the general kernel for the marked pixels.
+ * sigmas, z_vals (P, n); rgbs (P, n, 3) -> rgb (P,3), depth (P) [nullable], acc_trans (P) [nullable].
  * flags: SNR_WHITE_BKGD.  n_per_pixel <= 1706 (LDS).
  * ---------------------------------------------------------------------------------- */
 int snr_scene_composite_fwd(const float* sigmas, const float* rgbs, const float* z_vals, int64_t n_pixels, int n_per_pixel, int run_length,
