@@ -2,7 +2,9 @@
 
 Everything here requires fp32 tensors on an AMD GPU (``tensor.is_cuda`` under PyTorch-ROCm).
 There is no CPU/eager fallback -- a CPU tensor raises."""
+import copy
 import ctypes as C
+import math
 import warnings
 from typing import Dict, Optional, Sequence
 
@@ -366,6 +368,30 @@ def decoder_bwd(xyz, viewdir, latent, packed, masks, sigmas, d_sig, d_rgb, shape
     return d_latent, d_xyz, d_dir
 
 
+def _tile_pad(per_obj: int, unit: int = 1) -> int:
+    """Items per object after padding so that items x unit is a multiple of the 32-point wave tile (0 = no padding needed)."""
+    if (per_obj * unit) % 32 == 0:
+        return 0
+    step = 32 // math.gcd(32, unit)
+    return -(-per_obj // step) * step
+
+
+def _pad_rows(t, B, n, n_pad):
+    """(B*n, ...) -> (B*n_pad, ...): every object's block padded with zero rows (dummy points / rays: their upstream gradients are zero)."""
+    if t is None:
+        return None
+    v = t.reshape(B, n, *t.shape[1:])
+    out = v.new_zeros(B, n_pad, *t.shape[1:])
+    out[:, :n] = v
+    return out.reshape(B * n_pad, *t.shape[1:])
+
+
+def _unpad_rows(t, B, n, n_pad):
+    if t is None:
+        return None
+    return t.reshape(B, n_pad, *t.shape[1:])[:, :n].reshape(B * n, *t.shape[1:])
+
+
 class DecoderPoints(torch.autograd.Function):
     """SUPNeRF.forward on explicit points.  Differentiable wrt latent terms, xyz and viewdir (weights are
     treated as constants on this path)."""
@@ -374,19 +400,33 @@ class DecoderPoints(torch.autograd.Function):
     def forward(ctx, xyz, viewdir, latent, packed, shape_blocks, texture_blocks, precision="fp32"):
         xyz, viewdir, latent = _f32c(xyz), _f32c(viewdir), _f32c(latent)
         need = any(ctx.needs_input_grad[:3])
-        prec = resolve_precision(precision, shape_blocks, texture_blocks, xyz.shape[0] // max(latent.shape[0], 1))
+        B, P = max(latent.shape[0], 1), xyz.shape[0]
+        # the latent-gradient reduction works on whole 32-point wave tiles per object: other point counts (the reference takes any) are padded
+        # per object with dummy points whose upstream gradients are zero
+        n_pad = _tile_pad(P // B) if (ctx.needs_input_grad[2] and shape_blocks + texture_blocks > 0 and P % B == 0 and P > 0) else 0
+        ctx.pad = (B, P // B, n_pad)
+        if n_pad:
+            xyz, viewdir = _pad_rows(xyz, B, P // B, n_pad), _pad_rows(viewdir, B, P // B, n_pad)
+        prec = resolve_precision(precision, shape_blocks, texture_blocks, xyz.shape[0] // B)
         sig, rgb, masks = decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=need, precision=prec)
         if need:
             ctx.save_for_backward(xyz, viewdir, latent, packed, masks, sig)
             ctx.cfg = (shape_blocks, texture_blocks, prec)
+        if n_pad:
+            return _unpad_rows(sig, B, P // B, n_pad), _unpad_rows(rgb, B, P // B, n_pad)
         return sig, rgb
 
     @staticmethod
     def backward(ctx, d_sig, d_rgb):
         xyz, viewdir, latent, packed, masks, sig = ctx.saved_tensors
         sb, tb, prec = ctx.cfg
+        B, n, n_pad = ctx.pad
+        if n_pad:
+            d_sig, d_rgb = _pad_rows(_f32c(d_sig), B, n, n_pad), _pad_rows(_f32c(d_rgb), B, n, n_pad)
         d_lat, d_xyz, d_dir = decoder_bwd(xyz, viewdir, latent, packed, masks, sig, d_sig, d_rgb, sb, tb,
                                           ctx.needs_input_grad[2], ctx.needs_input_grad[0], ctx.needs_input_grad[1], precision=prec)
+        if n_pad:
+            d_xyz, d_dir = _unpad_rows(d_xyz, B, n, n_pad), _unpad_rows(d_dir, B, n, n_pad)
         return d_xyz, d_dir, d_lat, None, None, None, None
 
 
@@ -565,10 +605,26 @@ class FusedRender(torch.autograd.Function):
     def forward(ctx, rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg):
         rays_o, rays_d, t_vals, xyz_div, z_scale, latent = [_f32c(t) for t in (rays_o, rays_d, t_vals, xyz_div, z_scale, latent)]
         need = any(ctx.needs_input_grad[:6])
+        # few samples per ray (S < 32) and a ray count that leaves a partial 32-point wave tile per object: pad every object with dummy rays
+        # (see DecoderPoints); the outputs and gradients of the dummies are dropped
+        n = cfg.rays_per_obj
+        B = rays_o.shape[0] // n if n else 0
+        n_pad = _tile_pad(n, cfg.n_samples) if (ctx.needs_input_grad[5] and cfg.shape_blocks + cfg.texture_blocks > 0 and B > 0) else 0
+        ctx.pad = (B, n, n_pad)
+        if n_pad:
+            rays_o, rays_d = _pad_rows(rays_o, B, n, n_pad), _pad_rows(rays_d, B, n, n_pad)
+            if cfg.z_mode == Z_PER_RAY:
+                t_vals = _pad_rows(t_vals, B, n, n_pad)
+            if z_scale is not None and z_scale.numel() == B * n:
+                z_scale = _pad_rows(z_scale, B, n, n_pad)
+            cfg = copy.copy(cfg)
+            cfg.rays_per_obj = n_pad
         rgb, depth, acc, sig, rgbs, masks = render_fwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg, save_for_bwd=need)
         if need:
             ctx.save_for_backward(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, sig, rgbs, masks)
             ctx.cfg = cfg
+        if n_pad:
+            return _unpad_rows(rgb, B, n, n_pad), _unpad_rows(depth, B, n, n_pad), _unpad_rows(acc, B, n, n_pad)
         return rgb, depth, acc
 
     @staticmethod
@@ -580,9 +636,14 @@ class FusedRender(torch.autograd.Function):
         need_t = ctx.needs_input_grad[2]
         if need_t and cfg.z_mode != Z_PER_RAY:
             raise SnrError("gradient wrt shared / per-object depths is not provided (the reference detaches them)")
+        B, n, n_pad = ctx.pad
+        if n_pad:
+            d_rgb, d_depth, d_acc = [_pad_rows(_f32c(t), B, n, n_pad) for t in (d_rgb, d_depth, d_acc)]
         d_o, d_d, d_t, d_lat = render_bwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg, sig, rgbs, masks, d_rgb, d_depth, d_acc,
                                           need_o=ctx.needs_input_grad[0], need_d=ctx.needs_input_grad[1], need_t=need_t,
                                           need_latent=ctx.needs_input_grad[5])
+        if n_pad:
+            d_o, d_d, d_t = _unpad_rows(d_o, B, n, n_pad), _unpad_rows(d_d, B, n, n_pad), _unpad_rows(d_t, B, n, n_pad)
         return d_o, d_d, d_t, None, None, d_lat, None, None
 
 

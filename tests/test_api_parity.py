@@ -222,6 +222,36 @@ def test_model_forward_backward_vs_oracle_autograd(amd, dev, model, oracle_param
         assert close_grad(a.grad, b.grad), name
 
 
+@pytest.mark.parametrize("N,S,B", [(10, 7, 2), (3, 5, 3), (1, 33, 1), (6, 16, 2)])
+def test_model_backward_ragged_points_per_object(amd, dev, model, oracle_params, N, S, B):
+    """Point counts per object that are no multiple of the 32-point wave tile (the reference takes any, src/model_supnerf.py:241-269):
+    gradients wrt the codes still come out (the operator pads every object with dummy points), equal to the oracle's autograd."""
+    gen = torch.Generator().manual_seed(100 * N + S)
+    xyz = (torch.rand(B * N, S, 3, generator=gen) - 0.5).requires_grad_()
+    vd = torch.randn(B * N, S, 3, generator=gen); vd = (vd / vd.norm(dim=-1, keepdim=True)).requires_grad_()
+    sc = (torch.randn(B, 256, generator=gen) * 0.3).requires_grad_()
+    tc = (torch.randn(B, 256, generator=gen) * 0.3).requires_grad_()
+    ws, wr = torch.randn(B * N, S, 1, generator=gen), torch.randn(B * N, S, 3, generator=gen)
+    sig_o, rgb_o = O.decoder_forward(oracle_params, xyz, vd, sc, tc)
+    ((sig_o * ws).sum() + (rgb_o * wr).sum()).backward()
+    leaves = [t.detach().to(dev).requires_grad_() for t in (xyz, vd, sc, tc)]
+    sig, rgb = model(*leaves)
+    assert sig.shape == sig_o.shape and rgb.shape == rgb_o.shape
+    assert md(sig, sig_o) < 2e-5 and md(rgb, rgb_o) < 2e-5
+    ((sig * ws.to(dev)).sum() + (rgb * wr.to(dev)).sum()).backward()
+    for a, b, name in zip(leaves, (xyz, vd, sc, tc), ("xyz", "viewdir", "shapecode", "texturecode")):
+        assert a.grad.shape == b.grad.shape
+        if model.precision == "fp32" or name in ("shapecode", "texturecode"):
+            # (split-bf16: a code gradient sums the object's N x S points, so ONE point on the other side of a ReLU kink, see below, shows
+            # as ~1 % at 64 points and as several % at 15)
+            rel = 2e-4 if model.precision == "fp32" else (3e-2 if N * S >= 64 else 1e-1)
+            assert close_grad(a.grad, b.grad, rel=rel), (name, md(a.grad, b.grad), float(b.grad.abs().max()))
+        else:       # split-bf16: a point whose hidden unit sits within rounding of the ReLU's kink may differ by percents (DESIGN 4.3)
+            err = (a.grad.detach().cpu() - b.grad).abs().reshape(-1, 3).max(dim=1).values
+            off = int((err > 2e-3 * float(b.grad.abs().max())).sum())
+            assert off <= 2 and float(err.max()) < 0.1 * float(b.grad.abs().max()), (name, off, float(err.max()))
+
+
 @pytest.mark.parametrize("blocks", [(2, 1), (1, 2), (2, 2), (4, 0), (0, 4), (0, 0), (1, 0)])
 def test_model_backward_other_block_counts(amd, dev, blocks):
     """Odd and even numbers of 256-wide layers, no shape / no texture blocks: one code instance of the layer serves every chain
@@ -290,14 +320,14 @@ def test_gradients_family_b(amd, dev, model, golden, jitter):
     assert close_grad(pose.grad, g["d_cam_pose"], rel=5e-4)
 
 
-@pytest.mark.parametrize("S", [4, 8, 16, 32, 128])
-def test_fused_render_gradients_other_sample_counts(amd, dev, model, oracle_params, S):
+@pytest.mark.parametrize("S,N", [(4, 24), (8, 24), (16, 24), (32, 24), (128, 24), (4, 7), (16, 3), (8, 1)])
+def test_fused_render_gradients_other_sample_counts(amd, dev, model, oracle_params, S, N):
     """The per-ray gradient sums take a different path for every samples-per-ray count that divides 128 (lanes per ray:
     shuffles below 16, one DPP row at 16, row pairs at 32, LDS across waves above): forward and backward against the
-    oracle's autograd, family B (per-ray metric depths, white background)."""
+    oracle's autograd, family B (per-ray metric depths, white background).  Ray counts that leave a partial 32-point wave tile
+    (7 x 4, 3 x 16, 1 x 8 points) are padded with dummy rays inside the operator."""
     ops = amd.ops
-    gen = torch.Generator().manual_seed(S)
-    N = 24
+    gen = torch.Generator().manual_seed(S + 1000 * (N != 24) * N)
     ro = (torch.randn(N, 3, generator=gen) * 0.05 + torch.tensor([0.0, -2.2, 0.2])).requires_grad_()
     vd = torch.nn.functional.normalize(torch.randn(N, 3, generator=gen) * 0.1 + torch.tensor([0.0, 1.0, 0.0]), dim=-1).requires_grad_()
     t = (torch.sort(torch.rand(N, S, generator=gen), dim=-1)[0] * 1.5 + 1.4).requires_grad_()
