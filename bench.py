@@ -296,12 +296,12 @@ def main():
         for _ in range(5):
             fn()
         n = max(20, args.steps // 4)
-        # the launch is followed by the 2-step reduction of the latent partials and preceded by two memsets; the kernel dominates (>97 %)
+        # the launch is followed by the 2-step reduction of the latent partials; the kernel dominates (>97 %)
         return clock.events(fn, n)
     result["roofline_bwd"] = roofline(prec, bwd_ms(prec), "bwd")
     result[other]["roofline_bwd"] = roofline(other, bwd_ms(other), "bwd")
     for r in (result["roofline_bwd"], result[other]["roofline_bwd"]):
-        r["kernel_ms_includes"] = "backward kernel + two d_rays memsets + the reduction of the per-tile latent-gradient partials (one timed call of ops.render_bwd)"
+        r["kernel_ms_includes"] = "backward kernel + the reduction of the per-tile latent-gradient partials (one timed call of ops.render_bwd)"
 
     extra = {}
     log("public API legs")

@@ -202,6 +202,7 @@ class LossTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb, acc, rgb_tgt, occ, loss_occ_coef, rays_per_obj):
         rgb, acc, rgb_tgt, occ = _f32c(rgb), _f32c(acc), _f32c(rgb_tgt), _f32c(occ)
+        ctx.set_materialize_grads(False)        # (no zero tensors for outputs nobody differentiated: each would be a fill launch)
         out = loss_tail_fwd(rgb, acc, rgb_tgt, occ, loss_occ_coef, rays_per_obj)
         ctx.save_for_backward(rgb, acc, rgb_tgt, occ)
         ctx.cfg = (float(loss_occ_coef), int(rays_per_obj))
@@ -216,6 +217,8 @@ class LossTail(torch.autograd.Function):
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             raise SnrError("loss_tail: the targets and occupancy labels are data, no gradient is provided")
         dev = rgb.device
+        if g_loss is None:
+            return None, None, None, None, None, None
         d_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[0] else None
         d_acc = torch.empty_like(acc) if ctx.needs_input_grad[1] else None
         if d_rgb is not None or d_acc is not None:
@@ -240,6 +243,7 @@ class PoseRays(torch.autograd.Function):
         if rot_vec.shape != (B, 3) or trans_vec.shape != (B, 3) or half_diag.numel() != B or (jitter is not None and jitter.shape != (B, n_samples)):
             raise SnrError("pose_rays: expected rot_vec / trans_vec (B,3), cam_dirs (B,n,3), half_diag (B,), jitter (B,S)")
         dev = cam_dirs.device
+        ctx.set_materialize_grads(False)        # (the kernel takes null for the gradients of outputs that were not used)
         cam2opt = torch.empty(B, 3, 4, device=dev)
         rays_o, viewdir = torch.empty(B * n, 3, device=dev), torch.empty(B * n, 3, device=dev)
         z = torch.empty(B, n_samples, device=dev)
@@ -605,6 +609,7 @@ class FusedRender(torch.autograd.Function):
     def forward(ctx, rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg):
         rays_o, rays_d, t_vals, xyz_div, z_scale, latent = [_f32c(t) for t in (rays_o, rays_d, t_vals, xyz_div, z_scale, latent)]
         need = any(ctx.needs_input_grad[:6])
+        ctx.set_materialize_grads(False)        # (e.g. the depth output of an optimise iteration: the kernel takes null upstream gradients)
         # few samples per ray (S < 32) and a ray count that leaves a partial 32-point wave tile per object: pad every object with dummy rays
         # (see DecoderPoints); the outputs and gradients of the dummies are dropped
         n = cfg.rays_per_obj
@@ -637,6 +642,8 @@ class FusedRender(torch.autograd.Function):
         if need_t and cfg.z_mode != Z_PER_RAY:
             raise SnrError("gradient wrt shared / per-object depths is not provided (the reference detaches them)")
         B, n, n_pad = ctx.pad
+        if d_rgb is None and d_depth is None and d_acc is None:
+            return None, None, None, None, None, None, None, None
         if n_pad:
             d_rgb, d_depth, d_acc = [_pad_rows(_f32c(t), B, n, n_pad) for t in (d_rgb, d_depth, d_acc)]
         d_o, d_d, d_t, d_lat = render_bwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg, sig, rgbs, masks, d_rgb, d_depth, d_acc,
@@ -661,8 +668,8 @@ def render_bwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg: Re
         raise SnrError(f"gradient wrt the latent codes needs whole 32-point wave tiles per object, got {cfg.rays_per_obj} rays x {cfg.n_samples} "
                        "samples per object: pad the ray batch of every object so that rays x samples is a multiple of 32, or detach the codes")
     d_lat = torch.empty_like(latent) if need_latent else None
-    d_o = torch.zeros_like(rays_o) if need_o else None
-    d_d = torch.zeros_like(rays_d) if need_d else None
+    d_o = torch.empty_like(rays_o) if need_o else None      # (the kernel writes every ray's gradient exactly once: no memset)
+    d_d = torch.empty_like(rays_d) if need_d else None
     d_t = torch.empty_like(t_vals) if need_t else None
     a = _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg.frame, cfg.xyz_mul, cfg.z_mode, cfg.flags,
                      cfg.rays_per_obj, cfg.n_samples, cfg.shape_blocks, cfg.texture_blocks,
