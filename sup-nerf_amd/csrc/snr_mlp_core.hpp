@@ -91,28 +91,35 @@ __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NA], const float* __
         }
 }
 
-// accumulators -> next layer's operand registers: optional ReLU (+ mask bits), optional latent add
+// accumulators -> next layer's operand registers: optional ReLU (+ mask bits), optional latent add.  This runs between two layers with the
+// matrix pipe idle (hiding it does not pay: tools/_diag/experiments/README.md), so it is kept to 4-5 VALU instructions per value: the ReLU bit
+// is the sign of (0 - v), shifted in by one v_alignbit (highest element first, so element r lands on bit r); the max is one v_med3 against an
+// opaque +inf (a constant would be rewritten as canonicalise + v_max); without ReLU the floor is -inf and the bits are not stored.
 template <int NT, int NA>
 __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NA], float (&in)[9][16], bool relu, const float* __restrict__ zlat, int h,
                                          uint32_t (&mask)[4]) {
+    const float lo = relu ? 0.f : -__builtin_inff();
+    float hi = __builtin_inff();
+    asm volatile("" : "+v"(hi));
 #pragma unroll
     for (int i = 0; i < 4; ++i) mask[i] = 0u;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+        uint32_t m16 = 0u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 3; j >= 0; --j) {
             f32x4 zv = {0.f, 0.f, 0.f, 0.f};
             if (zlat) zv = *reinterpret_cast<const f32x4*>(zlat + 32 * t + 8 * j + 4 * h);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 3; e >= 0; --e) {
                 float v = acc[t][4 * j + e];
-                if (relu) {
-                    if (v > 0.f) mask[t >> 1] |= 1u << ((t & 1) * 16 + 4 * j + e);
-                    v = fmaxf(v, 0.f);
-                }
+                m16 = __builtin_amdgcn_alignbit(m16, __float_as_uint(0.f - v), 31);
+                v = __builtin_amdgcn_fmed3f(v, lo, hi);
                 in[t][4 * j + e] = v + zv[e];
             }
         }
+        mask[t >> 1] = (t & 1) ? (mask[t >> 1] | (m16 << 16)) : m16;
+    }
 }
 
 // which latent term (index into the (B,NLAT,256) table) is added after MFMA layer li; -1 = none
