@@ -18,25 +18,36 @@
 namespace snr {
 
 // accumulators -> operand registers with the saved ReLU bits applied (mask == nullptr: pass through);
-// `add` (nullable) is a per-feature vector scaled by `scale` added first (density-head path).
+// `add` (nullable, wave-uniform) is a per-feature vector scaled by `scale` added first (density-head path).
+// Between two layers the matrix pipe waits for this, so the common case is 3 VALU instructions per value: read, one v_bfe_i32 that
+// turns bit k into 0 / ~0, one v_and.
 template <int NT>
 __device__ __forceinline__ void masked_to_operand(const f32x16 (&acc)[9], float (&in)[9][16], const uint4* mask, const float* __restrict__ add,
                                                   float scale, int h) {
-    uint32_t m[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-    if (mask) { const uint4 v = *mask; m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w; }
+    int m[4] = {-1, -1, -1, -1};
+    if (mask) { const uint4 v = *mask; m[0] = (int)v.x; m[1] = (int)v.y; m[2] = (int)v.z; m[3] = (int)v.w; }
+    if (add) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 av = {0.f, 0.f, 0.f, 0.f};
-            if (add) av = *reinterpret_cast<const f32x4*>(add + 32 * t + 8 * j + 4 * h);
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(add + 32 * t + 8 * j + 4 * h);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = acc[t][4 * j + e] + scale * av[e];
-                const bool on = (m[t >> 1] >> ((t & 1) * 16 + 4 * j + e)) & 1u;
-                in[t][4 * j + e] = on ? v : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[t][4 * j + e] + scale * av[e];
+                    const int keep = __builtin_amdgcn_sbfe(m[t >> 1], (t & 1) * 16 + 4 * j + e, 1);
+                    in[t][4 * j + e] = __uint_as_float(__float_as_uint(v) & (uint32_t)keep);
+                }
             }
-        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int keep = __builtin_amdgcn_sbfe(m[t >> 1], (t & 1) * 16 + r, 1);
+                in[t][r] = __uint_as_float(__float_as_uint(acc[t][r]) & (uint32_t)keep);
+            }
+    }
 }
 
 template <int NT>
@@ -203,8 +214,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
 
     // ---- rgb.0^T : 128 -> 256
     auto rows_of = [&](int li) { return li == li_view ? K_VIEW_PAD : (li == 0 ? K_XYZ_PAD : 256); };
-    acc_zero<8>(acc);
-    step<8, 9>(acc, in[0], pipe, lds, 256, tid);
+    step<8, 9, true>(acc, in[0], pipe, lds, 256, tid);                 // (ZERO_C: the accumulators start from the constant 0)
     step<8, 9>(acc, in[1], pipe, lds, 256, tid);
     step<8, 9>(acc, in[2], pipe, lds, 256, tid);
     step<8, 9>(acc, in[3], pipe, lds, rows_of(li_last), tid);
@@ -218,9 +228,8 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
         masked_to_operand<8>(acc, in, relu ? io.masks + (tile32m * n_relu + relu_slot(li, sb)) * 64 + lane : nullptr,
                              li == li_encshape ? io.packed + L.sigma_w : nullptr, dpre, h);
         if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)li * io.n_points + gp) * 256, h);
-        acc_zero<9>(acc);
         const int rows = rows_of(li), rows_after = rows_of(li - 1);
-        step<8, 9>(acc, in[0], pipe, lds, rows, tid, is_view);
+        step<8, 9, true>(acc, in[0], pipe, lds, rows, tid, is_view);
         step<8, 9>(acc, in[1], pipe, lds, rows, tid, is_view);
         step<8, 9>(acc, in[2], pipe, lds, rows, tid, is_view);
         step<8, 9>(acc, in[3], pipe, lds, rows, tid, is_view);
@@ -240,8 +249,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     // ---- enc_xyz^T : 256 -> 64 positional-encoding features
     masked_to_operand<8>(acc, in, io.masks + (tile32m * n_relu + 0) * 64 + lane, nullptr, 0.f, h);
     if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)0 * io.n_points + gp) * 256, h);
-    acc_zero<2>(acc);
-    step<2, 9>(acc, in[0], pipe, lds, 64, tid);
+    step<2, 9, true>(acc, in[0], pipe, lds, 64, tid);
     step<2, 9>(acc, in[1], pipe, lds, 64, tid);
     step<2, 9>(acc, in[2], pipe, lds, 64, tid);
     step<2, 9>(acc, in[3], pipe, lds, 64, tid);

@@ -33,7 +33,8 @@ __device__ __forceinline__ void chunk_dma(const float* __restrict__ g, float* ld
 // one 32-deep k-chunk: acc[t] += W[32t..32t+31][chunk] * b     (NT output tiles).
 // aoff[j] = this lane's float offset of 16-byte slot (2j + h) in row (lane & 31), swizzle applied.
 // The A fragment of the next 4 MFMAs is fetched before the current 4 are issued.
-template <int NT, int NA, int T0 = 0>
+// ZERO_C: the accumulators start from zero -- the first MFMA of every tile takes the constant 0 as its C operand instead of a zeroed register set
+template <int NT, int NA, int T0 = 0, bool ZERO_C = false>
 __device__ __forceinline__ void chunk_mma(f32x16 (&acc)[NA], const float (&b)[16], const float* wbuf, const int (&aoff)[4]) {
     // output tiles T0 .. T0+NT-1
     f32x4 a = *reinterpret_cast<const f32x4*>(wbuf + aoff[0] + T0 * 32 * KC);
@@ -45,8 +46,10 @@ __device__ __forceinline__ void chunk_mma(f32x16 (&acc)[NA], const float (&b)[16
             if (t + 1 < T0 + NT) an = *reinterpret_cast<const f32x4*>(wbuf + aoff[j] + (t + 1) * 32 * KC);
             else if (j + 1 < 4) an = *reinterpret_cast<const f32x4*>(wbuf + aoff[j + 1] + T0 * 32 * KC);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[4 * j + e], acc[t], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[4 * j + e], (ZERO_C && j == 0 && e == 0) ? zero : acc[t], 0, 0, 0);
+            }
             a = an;
         }
     }
@@ -67,12 +70,12 @@ __device__ __forceinline__ void pipe_init(Pipe& p, const float* stream, int lane
 }
 
 // consume the current chunk while the following one (rows_next x 32; 0 = none) lands in the other buffer
-template <int NT, int NA>
+template <int NT, int NA, bool ZERO_C = false>
 __device__ __forceinline__ void step(f32x16 (&acc)[NA], const float (&b)[16], Pipe& p, float* lds, int rows_next, int tid,
                                      bool extra_tile = false) {
     if (rows_next) chunk_dma(p.next, lds + (p.cur ^ 1) * WBUF, rows_next, tid);
-    chunk_mma<NT, NA>(acc, b, lds + p.cur * WBUF, p.aoff);
-    if (NA > NT && extra_tile) chunk_mma<1, NA, (NA > NT ? NT : 0)>(acc, b, lds + p.cur * WBUF, p.aoff);   // tile NT (backward of enc_viewdir)
+    chunk_mma<NT, NA, 0, ZERO_C>(acc, b, lds + p.cur * WBUF, p.aoff);
+    if (NA > NT && extra_tile) chunk_mma<1, NA, (NA > NT ? NT : 0), ZERO_C>(acc, b, lds + p.cur * WBUF, p.aoff);   // tile NT (backward of enc_viewdir)
     p.next += rows_next * KC;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
