@@ -17,15 +17,15 @@
 
 namespace snr {
 
-// accumulators -> operand registers with the saved ReLU bits applied (mask == nullptr: pass through);
+// accumulators -> operand registers with the saved ReLU bits applied (has_mask == false: pass through);
 // `add` (nullable, wave-uniform) is a per-feature vector scaled by `scale` added first (density-head path).
 // Between two layers the matrix pipe waits for this, so the common case is 3 VALU instructions per value: read, one v_bfe_i32 that
 // turns bit k into 0 / ~0, one v_and.
 template <int NT>
-__device__ __forceinline__ void masked_to_operand(const f32x16 (&acc)[9], float (&in)[9][16], const uint4* mask, const float* __restrict__ add,
-                                                  float scale, int h) {
+__device__ __forceinline__ void masked_to_operand(const f32x16 (&acc)[9], float (&in)[9][16], bool has_mask, const uint4& mask /* requested a layer ahead */,
+                                                  const float* __restrict__ add, float scale, int h) {
     int m[4] = {-1, -1, -1, -1};
-    if (mask) { const uint4 v = *mask; m[0] = (int)v.x; m[1] = (int)v.y; m[2] = (int)v.z; m[3] = (int)v.w; }
+    if (has_mask) { m[0] = (int)mask.x; m[1] = (int)mask.y; m[2] = (int)mask.z; m[3] = (int)mask.w; }
     if (add) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -212,7 +212,8 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- rgb.0^T : 128 -> 256
+    // ---- rgb.0^T : 128 -> 256   (the first boundary's ReLU bits, layer li_last's, are requested before its four chunks)
+    uint4 mk_next = io.masks[(tile32m * n_relu + relu_slot(li_last, sb)) * 64 + lane];
     auto rows_of = [&](int li) { return li == li_view ? K_VIEW_PAD : (li == 0 ? K_XYZ_PAD : 256); };
     step<8, 9, true>(acc, in[0], pipe, lds, 256, tid);                 // (ZERO_C: the accumulators start from the constant 0)
     step<8, 9>(acc, in[1], pipe, lds, 256, tid);
@@ -225,8 +226,10 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
         const bool is_view = (li == li_view);
         const bool relu = (li != li_encshape);
         // acc = gradient wrt the OUTPUT of layer li; enc_shape's output also feeds the density head
-        masked_to_operand<8>(acc, in, relu ? io.masks + (tile32m * n_relu + relu_slot(li, sb)) * 64 + lane : nullptr,
-                             li == li_encshape ? io.packed + L.sigma_w : nullptr, dpre, h);
+        masked_to_operand<8>(acc, in, relu, mk_next, li == li_encshape ? io.packed + L.sigma_w : nullptr, dpre, h);
+        // the ReLU bits the NEXT boundary applies (layer li-1's, enc_xyz's after the loop) are requested now, a whole layer ahead:
+        // a load at the boundary itself would expose a memory round trip with the matrix pipe idle
+        mk_next = io.masks[(tile32m * n_relu + (li - 1 >= 1 ? relu_slot(li - 1, sb) : 0)   /* (enc_shape: a valid slot, not applied) */) * 64 + lane];
         if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)li * io.n_points + gp) * 256, h);
         const int rows = rows_of(li), rows_after = rows_of(li - 1);
         step<8, 9, true>(acc, in[0], pipe, lds, rows, tid, is_view);
@@ -247,7 +250,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     }
 
     // ---- enc_xyz^T : 256 -> 64 positional-encoding features
-    masked_to_operand<8>(acc, in, io.masks + (tile32m * n_relu + 0) * 64 + lane, nullptr, 0.f, h);
+    masked_to_operand<8>(acc, in, true, mk_next, nullptr, 0.f, h);
     if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)0 * io.n_points + gp) * 256, h);
     step<2, 9, true>(acc, in[0], pipe, lds, 64, tid);
     step<2, 9>(acc, in[1], pipe, lds, 64, tid);
