@@ -34,7 +34,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     const int n_relu = n_relu_layers(sb, tb);
     // a workgroup covers 4 wave tiles; the last one of a launch may own tiles past the end (buffers are sized for ceil(P/32) tiles)
     const bool tile_live = tile32 * 32 < io.n_points;
-    const float* bias = io.packed + L.bias;
+    const float* bias = lds + LDS_BIAS;            // staged in the prologue
     const float* lat = io.latent + (gp / io.points_per_obj) * (long long)L.n_lat * 256;
 
     float in[9][16];
@@ -47,6 +47,13 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     {
         chunk_dma(pipe.next, lds, 256, tid);
         pipe.next += 256 * KC;
+        // every layer's bias -> LDS (1 KiB per LDS-DMA instruction and wave, landed before the prologue's rendezvous): the accumulators
+        // are initialised from there between layers, an LDS round trip with the matrix pipe idle instead of a memory one
+        for (int r = wave; r < L.n_mfma_layers; r += 4) {
+            typedef const __attribute__((address_space(1))) void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+            __builtin_amdgcn_global_load_lds((gptr_t)(io.packed + L.bias + r * 256 + lane * 4), (lptr_t)(lds + LDS_BIAS + r * 256), 16, 0, 0);
+        }
         float* sc = lds + LDS_SCRATCH + wave * PE_WAVE + p * PE_ROW;
         // 30 (freq, axis) pairs of the xyz encoding, 15 per half-wave; 12 of the direction encoding, 6 each
 #pragma unroll 1
