@@ -35,6 +35,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     // a workgroup covers 4 wave tiles; the last one of a launch may own tiles past the end (buffers are sized for ceil(P/32) tiles)
     const bool tile_live = tile32 * 32 < io.n_points;
     const float* bias = lds + LDS_BIAS;            // staged in the prologue
+    const float* heads = bias + L.n_mfma_layers * 256;   // sigma_w (256) | sigma_b | rgb2_w (384) | rgb2_b, as in the packed stream
     const float* lat = io.latent + (gp / io.points_per_obj) * (long long)L.n_lat * 256;
 
     float in[9][16];
@@ -49,7 +50,8 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         pipe.next += 256 * KC;
         // every layer's bias -> LDS (1 KiB per LDS-DMA instruction and wave, landed before the prologue's rendezvous): the accumulators
         // are initialised from there between layers, an LDS round trip with the matrix pipe idle instead of a memory one
-        for (int r = wave; r < L.n_mfma_layers; r += 4) {
+        // (+ 3 KiB: sigma_w | sigma_b | rgb2_w | rgb2_b follow the biases in the packed stream, snr_layout.h)
+        for (int r = wave; r < L.n_mfma_layers + 3; r += 4) {
             typedef const __attribute__((address_space(1))) void* gptr_t;
             typedef __attribute__((address_space(3))) void* lptr_t;
             __builtin_amdgcn_global_load_lds((gptr_t)(io.packed + L.bias + r * 256 + lane * 4), (lptr_t)(lds + LDS_BIAS + r * 256), 16, 0, 0);
@@ -123,7 +125,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         if (io.act && live) dump_operand<8>(in, io.act + ((long long)li * io.n_points + gp) * 256, h);
         if (li == li_encshape) {
             // density head: softplus(w_sigma . y + b)   (src/model_supnerf.py:257)
-            const float* ws = io.packed + L.sigma_w;
+            const float* ws = heads;
             float part = 0.f;
 #pragma unroll
             for (int t = 0; t < 8; ++t)
@@ -133,7 +135,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) part = fmaf(wv[e], in[t][4 * j + e], part);
                 }
-            const float pre = sum_halves(part) + io.packed[L.sigma_b];
+            const float pre = sum_halves(part) + heads[L.sigma_b - L.sigma_w];
             o_sigma = pre > 20.f ? pre : log1pf(expf(pre));
         }
     }
@@ -152,7 +154,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     if (io.masks && tile_live) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mask[0], mask[1], 0u, 0u);
     if (io.act && live) dump_operand<4>(in, io.act + ((long long)(li_last + 1) * io.n_points + gp) * 256, h);
     {
-        const float* w2 = io.packed + L.rgb2_w;
+        const float* w2 = heads + (L.rgb2_w - L.sigma_w);
         float pr = 0.f, pg = 0.f, pb = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -168,7 +170,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
                     pr = fmaf(wr[e], v, pr); pg = fmaf(wg[e], v, pg); pb = fmaf(wb[e], v, pb);
                 }
             }
-        const float* b2 = io.packed + L.rgb2_b;
+        const float* b2 = heads + (L.rgb2_b - L.sigma_w);
         o_r = sum_halves(pr) + b2[0];
         o_g = sum_halves(pg) + b2[1];
         o_b = sum_halves(pb) + b2[2];
