@@ -38,6 +38,12 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     const float* heads = bias + L.n_mfma_layers * 256;   // sigma_w (256) | sigma_b | rgb2_w (384) | rgb2_b, as in the packed stream
     const float* lat = io.latent + (gp / io.points_per_obj) * (long long)L.n_lat * 256;
 
+    // one latent table for the whole workgroup (its 128 points are consecutive) and few enough rows: they are staged in LDS with the biases and
+    // the epilogues read them from there (an LDS round trip at the layer boundary instead of a memory one)
+    const long long wg_first = (long long)blockIdx.x * 128;
+    const long long wg_last = wg_first + 127 < io.n_points ? wg_first + 127 : io.n_points - 1;
+    const bool lat_in_lds = (wg_first / io.points_per_obj) == (wg_last / io.points_per_obj) && L.n_lat <= LDS_LAT_ROWS;
+    const float* lat_wg = io.latent + (wg_first / io.points_per_obj) * (long long)L.n_lat * 256;
     float in[9][16];
     f32x16 acc[8];
     uint32_t mask[4];
@@ -56,6 +62,12 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
             typedef __attribute__((address_space(3))) void* lptr_t;
             __builtin_amdgcn_global_load_lds((gptr_t)(io.packed + L.bias + r * 256 + lane * 4), (lptr_t)(lds + LDS_BIAS + r * 256), 16, 0, 0);
         }
+        if (lat_in_lds)
+            for (int r = wave; r < L.n_lat; r += 4) {
+                typedef const __attribute__((address_space(1))) void* gptr_t;
+                typedef __attribute__((address_space(3))) void* lptr_t;
+                __builtin_amdgcn_global_load_lds((gptr_t)(lat_wg + r * 256 + lane * 4), (lptr_t)(lds + LDS_LAT + r * 256), 16, 0, 0);
+            }
         float* sc = lds + LDS_SCRATCH + wave * PE_WAVE + p * PE_ROW;
         // 30 (freq, axis) pairs of the xyz encoding, 15 per half-wave; 12 of the direction encoding, 6 each
 #pragma unroll 1
@@ -95,7 +107,8 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     step<8, 8>(acc, in[1], pipe, lds, 256, tid);
     {
         const int la = latent_after(0, sb, tb);
-        epilogue<8, 8>(acc, in, true, la >= 0 ? lat + la * 256 : nullptr, h, mask);
+        if (lat_in_lds && la >= 0) epilogue<8, 8>(acc, in, true, lds + LDS_LAT + la * 256, h, mask);
+        else epilogue<8, 8>(acc, in, true, la >= 0 ? lat + la * 256 : nullptr, h, mask);
         if (io.masks && tile_live) io.masks[(tile32 * n_relu + 0) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
         if (io.act && live) dump_operand<8>(in, io.act + ((long long)0 * io.n_points + gp) * 256, h);
     }
@@ -119,7 +132,8 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         if (is_view) step<8, 8>(acc, in[8], pipe, lds, rows_after, tid);
         const bool relu = (li != li_encshape);
         const int la = latent_after(li, sb, tb);
-        epilogue<8, 8>(acc, in, relu, la >= 0 ? lat + la * 256 : nullptr, h, mask);
+        if (lat_in_lds && la >= 0) epilogue<8, 8>(acc, in, relu, lds + LDS_LAT + la * 256, h, mask);
+        else epilogue<8, 8>(acc, in, relu, la >= 0 ? lat + la * 256 : nullptr, h, mask);
         if (relu && io.masks && tile_live)
             io.masks[(tile32 * n_relu + relu_slot(li, sb)) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
         if (io.act && live) dump_operand<8>(in, io.act + ((long long)li * io.n_points + gp) * 256, h);

@@ -13,7 +13,9 @@ constexpr int COMP_STRIDE = 8;                      // sigma r g b zc + pad
 constexpr int LDS_COMP = LDS_SCRATCH + 4 * PE_WAVE;
 constexpr int LDS_BIAS = LDS_COMP + 128 * COMP_STRIDE;    // forward: every MFMA layer's bias (n_mfma_layers x 256) and, right behind them as in
                                                           // the packed stream, the two small heads (648 floats), staged once per workgroup
-constexpr int LDS_TOTAL = LDS_BIAS + (2 * MAX_BLOCKS + 4 + 3) * 256;   // floats
+constexpr int LDS_LAT = LDS_BIAS + (2 * MAX_BLOCKS + 4 + 3) * 256;     // forward: the workgroup's latent rows (up to LDS_LAT_ROWS x 256) when it has ONE object
+constexpr int LDS_LAT_ROWS = 8;
+constexpr int LDS_TOTAL = LDS_LAT + LDS_LAT_ROWS * 256;   // floats
 static_assert(LDS_TOTAL * 4 <= 160 * 1024, "LDS budget");
 
 // Weight chunks are stored in the packed stream as the exact LDS image (snr_layout.h: 16-byte slot
