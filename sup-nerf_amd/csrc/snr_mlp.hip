@@ -19,6 +19,13 @@
 
 namespace snr {
 
+#ifdef SNR_STAMPS   /* diagnostic build (tools/build_diag.sh): thread 0 of every workgroup writes s_memtime at phase boundaries into the sigma buffer */
+#define SNR32_STAMP(i) do { if (threadIdx.x == 0 && io.sigmas) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        reinterpret_cast<unsigned long long*>(io.sigmas)[(long long)blockIdx.x * 16 + 4 + (i)] = t_; } } while (0)
+#else
+#define SNR32_STAMP(i) do {} while (0)
+#endif
+
 // -------------------------------------------------------------------------------------------
 // The decoder for the 32 points of this wave.  Inputs: point (x,y,z) and direction (dx,dy,dz) of
 // lane's point p = lane & 31 (both half-waves hold the same point).  Outputs sigma, r, g, b valid in
@@ -101,6 +108,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         for (int r = 0; r < 16; ++r) in[8][r] = sc[64 + 8 * (r >> 2) + 4 * h + (r & 3)];
     }
 
+    SNR32_STAMP(0);      // prologue (encodings, staging) done
     // ---- enc_xyz: 64 -> 256
     acc_init_bias<8, 8>(acc, bias, h);
     step<8, 8>(acc, in[0], pipe, lds, 256, tid);
@@ -113,6 +121,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         if (io.act && live) dump_operand<8>(in, io.act + ((long long)0 * io.n_points + gp) * 256, h);
     }
 
+    SNR32_STAMP(1);      // enc_xyz + its epilogue
     // ---- the 256-wide middle layers: shape blocks, enc_shape, enc_viewdir, texture blocks
     const int li_encshape = sb + 1, li_view = sb + 2, li_last = sb + tb + 2;
     o_sigma = 0.f;
@@ -137,6 +146,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         if (relu && io.masks && tile_live)
             io.masks[(tile32 * n_relu + relu_slot(li, sb)) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
         if (io.act && live) dump_operand<8>(in, io.act + ((long long)li * io.n_points + gp) * 256, h);
+        if (li <= 6) SNR32_STAMP(1 + li);      // layer li + its epilogue (+ bias init of the next)
         if (li == li_encshape) {
             // density head: softplus(w_sigma . y + b)   (src/model_supnerf.py:257)
             const float* ws = heads;
@@ -154,6 +164,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         }
     }
 
+    SNR32_STAMP(8);
     // ---- rgb.0: 256 -> 128, ReLU;  rgb.2: 128 -> 3 on the VALU
     acc_init_bias<4, 8>(acc, bias + (li_last + 1) * 256, h);
     step<4, 8>(acc, in[0], pipe, lds, 128, tid);
@@ -164,6 +175,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     step<4, 8>(acc, in[5], pipe, lds, 128, tid);
     step<4, 8>(acc, in[6], pipe, lds, 128, tid);
     step<4, 8>(acc, in[7], pipe, lds, 0, tid);
+    SNR32_STAMP(9);      // rgb.0's chunks
     epilogue<4, 8>(acc, in, true, nullptr, h, mask);
     if (io.masks && tile_live) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mask[0], mask[1], 0u, 0u);
     if (io.act && live) dump_operand<4>(in, io.act + ((long long)(li_last + 1) * io.n_points + gp) * 256, h);
@@ -224,7 +236,7 @@ decoder_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const 
     if (tid == 0 && io.sigmas) {
         unsigned long long c1, r1;
         asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1) :: "memory");
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(io.sigmas) + tile128 * 4;
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(io.sigmas) + tile128 * 16;     // [4 ..]: SNR32_STAMP phases
         o[0] = st_c0; o[1] = st_r0; o[2] = c1; o[3] = r1;
     }
 #else

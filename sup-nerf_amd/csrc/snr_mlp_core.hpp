@@ -88,14 +88,26 @@ __device__ __forceinline__ void step(f32x16 (&acc)[NA], const float (&b)[16], Pi
 
 template <int NT, int NA>
 __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NA], const float* __restrict__ bias, int h) {
+    // the loads of tile t+1 are issued before tile t is handed to the accumulators, and that order is pinned: left alone the compiler
+    // sinks every load to its use (the register file is full here) and each of the 32 round trips is waited for on its own
+    f32x4 cur[4], nxt[4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int j = 0; j < 4; ++j) cur[j] = *reinterpret_cast<const f32x4*>(bias + 8 * j + 4 * h);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * t + 8 * j + 4 * h);
+    for (int t = 0; t < NT; ++t) {
+        if (t + 1 < NT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t][4 * j + e] = bv[e];
+            for (int j = 0; j < 4; ++j) nxt[j] = *reinterpret_cast<const f32x4*>(bias + 32 * (t + 1) + 8 * j + 4 * h);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * j + e] = cur[j][e];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+    }
 }
 
 // accumulators -> next layer's operand registers: optional ReLU (+ mask bits), optional latent add.  This runs between two layers with the
@@ -110,22 +122,35 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NA], float (&in)[9]
     asm volatile("" : "+v"(hi));
 #pragma unroll
     for (int i = 0; i < 4; ++i) mask[i] = 0u;
+    // (the latent values of tile t+1 are requested before tile t's arithmetic, order pinned: see acc_init_bias)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 zc[4] = {zero4, zero4, zero4, zero4}, zn[4] = {zero4, zero4, zero4, zero4};
+    if (zlat) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zc[j] = *reinterpret_cast<const f32x4*>(zlat + 8 * j + 4 * h);
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+        if (zlat && t + 1 < NT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zn[j] = *reinterpret_cast<const f32x4*>(zlat + 32 * (t + 1) + 8 * j + 4 * h);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         uint32_t m16 = 0u;
 #pragma unroll
         for (int j = 3; j >= 0; --j) {
-            f32x4 zv = {0.f, 0.f, 0.f, 0.f};
-            if (zlat) zv = *reinterpret_cast<const f32x4*>(zlat + 32 * t + 8 * j + 4 * h);
 #pragma unroll
             for (int e = 3; e >= 0; --e) {
                 float v = acc[t][4 * j + e];
                 m16 = __builtin_amdgcn_alignbit(m16, __float_as_uint(0.f - v), 31);
                 v = __builtin_amdgcn_fmed3f(v, lo, hi);
-                in[t][4 * j + e] = v + zv[e];
+                in[t][4 * j + e] = v + zc[j][e];
             }
         }
         mask[t >> 1] = (t & 1) ? (mask[t >> 1] | (m16 << 16)) : m16;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zc[j] = zn[j];
     }
 }
 

@@ -40,7 +40,7 @@ for _ in range(20):
     stamps.snr_render_fwd(C.byref(a), rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), dbg.data_ptr(), None, None, st())
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
-t = dbg.cpu().numpy().view(np.uint64).reshape(-1, 4)[: N * S // 128].astype(np.int64)
+t = dbg.cpu().numpy().view(np.uint64).reshape(-1, 16)[: N * S // 128].astype(np.int64)
 cyc = t[:, 2] - t[:, 0]; real = t[:, 3] - t[:, 1]
 clk = cyc / np.maximum(real, 1) * 100.0        # MHz
 span_real = (t[:, 3].max() - t[:, 1].min()) / 100.0   # us
@@ -52,3 +52,14 @@ flops_wg = 2.0 * 128 * (64 * 256 + 5 * 256 * 256 + 288 * 256 + 256 * 128)
 peak_at_clk = 256 * 4 * (32 * 32 * 2 * 2 / 64.0) * np.median(clk) * 1e6
 print(f"MFMA flops per workgroup {flops_wg:.3e}; fp32 MFMA peak at the measured clock {peak_at_clk/1e12:.1f} TFLOP/s; "
       f"achieved {flops_wg * (N * S // 128) / (ms * 1e-3) / 1e12:.1f} TFLOP/s = {flops_wg * (N * S // 128) / (ms * 1e-3) / peak_at_clk:.3f} of it")
+
+names = ["prologue", "enc_xyz + boundary"] + [f"layer {i} + boundary" for i in range(1, 7)] + ["(to rgb.0)", "rgb.0 chunks"]
+ph = t[:, 4:14] - t[:, :1]
+med = np.median(ph, axis=0)
+floor = [0, 2 * 128 * 64] + [8 * 128 * 64] * 4 + [9 * 128 * 64] + [8 * 128 * 64] + [0, 8 * 64 * 64]
+print("phase, cycles from workgroup start (median), this phase, its MFMA cycles")
+prev = 0
+for n_, m_, f_ in zip(names, med, floor):
+    print(f"  {n_:22s} {m_:9.0f}  +{m_ - prev:8.0f}   {f_:7d}")
+    prev = m_
+print(f"  {'heads, composite, end':22s} {np.median(cyc):9.0f}  +{np.median(cyc) - prev:8.0f}")
