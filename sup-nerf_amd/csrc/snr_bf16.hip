@@ -257,15 +257,26 @@ __device__ __forceinline__ void fwd_half_tile(const f32x16& acc, XOp& out, const
 // density head on finished enc_shape accumulators (bias included): this lane's share of w_sigma . y
 __device__ __forceinline__ float sigma_partial(const f32x16 (&acc)[8], const float* __restrict__ wsig, int h) {
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    // the weight vectors of tile t+1 are requested before tile t's arithmetic (order pinned): one LDS round trip in flight per tile
+    // instead of 32 waited for one after the other with the matrix pipe idle
+    f32x4 wc[4], wn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wc[j] = *reinterpret_cast<const f32x4*>(wsig + 8 * j + 4 * h);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
+        if (t + 1 < 8) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(wsig + 32 * t + 8 * j + 4 * h);
-            d0 = fmaf(wv[0], acc[t][4 * j + 0], d0); d1 = fmaf(wv[1], acc[t][4 * j + 1], d1);
-            d2 = fmaf(wv[2], acc[t][4 * j + 2], d2); d3 = fmaf(wv[3], acc[t][4 * j + 3], d3);
+            for (int j = 0; j < 4; ++j) wn[j] = *reinterpret_cast<const f32x4*>(wsig + 32 * (t + 1) + 8 * j + 4 * h);
         }
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            d0 = fmaf(wc[j][0], acc[t][4 * j + 0], d0); d1 = fmaf(wc[j][1], acc[t][4 * j + 1], d1);
+            d2 = fmaf(wc[j][2], acc[t][4 * j + 2], d2); d3 = fmaf(wc[j][3], acc[t][4 * j + 3], d3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wc[j] = wn[j];
     }
     return (d0 + d1) + (d2 + d3);
 }
@@ -441,10 +452,18 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
             sc[3 + q] = sn; sc[3 + 3 * XYZ_FREQ + q] = cs;
         }
         if (h == 0) { sc[0] = px; sc[1] = py; sc[2] = pz; sc[63] = 0.f; }
+        {   // all 32 scratch reads first, then the conversions (order pinned: the compiler otherwise waits for every read on its own)
+            float pv[32];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) split_store(sc[16 * s + 8 * (j >> 2) + 4 * h + (j & 3)], x[s], j);
+                for (int j = 0; j < 8; ++j) pv[8 * s + j] = sc[16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) split_store(pv[8 * s + j], x[s], j);
+        }
 #pragma unroll 1
         for (int i = 0; i < 6; ++i) {
             const int q = 6 * h + i;
@@ -457,11 +476,17 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
 #pragma unroll
             for (int f = D_DIR; f < 32; ++f) sc[f] = 0.f;
         }
+        float dvv[16];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dvv[8 * s + j] = sc[16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             XOp d;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) split_store(sc[16 * s + 8 * (j >> 2) + 4 * h + (j & 3)], d, j);
+            for (int j = 0; j < 8; ++j) split_store(dvv[8 * s + j], d, j);
             *reinterpret_cast<bf16x8*>(xdir + s * 2048) = d.hi;
             *reinterpret_cast<bf16x8*>(xdir + s * 2048 + 1024) = d.lo;
         }
@@ -539,14 +564,24 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
             const long long gpd = tile128 * 128 + wave * 32 + p_t;
             if (gpd < io.n_points) hdump = io.act + ((long long)(li_last + 1) * io.n_points + gpd) * 256 + 4 * h_t;
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
+        // (the 12 weight vectors of tile t+1 requested before tile t's arithmetic, order pinned: see sigma_partial)
+        f32x4 wc[12], wn[12];
+        auto request = [&](f32x4 (&w)[12], int t) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n0 = 32 * t + 8 * j + 4 * h_t;
-                const f32x4 wr = *reinterpret_cast<const f32x4*>(w2 + n0);
-                const f32x4 wg = *reinterpret_cast<const f32x4*>(w2 + 128 + n0);
-                const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + n0);
+                w[3 * j] = *reinterpret_cast<const f32x4*>(w2 + n0);
+                w[3 * j + 1] = *reinterpret_cast<const f32x4*>(w2 + 128 + n0);
+                w[3 * j + 2] = *reinterpret_cast<const f32x4*>(w2 + 256 + n0);
+            }
+        };
+        request(wc, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t + 1 < 4) request(wn, t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
                 f32x4 dv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -554,10 +589,14 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
                     if (MASKS && v > 0.f) mk[t >> 1] |= 1u << ((t & 1) * 16 + 4 * j + e);
                     v = fmaxf(v, 0.f);
                     dv[e] = v;
-                    pr = fmaf(wr[e], v, pr); pg = fmaf(wg[e], v, pg); pb = fmaf(wb[e], v, pb);
+                    pr = fmaf(wc[3 * j][e], v, pr); pg = fmaf(wc[3 * j + 1][e], v, pg); pb = fmaf(wc[3 * j + 2][e], v, pb);
                 }
                 if (DUMP) { if (hdump) *reinterpret_cast<f32x4*>(hdump + 32 * t + 8 * j) = dv; }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) wc[i] = wn[i];
+        }
         if (MASKS && tile_live) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane_t] = make_uint4(mk[0], mk[1], 0u, 0u);
     }
     const float cr = sum_halves(pr) + vec[VEC_MISC + 4];
