@@ -17,6 +17,14 @@
 
 namespace snr {
 
+#ifdef SNR_STAMPS   /* diagnostic build (tools/build_diag.sh): lane 0 of every live wave tile writes s_memtime at phase boundaries into the d_t buffer
+                       (same slots as the split-bf16 backward: tools/stamps.py prints them) */
+#define SNR32_BSTAMP(i) do { if (io.d_t && lane == 0 && tile_live) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        reinterpret_cast<unsigned long long*>(io.d_t)[tile32 * 16 + (i)] = t_; } } while (0)
+#else
+#define SNR32_BSTAMP(i) do {} while (0)
+#endif
+
 // accumulators -> operand registers with the saved ReLU bits applied (has_mask == false: pass through);
 // `add` (nullable, wave-uniform) is a per-feature vector scaled by `scale` added first (density-head path).
 // Between two layers the matrix pipe waits for this, so the common case is 3 VALU instructions per value: read, one v_bfe_i32 that
@@ -120,6 +128,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     chunk_dma(pipe.next, lds, 256, tid);
     pipe.next += 256 * KC;
 
+    SNR32_BSTAMP(0);
     // ---- this lane's point and its upstream gradient
     float x, y, z, dx, dy, dz, tval = 0.f, zc = 0.f;
     long long ray = 0;
@@ -187,6 +196,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     f32x16 acc[9];
     float gdir[16];
 
+    SNR32_BSTAMP(1);
     // ---- colour head backward: g_h = W2^T d_rgb, masked by rgb.0's ReLU
     {
         const uint4 mk = io.masks[(tile32m * n_relu + (n_relu - 1)) * 64 + lane];
@@ -212,6 +222,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    SNR32_BSTAMP(2);
     // ---- rgb.0^T : 128 -> 256   (the first boundary's ReLU bits, layer li_last's, are requested before its four chunks)
     uint4 mk_next = io.masks[(tile32m * n_relu + relu_slot(li_last, sb)) * 64 + lane];
     auto rows_of = [&](int li) { return li == li_view ? K_VIEW_PAD : (li == 0 ? K_XYZ_PAD : 256); };
@@ -220,6 +231,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     step<8, 9>(acc, in[2], pipe, lds, 256, tid);
     step<8, 9>(acc, in[3], pipe, lds, rows_of(li_last), tid);
 
+    SNR32_BSTAMP(3);
     // ---- 256-wide layers in reverse: texture .., enc_viewdir, enc_shape, shape ..
 #pragma unroll 1
     for (int li = li_last; li >= 1; --li) {
@@ -231,15 +243,27 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
         // a load at the boundary itself would expose a memory round trip with the matrix pipe idle
         mk_next = io.masks[(tile32m * n_relu + (li - 1 >= 1 ? relu_slot(li - 1, sb) : 0)   /* (enc_shape: a valid slot, not applied) */) * 64 + lane];
         if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)li * io.n_points + gp) * 256, h);
-        const int rows = rows_of(li), rows_after = rows_of(li - 1);
-        step<8, 9, true>(acc, in[0], pipe, lds, rows, tid, is_view);
-        step<8, 9>(acc, in[1], pipe, lds, rows, tid, is_view);
-        step<8, 9>(acc, in[2], pipe, lds, rows, tid, is_view);
-        step<8, 9>(acc, in[3], pipe, lds, rows, tid, is_view);
-        step<8, 9>(acc, in[4], pipe, lds, rows, tid, is_view);
-        step<8, 9>(acc, in[5], pipe, lds, rows, tid, is_view);
-        step<8, 9>(acc, in[6], pipe, lds, rows, tid, is_view);
-        step<8, 9>(acc, in[7], pipe, lds, rows_after, tid, is_view);
+        const int rows_after = rows_of(li - 1);
+        if (is_view) {      // two instances of the layer body, each with compile-time chunk heights and tile count: a run-time "ninth tile?" /
+                            // "how many DMA pieces?" inside every chunk costs scalar branches that nothing overlaps (one wave per SIMD)
+            step<8, 9, true>(acc, in[0], pipe, lds, K_VIEW_PAD, tid, true);
+            step<8, 9>(acc, in[1], pipe, lds, K_VIEW_PAD, tid, true);
+            step<8, 9>(acc, in[2], pipe, lds, K_VIEW_PAD, tid, true);
+            step<8, 9>(acc, in[3], pipe, lds, K_VIEW_PAD, tid, true);
+            step<8, 9>(acc, in[4], pipe, lds, K_VIEW_PAD, tid, true);
+            step<8, 9>(acc, in[5], pipe, lds, K_VIEW_PAD, tid, true);
+            step<8, 9>(acc, in[6], pipe, lds, K_VIEW_PAD, tid, true);
+            step<8, 9>(acc, in[7], pipe, lds, rows_after, tid, true);
+        } else {
+            step<8, 9, true>(acc, in[0], pipe, lds, 256, tid, false);
+            step<8, 9>(acc, in[1], pipe, lds, 256, tid, false);
+            step<8, 9>(acc, in[2], pipe, lds, 256, tid, false);
+            step<8, 9>(acc, in[3], pipe, lds, 256, tid, false);
+            step<8, 9>(acc, in[4], pipe, lds, 256, tid, false);
+            step<8, 9>(acc, in[5], pipe, lds, 256, tid, false);
+            step<8, 9>(acc, in[6], pipe, lds, 256, tid, false);
+            step<8, 9>(acc, in[7], pipe, lds, rows_after, tid, false);
+        }
         // acc = gradient wrt the INPUT of layer li = previous output + latent term
         const int la = latent_after(li - 1, sb, tb);
         if (la >= 0 && io.partial && tile_live) reduce_points_store(acc, io.partial + (tile32 * L.n_lat + la) * 256, lane);
@@ -247,8 +271,10 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) gdir[r] = acc[8][r];
         }
+        if (li_last - li < 6) SNR32_BSTAMP(4 + (li_last - li));
     }
 
+    SNR32_BSTAMP(11);
     // ---- enc_xyz^T : 256 -> 64 positional-encoding features
     masked_to_operand<8>(acc, in, true, mk_next, nullptr, 0.f, h);
     if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)0 * io.n_points + gp) * 256, h);
@@ -261,6 +287,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     step<2, 9>(acc, in[6], pipe, lds, 64, tid);
     step<2, 9>(acc, in[7], pipe, lds, 0, tid);
 
+    SNR32_BSTAMP(12);
     // ---- positional-encoding backward through the per-wave scratch rows
     float* sc = lds + LDS_SCRATCH + wave * PE_WAVE + p * PE_ROW;
 #pragma unroll
@@ -326,7 +353,10 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
 #pragma unroll
             for (int i = 0; i < 6; ++i) c[i] = 0.f;
         }
+        SNR32_BSTAMP(13);
+#ifndef SNR_STAMPS
         if (io.d_t && live && h == 0) io.d_t[gp] = dt;
+#endif
         if (io.d_rays_o || io.d_rays_d) {
             const int S = g.S;
             const int G = S < 32 ? S : 32;      // lanes of this wave that share a ray (S divides 128)

@@ -25,7 +25,8 @@ with torch.no_grad():
 pk = model.packed_weights()
 div = torch.full((1,), float(ob["obj_diag"]), device=dev)
 ro, vd = ro.contiguous(), vd.contiguous()
-a = ops._render_args(ro, vd, z, div, None, lat, pk, U._frame(False, False, True), 1.0, ops.Z_SHARED, 0, N, S, 3, 1, 1,
+PREC = int(os.environ.get("SNR_STAMP_PRECISION", "1"))        # 1 = bf16x3 (default), 0 = fp32 (backward timeline only: the fp32 forward's is tools/clock32.py)
+a = ops._render_args(ro, vd, z, div, None, lat, pk, U._frame(False, False, True), 1.0, ops.Z_SHARED, 0, N, S, 3, 1, PREC,
                      latent_bias=model.latent_biases(lat))
 rgb = torch.empty(N, 3, device=dev); depth = torch.empty(N, device=dev); acc = torch.empty(N, device=dev)
 dbg = torch.zeros(N * S, device=dev)               # "sigmas" buffer receives the stamps: 16 x u64 per wave tile
