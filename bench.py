@@ -358,7 +358,7 @@ def main():
                      "hip_graph_auto": {"ms_per_iteration": t_g / n_it1 * 1e3, "object_iterations_per_s": n_it1 / t_g},
                      "iterations": n_it1, "rays_per_object": N_RAYS,
                      "note": "iteration = forward + backward (codes, pose) + 64-pixel depth render + metric row + AdamW at 4096 x 64; fused_eager = driver.optimize_object "
-                             "(~30 launches per iteration, no graph); api_structured = the same loop on the public functions, call for call like the reference (~350 launches); "
+                             "(~24 launches per iteration, no graph); api_structured = the same loop on the public functions, call for call like the reference (~350 launches); "
                              "hip_graph = the torch-op iteration recorded once and replayed; set-up (and recording) included everywhere"})
     extra["optimise_loop"] = loop
 
