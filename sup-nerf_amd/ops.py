@@ -470,6 +470,13 @@ class DecoderPointsTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, viewdir, latent, shape_blocks, texture_blocks, precision, *weights):
         xyz, viewdir, latent = _f32c(xyz), _f32c(viewdir), _f32c(latent)
+        # ragged point counts per object: padded to whole wave tiles with dummy points like DecoderPoints (zero upstream gradient, so they add
+        # nothing to any weight gradient either)
+        B, P0 = max(latent.shape[0], 1), xyz.shape[0]
+        n_pad = _tile_pad(P0 // B) if (shape_blocks + texture_blocks > 0 and P0 % B == 0 and P0 > 0) else 0
+        ctx.pad = (B, P0 // B, n_pad)
+        if n_pad:
+            xyz, viewdir = _pad_rows(xyz, B, P0 // B, n_pad), _pad_rows(viewdir, B, P0 // B, n_pad)
         # one arithmetic for the whole step: the forward / backward layer chains and the weight-gradient products
         prec = resolve_precision(precision, shape_blocks, texture_blocks, xyz.shape[0] // max(latent.shape[0], 1))
         wgrad_precision = "bf16x3" if prec == BF16X3 else "fp32"
@@ -482,6 +489,8 @@ class DecoderPointsTrain(torch.autograd.Function):
                                       activations=act)
         ctx.save_for_backward(xyz, viewdir, latent, packed, masks, sig, act, *weights)
         ctx.cfg = (shape_blocks, texture_blocks, wgrad_precision, prec)
+        if n_pad:
+            return _unpad_rows(sig, B, P0 // B, n_pad), _unpad_rows(rgb, B, P0 // B, n_pad)
         return sig, rgb
 
     @staticmethod
@@ -492,6 +501,9 @@ class DecoderPointsTrain(torch.autograd.Function):
         n_slots = sb + tb + 4
         G = torch.empty(n_slots, P, 256, device=dev)
         d_sig, d_rgb = _f32c(d_sig), _f32c(d_rgb)
+        B_, n_, n_pad = ctx.pad
+        if n_pad:
+            d_sig, d_rgb = _pad_rows(d_sig, B_, n_, n_pad), _pad_rows(d_rgb, B_, n_, n_pad)
         d_lat, d_xyz, d_dir = decoder_bwd(xyz, viewdir, latent, packed, masks, sig, d_sig, d_rgb, sb, tb,
                                           ctx.needs_input_grad[2], ctx.needs_input_grad[0], ctx.needs_input_grad[1], precision=prec,
                                           layer_grads=G)
@@ -528,6 +540,8 @@ class DecoderPointsTrain(torch.autograd.Function):
                 out += [d_rgb2_w, d_rgb2_b]
             else:
                 out += list(by_layer[k])
+        if n_pad:
+            d_xyz, d_dir = _unpad_rows(d_xyz, B_, n_, n_pad), _unpad_rows(d_dir, B_, n_, n_pad)
         return (d_xyz, d_dir, d_lat, None, None, None, *out)
 
 

@@ -414,6 +414,41 @@ def test_training_step_weight_gradients(amd, dev, oracle_params, golden, precisi
     print(f"[training gradients vs the reference, {precision}] worst relative entry error {worst:.2e}")
 
 
+def test_training_step_ragged_points_per_object(amd, dev, oracle_params):
+    """Training mode with a point count per object that is no multiple of the 32-point wave tile (2 objects x 5 rays x 7 samples): every
+    decoder weight gradient and the code gradients against the oracle's autograd (exact fp32 kernels; the operator pads with dummy
+    points that must not contribute to any gradient)."""
+    B, n, S = 2, 5, 7
+    gen = torch.Generator().manual_seed(41)
+    xyz = torch.rand(B * n, S, 3, generator=gen) - 0.5
+    vd = torch.randn(B * n, S, 3, generator=gen); vd = vd / vd.norm(dim=-1, keepdim=True)
+    sc = (torch.randn(B, 256, generator=gen) * 0.3).requires_grad_()
+    tc = (torch.randn(B, 256, generator=gen) * 0.3).requires_grad_()
+    ws, wr = torch.randn(B * n, S, 1, generator=gen), torch.randn(B * n, S, 3, generator=gen)
+    params = {k: v.clone().requires_grad_() for k, v in oracle_params.items()}
+    sig_o, rgb_o = O.decoder_forward(params, xyz, vd, sc, tc)
+    ((sig_o * ws).sum() + (rgb_o * wr).sum()).backward()
+    m = amd.CodeNeRF(shape_blocks=3, texture_blocks=1)
+    m.load_state_dict(oracle_params, strict=True)
+    m.precision = "fp32"
+    m = m.to(dev)
+    m.train_decoder_weights = True
+    sc_d, tc_d = sc.detach().to(dev).requires_grad_(), tc.detach().to(dev).requires_grad_()
+    sig, rgb = m(xyz.to(dev), vd.to(dev), sc_d, tc_d)
+    assert sig.shape == sig_o.shape and md(sig, sig_o) < 2e-5 and md(rgb, rgb_o) < 2e-5
+    ((sig * ws.to(dev)).sum() + (rgb * wr.to(dev)).sum()).backward()
+    assert close_grad(sc_d.grad, sc.grad) and close_grad(tc_d.grad, tc.grad)
+    checked = 0
+    for name, p in m.named_parameters():
+        ref = params.get(name)
+        if ref is None or ref.grad is None:
+            continue
+        assert p.grad is not None, name
+        assert close_grad(p.grad, ref.grad, rel=5e-4), (name, md(p.grad, ref.grad), float(ref.grad.abs().max()))
+        checked += 1
+    assert checked >= 20, checked
+
+
 def test_renderer_twins(amd, dev, model, oracle_params, golden, jitter):
     """NeRFRenderer's other methods (src/renderer.py:27-115,169-352) and the small utilities of src/utils.py on the GPU against the
     reference's outputs (fixture `twins`)."""
