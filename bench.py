@@ -62,6 +62,25 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+_JSON_OUT = None
+
+
+def claim_stdout():
+    """stdout must carry exactly ONE line, the JSON; RCCL prints a version banner on fd 1 when the first communicator is made, and other
+    libraries may chat there too.  So fd 1 is pointed at stderr for the whole run and the JSON line goes to a saved copy of the real stdout."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    out = _JSON_OUT if _JSON_OUT is not None else sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def profile_traffic(precision, which="fwd"):
     """HBM bytes per launch of the dominant kernel from the newest committed counter profile of this kernel (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes; FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md).  The counters cannot be collected from
@@ -192,6 +211,7 @@ def main():
                     help="c2: fused forward of one object per GPU (BASELINE configs[1], weak scaling); c3: the optimise iteration over 64 objects "
                          "sharded across the GPUs (BASELINE configs[2], strong scaling)")
     args = ap.parse_args()
+    claim_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -206,7 +226,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SNR_BENCH_FORCE_DIST"):      # (FORCE_DIST: exercise the RCCL set-up with a single rank)
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
@@ -232,7 +252,7 @@ def main():
                           "objects": C3_OBJECTS, "objects_this_rank": n_mine, "precision": prec},
                "object_iterations_per_s": C3_OBJECTS * n_it / dt, "metric_rows_finite": bool(torch.isfinite(rows).all())}
         if rank == 0:
-            print(json.dumps(res), flush=True)
+            emit(res)
         if dist is not None:
             dist.barrier(); dist.destroy_process_group()
         return
@@ -273,7 +293,7 @@ def main():
     }
     if args.headline_only:
         if rank == 0:
-            print(json.dumps(result), flush=True)
+            emit(result)
         if dist is not None:
             dist.barrier(); dist.destroy_process_group()
         return
@@ -472,7 +492,7 @@ def main():
         result["parity"] = parity(prec)
         result[other]["parity"] = parity(other)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
