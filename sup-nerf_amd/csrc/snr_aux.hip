@@ -329,8 +329,11 @@ __global__ void __launch_bounds__(256) scene_general_kernel(const float* __restr
 // NaN with a payload in rgb[3 pix] (a pixel whose true result carries those bits is recomputed to the same value).  Keeping the general
 // code out of this kernel keeps it at 4 waves per SIMD without spills; the next pixel's 5 x 4 values per lane are requested one pixel ahead
 // so that the memory latency is off the per-pixel chain LDS -> search -> scatter -> composite.
+#ifndef SCENE_FAST_WAVES
+#define SCENE_FAST_WAVES 6
+#endif
 template <int RUN>
-__global__ void __launch_bounds__(256) scene_fast_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ zv,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SCENE_FAST_WAVES, 8))) scene_fast_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ zv,
                                                          long long n_pixels, int n, int flags, float* __restrict__ rgb, float* __restrict__ depth,
                                                          float* __restrict__ acc) {
     extern __shared__ __attribute__((aligned(16))) float scene_lds[];
