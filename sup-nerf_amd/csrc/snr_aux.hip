@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) scene_general_kernel(const float* __restr
 // Pixels whose n <= 256 samples are lists of 32 / 64 / 128 ascending depths without equal depths inside or across increasing lists (all
 // but ~0.1 % of pixels): ranks by scene_merge_fast, scatter, composite.  Any other pixel is left to scene_general_kernel<true>, marked by a
 // NaN with a payload in rgb[3 pix] (a pixel whose true result carries those bits is recomputed to the same value).  Keeping the general
-// code out of this kernel keeps it at 4 waves per SIMD without spills; the next pixel's 5 x 4 values per lane are requested one pixel ahead
+// code out of this kernel keeps its registers low (6 waves per SIMD); the next pixel's 5 x 4 values per lane are requested one pixel ahead
 // so that the memory latency is off the per-pixel chain LDS -> search -> scatter -> composite.
 #ifndef SCENE_FAST_WAVES
 #define SCENE_FAST_WAVES 6
