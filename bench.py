@@ -2,7 +2,8 @@
 """bench.py -- rays/s of the fused render hot path at BASELINE.json's configuration.
 
     python bench.py --gpus N --steps K --warmup W                 (driver contract; --precision fp32 | bf16x3, --workload c2 | c3)
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    (N > 1: one rank per GPU, either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` or --
+     when WORLD_SIZE is not set -- by bench.py itself, which starts exactly that command as a child and relays rank 0's line)
 
 Default workload (BASELINE configs[1], "c2"): one *step* = one fused forward pass (sample -> frame transform -> positional encoding ->
 decoder -> composite) over one object's ray batch, 4096 rays x 64 samples (supnerf.nusc.vehicle.car.json hyper-parameters, im_sz 64,
@@ -79,6 +80,31 @@ def emit(obj):
     out = _JSON_OUT if _JSON_OUT is not None else sys.stdout
     out.write(json.dumps(obj) + "\n")
     out.flush()
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks the way the driver's multi-GPU command does
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...) as CHILD
+    processes and relay rank 0's JSON line.  This process never initialises the GPU (no torch.cuda call has happened yet) and never
+    execs: the children are fresh interpreters."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                     # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n_gpus} without WORLD_SIZE: launching {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    if proc.returncode == 0 and not lines:
+        print("[bench] the ranks exited cleanly but printed no JSON line", file=sys.stderr)
+        return 1
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return proc.returncode
 
 
 def profile_traffic(precision, which="fwd"):
@@ -211,14 +237,16 @@ def main():
                     help="c2: fused forward of one object per GPU (BASELINE configs[1], weak scaling); c3: the optimise iteration over 64 objects "
                          "sharded across the GPUs (BASELINE configs[2], strong scaling)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))            # (before anything touches the GPU: the ranks are fresh child processes)
     claim_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         "(python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # SNR_BENCH_BACKEND=gloo: rehearsal of the N > 1 branch on a box with fewer GPUs than ranks (ranks share the cards; the numbers mean nothing)
     backend = os.environ.get("SNR_BENCH_BACKEND", "nccl")
@@ -340,15 +368,64 @@ def main():
             loss, _ = ops.LossTail.apply(out[0], out[2], out[3], out[4], 0.1, N_RAYS)
             sc_g.grad = tc_g.grad = pose_g.grad = None
             loss.sum().backward()
+        # family B: NeRFRenderer.render_rays (src/renderer.py:117-166; its defaults ARE 4096 rays x 64 samples) -- box bounds, per-ray
+        # depths and the in-kernel jitter in the fused launch's prologue
+        rend = A.NeRFRenderer(n_samples=N_SAMPLES, white_bkgd=True)
+
+        def b_fwd():
+            with torch.no_grad():
+                return rend.render_rays(model, dev, w["img"], w["mask"], pose_g, ob["wlh"], ob["K"], ob["roi"], sc_g, tc_g, im_sz=IM_SZ)
+
+        def b_fwd_bwd():
+            out = rend.render_rays(model, dev, w["img"], w["mask"], pose_g, ob["wlh"], ob["K"], ob["roi"], sc_g, tc_g, im_sz=IM_SZ)
+            loss, _ = ops.LossTail.apply(out[0], out[2], out[3], out[4], 0.1, N_RAYS)
+            sc_g.grad = tc_g.grad = pose_g.grad = None
+            loss.sum().backward()
         n = max(20, args.steps // 4)
         t_f = clock.wall(fwd, n, 3)
         t_fb = clock.wall(fwd_bwd, n, 3)
+        t_bf = clock.wall(b_fwd, n, 3)
+        t_bfb = clock.wall(b_fwd_bwd, n, 3)
         return {"render_rays_v2_fwd_rays_per_s": world * N_RAYS * n / t_f, "render_rays_v2_fwd_ms": t_f / n * 1e3,
-                "render_rays_v2_fwd_bwd_rays_per_s": world * N_RAYS * n / t_fb, "render_rays_v2_fwd_bwd_ms": t_fb / n * 1e3, "calls": n}
+                "render_rays_v2_fwd_bwd_rays_per_s": world * N_RAYS * n / t_fb, "render_rays_v2_fwd_bwd_ms": t_fb / n * 1e3,
+                "nerf_renderer_render_rays_fwd_rays_per_s": world * N_RAYS * n / t_bf, "nerf_renderer_render_rays_fwd_ms": t_bf / n * 1e3,
+                "nerf_renderer_render_rays_fwd_bwd_rays_per_s": world * N_RAYS * n / t_bfb, "nerf_renderer_render_rays_fwd_bwd_ms": t_bfb / n * 1e3,
+                "calls": n}
     extra["api"] = {p: api_leg(p) for p in (prec, other)}
-    extra["api"]["note"] = ("utils.render_rays_v2 with the reference's signature, every call: ray generation from the pose, bilinear target resize "
-                            "on the host + upload, depth vector, per-object latent layers, fused render; fwd_bwd adds the loss tail and the backward to both "
-                            "codes and the camera pose")
+    extra["api"]["note"] = ("utils.render_rays_v2 / NeRFRenderer.render_rays with the reference's signatures, every call: ray generation from the pose, "
+                            "(cached) target resize, depths (family A: one shared vector; family B: box bounds + per-ray stratified depths + jitter inside "
+                            "the fused launch), per-object latent layers, fused render; fwd_bwd adds the loss tail and the backward to both codes and the "
+                            "camera pose (family B: also through the box bounds)")
+
+    log("family B fused kernels (box bounds in the prologue)")
+    # ---- family B at the kernel level: the same launches as the headline with SNR_Z_BOX sampling (slab test, per-ray depths, Philox
+    # jitter, metric z, white background), device events; roofline like the headline's (same FLOPs per ray)
+    def box_leg(p):
+        from supnerf_amd import renderer as R
+        _, half, zs = R._box_constants(ob["wlh"], 1, dev)
+        cfg_b = ops.RenderCfg(N_SAMPLES, ops.Z_BOX, N_RAYS, 3, 1, frame=U._frame(False, False, False), white_bkgd=True, metric_z=True,
+                              precision=p, box_half=half)
+        cfg_b.latent_bias = cfgs[p].latent_bias
+        ro_raw = rays_o.contiguous()
+        f = lambda: ops.render_fwd(ro_raw, viewdir, None, None, zs, lat, packed, cfg_b)
+        for _ in range(5):
+            f()
+        n = max(20, args.steps // 4)
+        ms_f = clock.events(f, n)
+        fw = ops.render_fwd(ro_raw, viewdir, None, None, zs, lat, packed, cfg_b, save_for_bwd=True)
+        d_rgb, d_depth, d_acc = torch.rand_like(fw[0]), torch.rand_like(fw[1]), torch.rand_like(fw[2])
+        b = lambda: ops.render_bwd(ro_raw, viewdir, None, None, zs, lat, packed, cfg_b, fw[3], fw[4], fw[5], d_rgb, d_depth, d_acc)
+        for _ in range(5):
+            b()
+        ms_b = clock.events(b, n)
+        hit_frac = float((fw[2] < 0.999).float().mean())
+        return {"fwd_kernel_ms": ms_f, "fwd_rays_per_s": N_RAYS / (ms_f * 1e-3), "fwd_frac_of_peak": N_RAYS * FLOP_PER_RAY / (ms_f * 1e-3) / 1e12 / PEAK_TFLOPS[p],
+                "bwd_kernel_ms": ms_b, "bwd_frac_of_peak": N_RAYS * FLOP_PER_RAY / (ms_b * 1e-3) / 1e12 / PEAK_TFLOPS[p],
+                "rays_with_opacity": hit_frac}
+    extra["family_b_fused"] = {p: box_leg(p) for p in (prec, other)}
+    extra["family_b_fused"]["note"] = ("ops.render_fwd / render_bwd with z_mode SNR_Z_BOX at 4096 x 64: the slab test, hit / miss bounds, per-ray stratified depths, "
+                                       "in-kernel Philox jitter (torch.rand_like's stream) and metric depth run in the prologue of the same kernels as the headline; "
+                                       "the backward also returns the gradient through the box bounds")
     model.precision = "auto"
 
     log("one-object optimise loops")
@@ -383,39 +460,48 @@ def main():
     extra["optimise_loop"] = loop
 
     log("config 3: 64 objects sharded")
-    # ---- BASELINE config 3 through the driver: 64 objects sharded over the ranks, one all_gather at the end
-    model.precision = "auto"
+    # ---- BASELINE config 3 through the driver: 64 objects sharded over the ranks, one all_gather at the end; the library's default
+    # arithmetic, then the reference's
     n_it3 = 8
-    dt3, rows3, n_mine = c3_leg(model, dev, rank, world, dist, clock, n_it3)
-    extra["c3_sharded"] = {"objects": C3_OBJECTS, "objects_this_rank": n_mine, "iterations": n_it3, "seconds": dt3,
-                           "ms_per_iteration": dt3 / n_it3 * 1e3, "object_iterations_per_s": C3_OBJECTS * n_it3 / dt3,
-                           "rays_per_s_fwd_bwd_plus_depth_render": C3_OBJECTS * n_it3 * N_RAYS / dt3, "precision": "auto (bf16x3)",
-                           "metric_rows_finite": bool(torch.isfinite(rows3).all()),
-                           "note": "strong scaling of BASELINE configs[2]: the 64 objects are fixed, each rank optimises its contiguous slice in one launch per "
-                                   "iteration; includes the per-object host set-up and the final all_gather of the metric rows (RCCL)"}
+    for p3, key in (("auto", "c3_sharded"), ("fp32", "c3_sharded_fp32")):
+        model.precision = p3
+        dt3, rows3, n_mine = c3_leg(model, dev, rank, world, dist, clock, n_it3 if p3 == "auto" else 4)
+        it3 = n_it3 if p3 == "auto" else 4
+        extra[key] = {"objects": C3_OBJECTS, "objects_this_rank": n_mine, "iterations": it3, "seconds": dt3,
+                      "ms_per_iteration": dt3 / it3 * 1e3, "object_iterations_per_s": C3_OBJECTS * it3 / dt3,
+                      "rays_per_s_fwd_bwd_plus_depth_render": C3_OBJECTS * it3 * N_RAYS / dt3,
+                      "precision": "auto (bf16x3)" if p3 == "auto" else "fp32", "metric_rows_finite": bool(torch.isfinite(rows3).all()),
+                      "note": "strong scaling of BASELINE configs[2]: the 64 objects are fixed, each rank optimises its contiguous slice in one launch per "
+                              "iteration; includes the per-object host set-up and the final all_gather of the metric rows (RCCL)"}
+    model.precision = "auto"
 
     log("training step")
-    # ---- BASELINE config 5's per-GPU step: decoder + codes trained (weak scaling across ranks; the gradient bucket is all-reduced)
-    if True:
-        from supnerf_amd import trainer as T
-        Bt, nt = 8, 1024
+    # ---- BASELINE config 5's per-GPU step: decoder + codes trained (weak scaling across ranks; the gradient bucket is all-reduced), in the
+    # reference's arithmetic (exact fp32 chains and weight-gradient products) and in split-bf16
+    from supnerf_amd import trainer as T
+    Bt, nt = 8, 1024
+    gt = torch.Generator().manual_seed(rank)
+    batch = dict(code_idx=torch.arange(Bt), xyz=torch.rand(Bt, nt, N_SAMPLES, 3, generator=gt) - 0.5,
+                 viewdir=torch.nn.functional.normalize(torch.randn(Bt, nt, 1, 3, generator=gt), dim=-1).repeat(1, 1, N_SAMPLES, 1),
+                 z_vals=torch.sort(torch.rand(Bt, N_SAMPLES, generator=gt) * 4 + 9, dim=-1)[0], rgb_tgt=torch.rand(Bt, nt, 3, generator=gt),
+                 occ_pixels=(torch.randint(0, 3, (Bt, nt, 1), generator=gt) - 1).float())
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    hp_t = dict(lr_schedule=[dict(lr=1e-4, interval=40000), dict(lr=1e-4, interval=40000)])
+    extra["training_step"] = {}
+    for p_t in ("fp32", "bf16x3"):
         m_t = A.CodeNeRF(3, 1); m_t.load_state_dict(w["params"]); m_t = m_t.to(dev); m_t.train_decoder_weights = True
+        m_t.precision = p_t
         codes = T.CodeTables(64, 256, seed=1).to(dev)
-        gt = torch.Generator().manual_seed(rank)
-        batch = dict(code_idx=torch.arange(Bt), xyz=torch.rand(Bt, nt, N_SAMPLES, 3, generator=gt) - 0.5,
-                     viewdir=torch.nn.functional.normalize(torch.randn(Bt, nt, 1, 3, generator=gt), dim=-1).repeat(1, 1, N_SAMPLES, 1),
-                     z_vals=torch.sort(torch.rand(Bt, N_SAMPLES, generator=gt) * 4 + 9, dim=-1)[0], rgb_tgt=torch.rand(Bt, nt, 3, generator=gt),
-                     occ_pixels=(torch.randint(0, 3, (Bt, nt, 1), generator=gt) - 1).float())
-        batch = {k: v.to(dev) for k, v in batch.items()}
-        hp_t = dict(lr_schedule=[dict(lr=1e-4, interval=40000), dict(lr=1e-4, interval=40000)])
         bucket = T.GradBucket(list(m_t.parameters()) + list(codes.parameters()))
         opt_t = T.make_optimizer(m_t, codes, hp_t)
         n_t = 10
         t_t = clock.wall(lambda: T.train_step(m_t, codes, opt_t, bucket, batch, 0.1), n_t, 3)
-        extra["training_step"] = {"ms_per_step": t_t / n_t * 1e3, "rays_per_s": world * Bt * nt * n_t / t_t, "objects_per_gpu": Bt, "rays_per_object": nt,
-                                  "samples": N_SAMPLES, "steps": n_t, "dtype": "f32",
-                                  "note": "trainer.train_step: forward + backward incl. every decoder weight gradient + one all-reduce of the flat gradient bucket + AdamW"}
-        del m_t, codes, batch, bucket, opt_t
+        extra["training_step"][p_t] = {"ms_per_step": t_t / n_t * 1e3, "rays_per_s": world * Bt * nt * n_t / t_t, "objects_per_gpu": Bt, "rays_per_object": nt,
+                                       "samples": N_SAMPLES, "steps": n_t, "dtype": DTYPE[p_t], "model_precision": m_t.precision}
+        del m_t, codes, bucket, opt_t
+    extra["training_step"]["note"] = ("trainer.train_step: forward + backward incl. every decoder weight gradient + one all-reduce of the flat gradient bucket + AdamW; "
+                                      "`fp32` = the reference's arithmetic (trainer default), `bf16x3` = split-bf16 chains and weight-gradient products")
+    del batch
 
     log("HBM-bound kernels")
     # ---- the HBM-bound stand-alone kernels (encode with PE output, composite, scene composite): achieved GB/s
@@ -434,9 +520,18 @@ def main():
             return clock.events(fn, n) * 1e-3
         t_enc = timed_ev(lambda: ops.encode(ro_h, vd_h, z_h, div_h, None, cfg_h, want_pe=True))
         enc_bytes = P_h * (12 + 12 + 4 + 63 * 4) + Bh * N_RAYS * (24 + 27 * 4)          # xyz, viewdir, z, PE(xyz) per point; rays in, PE(dir) out
-        sig_h = torch.rand(Bh * N_RAYS, N_SAMPLES, device=dev)
-        rgb_h = torch.rand(Bh * N_RAYS, N_SAMPLES, 3, device=dev)
-        t_cmp = timed_ev(lambda: ops.composite_fwd(sig_h, rgb_h, z_h, ops.Z_PER_OBJECT, False, N_RAYS))
+        # three input sets used in turn (3 x 268 MB): with one set, launches back to back re-read part of it from the 256 MB Infinity Cache
+        # and the figure lands above what HBM can deliver
+        sets = [(torch.rand(Bh * N_RAYS, N_SAMPLES, device=dev), torch.rand(Bh * N_RAYS, N_SAMPLES, 3, device=dev)) for _ in range(3)]
+        turn = [0]
+
+        def cmp_once():
+            sg_, rg_ = sets[turn[0] % 3]
+            turn[0] += 1
+            return ops.composite_fwd(sg_, rg_, z_h, ops.Z_PER_OBJECT, False, N_RAYS)
+        t_cmp = timed_ev(cmp_once, n=12)
+        sig_h, rgb_h = sets[0]
+        del sets
         cmp_bytes = P_h * 16 + Bh * N_RAYS * 20
         # scene composite (vis_scene): 131072 pixels x 3 objects x 64 samples, depth merge + composite
         P_s, n_s = 131072, 3 * N_SAMPLES

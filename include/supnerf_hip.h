@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SNR_ABI_VERSION 5
+#define SNR_ABI_VERSION 6
 
 enum {
     SNR_OK = 0,
@@ -42,8 +42,18 @@ enum {
     SNR_E_UNSUPPORTED = -5
 };
 
-/* how per-sample depths are laid out */
-enum { SNR_Z_SHARED = 0 /* (S,) */, SNR_Z_PER_OBJECT = 1 /* (B,S) */, SNR_Z_PER_RAY = 2 /* (N,S) */ };
+/* how per-sample depths are laid out.
+ * SNR_Z_BOX: no depth table at all -- the kernel derives every ray's depths itself, the way family B does
+ * (NeRFRenderer.prepare_sampled_rays + sample_from_ray, src/renderer.py:27-41,91-115):
+ *   o_n = rays_o / z_scale[obj]                           (`rays_o / (obj_diag / 2)`, :103)
+ *   slab test of (o_n, rays_d) against the box +-box_half[obj] (ray_box_intersection_tensor, src/utils.py:283-327; NaN-propagating
+ *   min / max like torch's), near = far = -1 for rays that miss (:106-108)
+ *   u_s = s / S + jitter * (1 / S),  t_s = near (1 - u_s) + far u_s          (:33-41; S a power of two)
+ *   p = o_n + t d (xyz_div is NOT applied), composite depth |p - o_n| z_scale with SNR_METRIC_Z (:114)
+ * `t_vals` then is the (N,S) jitter in [0,1) (the reference's rand_like draw), or NULL: the kernel draws it itself with
+ * Philox4x32-10 (see rng_* below).  The backward kernel returns the gradient THROUGH the bounds to rays_o / rays_d like the
+ * reference's autograd (maximum / minimum split ties evenly, as torch does) unless SNR_BOX_DETACH is set. */
+enum { SNR_Z_SHARED = 0 /* (S,) */, SNR_Z_PER_OBJECT = 1 /* (B,S) */, SNR_Z_PER_RAY = 2 /* (N,S) */, SNR_Z_BOX = 3 /* none: box bounds */ };
 
 /* arithmetic of the decoder GEMMs.  SNR_FP32: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain.
  * SNR_BF16X3: every operand split into bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate (relative operand
@@ -55,7 +65,8 @@ int snr_precision_supported(int precision, int shape_blocks, int texture_blocks,
 /* flags for the render / composite entry points */
 enum {
     SNR_WHITE_BKGD = 1,    /* rgb += 1 - sum(w)            (src/renderer.py:60-63,374-377) */
-    SNR_METRIC_Z   = 2     /* composite depth = |t*d|*z_scale (src/renderer.py:114) instead of t */
+    SNR_METRIC_Z   = 2,    /* composite depth = |t*d|*z_scale (src/renderer.py:114) instead of t */
+    SNR_BOX_DETACH = 4     /* SNR_Z_BOX: the bounds carry no gradient (render_rays_v3 runs its slab test in numpy, src/renderer.py:425-432) */
 };
 
 int snr_abi_version(void);
@@ -147,6 +158,15 @@ typedef struct snr_render_args {
      * `shape_layer_j(y + z_j)`, src/model_supnerf.py:253-263).  With it the split-bf16 forward drops the latent add and its vector
      * loads from every epilogue (-4 %); `latent` is still what the gradient d_latent of snr_render_bwd refers to. */
     const float* latent_bias;
+    /* SNR_Z_BOX only: (B,3) half extents of every object's box in the o_n frame, (l, w, h) / diag (src/renderer.py:96-99) */
+    const float* box_half;
+    /* SNR_Z_BOX with t_vals == NULL: jitter of point i = ray * S + s is the uniform that torch.rand_like of an (N,S) tensor would
+     * hold at i for the device generator state (rng_seed, rng_offset) when its kernel runs rng_threads threads (Philox4x32-10:
+     * key = seed, counter = (offset / 4 + i / (4 rng_threads), subsequence i % rng_threads), word (i / rng_threads) % 4, value
+     * (w + 1) 2^-32 folded to [0,1)).  rng_threads == 0: counter = (offset / 4, subsequence i), word 0. */
+    uint64_t rng_seed;
+    uint64_t rng_offset;
+    uint64_t rng_threads;
 } snr_render_args;
 
 int snr_render_fwd(const snr_render_args* a, float* rgb, float* depth, float* acc_trans,
@@ -197,10 +217,11 @@ int snr_composite_bwd(const float* sigmas, const float* rgbs, const float* z_val
  * point/metric-depth part of NeRFRenderer.prepare_sampled_rays (src/renderer.py:111-114) and
  * PE (src/model_supnerf.py:155-161).  Arguments as snr_render_args; outputs
  *   xyz (N,S,3), viewdir (N,S,3), z_out (N,S) [nullable], pe_xyz (N,S,63) [nullable],
- *   pe_dir (N,27) [nullable; constant along S]
+ *   pe_dir (N,27) [nullable; constant along S], hit (N) [nullable; SNR_Z_BOX: 1 where the ray meets its box, the
+ *   `intersect` map of prepare_sampled_rays]
  * ---------------------------------------------------------------------------------- */
 int snr_encode_fwd(const snr_render_args* a, float* xyz, float* viewdir, float* z_out,
-                   float* pe_xyz, float* pe_dir, void* stream);
+                   float* pe_xyz, float* pe_dir, uint8_t* hit, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Loss / metric tail of one optimise iteration: replaces the three masked reductions the callers run right after the render

@@ -130,15 +130,46 @@ def latent_terms(params: Dict[str, Tensor], shape_code: Tensor, texture_code: Te
     return torch.stack(outs, dim=1)
 
 
+class _ReluWithGivenMask(torch.autograd.Function):
+    """relu(x) whose DERIVATIVE is a given 0/1 mask instead of [x > 0] (test infrastructure, see ``decoder_forward``)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return torch.relu(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask.to(g.dtype), None
+
+
 def decoder_forward(params: Dict[str, Tensor], xyz: Tensor, viewdir: Tensor,
                     shape_code: Tensor, texture_code: Tensor,
-                    num_xyz_freq: int = 10, num_dir_freq: int = 4) -> Tuple[Tensor, Tensor]:
+                    num_xyz_freq: int = 10, num_dir_freq: int = 4,
+                    relu_masks: Optional[Sequence[Tensor]] = None) -> Tuple[Tensor, Tensor]:
     """sigma (N,S,1), rgb (N,S,3) for xyz/viewdir (N,S,3) and codes (B,latent).
 
     Restates ``SUPNeRF.forward`` (src/model_supnerf.py:241-269) ==
     ``CodeNeRF.forward`` (src/model_codenerf.py:39-63).  Rays are object-major:
     ray r belongs to object ``r // (N // B)`` (src/model_supnerf.py:246-249).
+
+    ``relu_masks`` (tests only; None = the reference's computation): one 0/1 tensor per ReLU layer of the per-point chain in
+    forward order (encoding_xyz, shape layers, encoding_viewdir, texture layers, rgb.0), each shaped like that layer's output.
+    The forward values are unchanged; the backward of each ReLU uses the given mask as its derivative.  A hidden unit whose
+    pre-activation sits within rounding of zero lands on either side of the ReLU depending on the summation order, which moves
+    that point's gradient by percents in ANY two correct implementations; with the masks an implementation saved, the oracle
+    differentiates the same piecewise-linear function as that implementation, and the comparison can be tight.
     """
+    relu_i = [0]
+
+    def relu(t):
+        if relu_masks is None:
+            return F.relu(t)
+        m = relu_masks[relu_i[0]]
+        relu_i[0] += 1
+        return _ReluWithGivenMask.apply(t, m.reshape(t.shape))
+
     sb, tb = _count_blocks(params)
     n_ray = xyz.shape[0]
     n_obj = shape_code.shape[0]
@@ -150,18 +181,18 @@ def decoder_forward(params: Dict[str, Tensor], xyz: Tensor, viewdir: Tensor,
     def lin(name, t):
         return F.linear(t, params[name + ".weight"], params[name + ".bias"])
 
-    h = F.relu(lin("encoding_xyz.0", positional_encoding(xyz, num_xyz_freq)))
+    h = relu(lin("encoding_xyz.0", positional_encoding(xyz, num_xyz_freq)))
     for j in range(1, sb + 1):
         z = F.relu(lin(f"shape_latent_layer_{j}.0", shape_rows))
-        h = F.relu(lin(f"shape_layer_{j}.0", h + z))
+        h = relu(lin(f"shape_layer_{j}.0", h + z))
     h = lin("encoding_shape", h)                       # no activation
     sigma = F.softplus(lin("sigma.0", h))              # beta=1, threshold=20
-    h = F.relu(lin("encoding_viewdir.0",
-                   torch.cat([h, positional_encoding(viewdir, num_dir_freq)], dim=-1)))
+    h = relu(lin("encoding_viewdir.0",
+                 torch.cat([h, positional_encoding(viewdir, num_dir_freq)], dim=-1)))
     for j in range(1, tb + 1):
         z = F.relu(lin(f"texture_latent_layer_{j}.0", tex_rows))
-        h = F.relu(lin(f"texture_layer_{j}.0", h + z))
-    rgb = lin("rgb.2", F.relu(lin("rgb.0", h)))        # raw linear output, no sigmoid
+        h = relu(lin(f"texture_layer_{j}.0", h + z))
+    rgb = lin("rgb.2", relu(lin("rgb.0", h)))          # raw linear output, no sigmoid
     return sigma, rgb
 
 

@@ -8,8 +8,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsupnerf_hip.so")
 
-Z_SHARED, Z_PER_OBJECT, Z_PER_RAY = 0, 1, 2
-WHITE_BKGD, METRIC_Z = 1, 2
+Z_SHARED, Z_PER_OBJECT, Z_PER_RAY, Z_BOX = 0, 1, 2, 3
+WHITE_BKGD, METRIC_Z, BOX_DETACH = 1, 2, 4
 FP32, BF16X3 = 0, 1
 ERRORS = {-1: "SNR_E_ARG", -2: "SNR_E_SHAPE", -3: "SNR_E_WORKSPACE", -4: "SNR_E_LAUNCH", -5: "SNR_E_UNSUPPORTED"}
 
@@ -24,7 +24,8 @@ class RenderArgs(C.Structure):
                 ("frame", C.c_float * 9), ("xyz_mul", C.c_float), ("z_mode", C.c_int32), ("flags", C.c_int32),
                 ("n_rays", C.c_int64), ("rays_per_obj", C.c_int64), ("n_samples", C.c_int32),
                 ("shape_blocks", C.c_int32), ("texture_blocks", C.c_int32), ("precision", C.c_int32),
-                ("latent_bias", C.c_void_p)]
+                ("latent_bias", C.c_void_p), ("box_half", C.c_void_p), ("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64),
+                ("rng_threads", C.c_uint64)]
 
 
 _lib = None
@@ -59,7 +60,7 @@ _SIGS = {
     "snr_scene_composite_fwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "snr_composite_fwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P]),
     "snr_composite_bwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
-    "snr_encode_fwd": (C.c_int, [C.POINTER(RenderArgs), _P, _P, _P, _P, _P, _P]),
+    "snr_encode_fwd": (C.c_int, [C.POINTER(RenderArgs), _P, _P, _P, _P, _P, _P, _P]),
     "snr_loss_tail_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, _P, _P]),
     "snr_loss_tail_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, _P, _P, _P, _P]),
     "snr_weight_grad_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),

@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
 // sample (coalesced xyz / viewdir / z stores).  Phase 2: the block's 256x63 positional-encoding
 // features are produced in flat output order so every store instruction is fully coalesced.
 __global__ void __launch_bounds__(256) encode_kernel(RayGeom g, float* __restrict__ xyz, float* __restrict__ viewdir,
-                                                     float* __restrict__ z_out, float* __restrict__ pe_xyz) {
+                                                     float* __restrict__ z_out, float* __restrict__ pe_xyz, uint8_t* __restrict__ hit) {
     __shared__ float sx[256][3];
     const long long P = g.n_rays * g.S;
     const long long base = blockIdx.x * 256ll;
@@ -450,6 +450,15 @@ __global__ void __launch_bounds__(256) encode_kernel(RayGeom g, float* __restric
         if (xyz) { xyz[gp * 3] = sp.x; xyz[gp * 3 + 1] = sp.y; xyz[gp * 3 + 2] = sp.z; }
         if (viewdir) { viewdir[gp * 3] = sp.dx; viewdir[gp * 3 + 1] = sp.dy; viewdir[gp * 3 + 2] = sp.dz; }
         if (z_out) z_out[gp] = sp.zc;
+        if (hit && s == 0) {        // the `intersect` map of prepare_sampled_rays (src/renderer.py:101-104)
+            bool h = true;
+            if (g.z_mode == SNR_Z_BOX) {
+                float o[3], d[3], hb[3], zs;
+                box_ray(g, ray, o, d, hb, zs);
+                h = box_slab(o, d, hb).hit;
+            }
+            hit[ray] = h ? 1 : 0;
+        }
     }
     if (!pe_xyz) return;
     __syncthreads();
@@ -744,14 +753,14 @@ int snr_composite_bwd(const float* sigmas, const float* rgbs, const float* z_val
     return snr_check_launch_();
 }
 
-int snr_encode_fwd(const snr_render_args* a, float* xyz, float* viewdir, float* z_out, float* pe_xyz, float* pe_dir, void* stream_) {
+int snr_encode_fwd(const snr_render_args* a, float* xyz, float* viewdir, float* z_out, float* pe_xyz, float* pe_dir, uint8_t* hit, void* stream_) {
     RayGeom g;
     int rc = snr_fill_geom_(a, &g, /*need_model=*/0);
     if (rc != SNR_OK) return rc;
     if (a->n_rays == 0) return SNR_OK;
     hipStream_t st = (hipStream_t)stream_;
     const long long P = a->n_rays * a->n_samples;
-    encode_kernel<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(g, xyz, viewdir, z_out, pe_xyz);
+    encode_kernel<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(g, xyz, viewdir, z_out, pe_xyz, hit);
     if (pe_dir) encode_dir_kernel<<<(unsigned)((a->n_rays * D_DIR + 255) / 256), 256, 0, st>>>(g, pe_dir);
     return snr_check_launch_();
 }
@@ -760,8 +769,13 @@ int snr_encode_fwd(const snr_render_args* a, float* xyz, float* viewdir, float* 
 
 // shared with snr_mlp.hip
 int snr_fill_geom_(const snr_render_args* a, snr::RayGeom* g, int need_model) {
-    if (!a || !a->rays_o || !a->rays_d || !a->t_vals || !a->xyz_div) return SNR_E_ARG;
-    if (a->n_rays < 0 || a->n_samples < 1 || a->z_mode < 0 || a->z_mode > 2) return SNR_E_ARG;
+    if (!a || !a->rays_o || !a->rays_d) return SNR_E_ARG;
+    if (a->n_rays < 0 || a->n_samples < 1 || a->z_mode < 0 || a->z_mode > SNR_Z_BOX) return SNR_E_ARG;
+    if (a->z_mode == SNR_Z_BOX) {
+        /* depths from the ray's own box bounds: origins are divided by z_scale, the unit-interval grid s / S is exact for powers of two only */
+        if (!a->box_half || !a->z_scale) return SNR_E_ARG;
+        if (a->n_samples & (a->n_samples - 1)) return SNR_E_UNSUPPORTED;
+    } else if (!a->t_vals || !a->xyz_div) return SNR_E_ARG;
     if ((a->flags & SNR_METRIC_Z) && !a->z_scale) return SNR_E_ARG;
     if (a->rays_per_obj < 1 || (a->n_rays % a->rays_per_obj) != 0) return SNR_E_SHAPE;
     if (need_model) {
@@ -773,6 +787,7 @@ int snr_fill_geom_(const snr_render_args* a, snr::RayGeom* g, int need_model) {
     for (int i = 0; i < 9; ++i) g->m[i] = a->frame[i];
     g->xyz_mul = a->xyz_mul; g->z_mode = a->z_mode; g->flags = a->flags;
     g->n_rays = a->n_rays; g->rays_per_obj = a->rays_per_obj; g->S = a->n_samples;
+    g->box_half = a->box_half; g->rng_seed = a->rng_seed; g->rng_offset = a->rng_offset; g->rng_threads = a->rng_threads;
     return SNR_OK;
 }
 

@@ -836,7 +836,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     uint4 mk[MAX_LAYERS - 1];                                  // ReLU bits of every ReLU layer of this wave tile
 #pragma unroll
     for (int s = 0; s < MAX_LAYERS - 1; ++s) mk[s] = (s < n_relu && tile_live) ? io.masks[(tile32 * n_relu + s) * 64 + lane] : make_uint4(0, 0, 0, 0);
-    float px_, py_, pz_, dx, dy, dz, tval = 0.f, zc = 0.f;
+    float px_, py_, pz_, dx, dy, dz, tval = 0.f, zc = 0.f, uval = 0.f;
     long long ray = 0;
     if (MODE == 0) {
         px_ = xyz[gp * 3]; py_ = xyz[gp * 3 + 1]; pz_ = xyz[gp * 3 + 2];
@@ -844,7 +844,7 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     } else {
         ray = gp / g.S;
         const SamplePoint sp = make_sample(g, ray, (int)(gp - ray * g.S));
-        px_ = sp.x; py_ = sp.y; pz_ = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc; tval = sp.t;
+        px_ = sp.x; py_ = sp.y; pz_ = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc; tval = sp.t; uval = sp.u;
     }
     const float sig_gp = io.sigmas[gp];       // (issued here: behind the composite's barriers it would be one more exposed round trip)
     float gs = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gzc = 0.f;
@@ -1030,66 +1030,8 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
         }
         return;
     }
-    {
-        const long long obj = ray / g.rays_per_obj;
-        const float sc_ = g.xyz_mul / g.xyz_div[obj];
-        const float qx0 = (g.m[0] * gx + g.m[3] * gy + g.m[6] * gz) * sc_;
-        const float qy0 = (g.m[1] * gx + g.m[4] * gy + g.m[7] * gz) * sc_;
-        const float qz0 = (g.m[2] * gx + g.m[5] * gy + g.m[8] * gz) * sc_;
-        const float qx = g.m[0] * hx + g.m[3] * hy + g.m[6] * hz;
-        const float qy = g.m[1] * hx + g.m[4] * hy + g.m[7] * hz;
-        const float qz = g.m[2] * hx + g.m[5] * hy + g.m[8] * hz;
-        const float rdx = g.rays_d[ray * 3], rdy = g.rays_d[ray * 3 + 1], rdz = g.rays_d[ray * 3 + 2];
-        float c[6] = {qx0, qy0, qz0, tval * qx0 + qx, tval * qy0 + qy, tval * qz0 + qz};
-        float dt = rdx * qx0 + rdy * qy0 + rdz * qz0;
-        if (g.flags & SNR_METRIC_Z) {
-            const float zs = g.z_scale[obj];
-            const float k = zc > 0.f ? gzc * zs * zs * tval / zc : 0.f;
-            dt += k * (rdx * rdx + rdy * rdy + rdz * rdz);
-            c[3] += k * tval * rdx; c[4] += k * tval * rdy; c[5] += k * tval * rdz;
-        } else {
-            dt += gzc;
-        }
-        if (!(live && h == 0)) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) c[i] = 0.f;
-        }
-#ifndef SNR_STAMPS
-        if (io.d_t && live && h == 0) io.d_t[gp] = dt;
-#endif
-        if (io.d_rays_o || io.d_rays_d) {
-            const int S = g.S;
-            const int G = S < 32 ? S : 32;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) c[i] = group_sum(c[i], G);
-            if (S <= 32) {
-                if (live && h == 0 && (p % S) == 0) {
-                    if (io.d_rays_o) { io.d_rays_o[ray * 3] = c[0]; io.d_rays_o[ray * 3 + 1] = c[1]; io.d_rays_o[ray * 3 + 2] = c[2]; }
-                    if (io.d_rays_d) { io.d_rays_d[ray * 3] = c[3]; io.d_rays_d[ray * 3 + 1] = c[4]; io.d_rays_d[ray * 3 + 2] = c[5]; }
-                }
-            } else {
-                float* part = reinterpret_cast<float*>(lds + OFF_COMP);
-                __syncthreads();
-                if (lane == 0) {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) part[wave * 8 + i] = c[i];
-                }
-                __syncthreads();
-                const int waves_per_ray = S / 32;
-                const int rays_here = 128 / S;
-                if (tid < rays_here * 6) {
-                    const int r = tid / 6, i = tid % 6;
-                    const long long rr = tile128 * rays_here + r;
-                    if (rr < g.n_rays) {
-                        float s = 0.f;
-                        for (int w = 0; w < waves_per_ray; ++w) s += part[(r * waves_per_ray + w) * 8 + i];
-                        float* dst = i < 3 ? io.d_rays_o : io.d_rays_d;
-                        if (dst) dst[rr * 3 + (i % 3)] = s;
-                    }
-                }
-            }
-        }
-    }
+    ray_grad_tail(g, io.d_rays_o, io.d_rays_d, io.d_t, reinterpret_cast<float*>(lds + OFF_COMP), tile128, ray, gp, live, tval, uval, zc,
+                  gx, gy, gz, hx, hy, hz, gzc);
     SNR_BSTAMP(14);
 }
 

@@ -130,7 +130,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
 
     SNR32_BSTAMP(0);
     // ---- this lane's point and its upstream gradient
-    float x, y, z, dx, dy, dz, tval = 0.f, zc = 0.f;
+    float x, y, z, dx, dy, dz, tval = 0.f, zc = 0.f, uval = 0.f;
     long long ray = 0;
     if (MODE == 0) {
         x = xyz[gp * 3]; y = xyz[gp * 3 + 1]; z = xyz[gp * 3 + 2];
@@ -138,7 +138,7 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     } else {
         ray = gp / g.S;
         const SamplePoint sp = make_sample(g, ray, (int)(gp - ray * g.S));
-        x = sp.x; y = sp.y; z = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc; tval = sp.t;
+        x = sp.x; y = sp.y; z = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc; tval = sp.t; uval = sp.u;
     }
     float gs = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gzc = 0.f;
     if (MODE == 0) {
@@ -327,69 +327,9 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     }
 
     // ---- sample point -> ray: p' = M (((o + t d) / div) mul), dir' = M d
-    {
-        const long long obj = ray / g.rays_per_obj;
-        const float sc_ = g.xyz_mul / g.xyz_div[obj];
-        // M^T g
-        const float px = (g.m[0] * gx + g.m[3] * gy + g.m[6] * gz) * sc_;
-        const float py = (g.m[1] * gx + g.m[4] * gy + g.m[7] * gz) * sc_;
-        const float pz = (g.m[2] * gx + g.m[5] * gy + g.m[8] * gz) * sc_;
-        const float qx = g.m[0] * hx + g.m[3] * hy + g.m[6] * hz;
-        const float qy = g.m[1] * hx + g.m[4] * hy + g.m[7] * hz;
-        const float qz = g.m[2] * hx + g.m[5] * hy + g.m[8] * hz;
-        const float rdx = g.rays_d[ray * 3], rdy = g.rays_d[ray * 3 + 1], rdz = g.rays_d[ray * 3 + 2];
-        float c[6] = {px, py, pz, tval * px + qx, tval * py + qy, tval * pz + qz};
-        float dt = rdx * px + rdy * py + rdz * pz;
-        if (g.flags & SNR_METRIC_Z) {
-            // zc = | t d | zs  ->  d zc/d t = zs^2 t |d|^2 / zc ,  d zc/d d = zs^2 t^2 d / zc
-            const float zs = g.z_scale[obj];
-            const float k = zc > 0.f ? gzc * zs * zs * tval / zc : 0.f;
-            dt += k * (rdx * rdx + rdy * rdy + rdz * rdz);
-            c[3] += k * tval * rdx; c[4] += k * tval * rdy; c[5] += k * tval * rdz;
-        } else {
-            dt += gzc;
-        }
-        if (!(live && h == 0)) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) c[i] = 0.f;
-        }
-        SNR32_BSTAMP(13);
-#ifndef SNR_STAMPS
-        if (io.d_t && live && h == 0) io.d_t[gp] = dt;
-#endif
-        if (io.d_rays_o || io.d_rays_d) {
-            const int S = g.S;
-            const int G = S < 32 ? S : 32;      // lanes of this wave that share a ray (S divides 128)
-#pragma unroll
-            for (int i = 0; i < 6; ++i) c[i] = group_sum(c[i], G);
-            if (S <= 32) {
-                if (live && h == 0 && (p % S) == 0) {
-                    if (io.d_rays_o) { io.d_rays_o[ray * 3] = c[0]; io.d_rays_o[ray * 3 + 1] = c[1]; io.d_rays_o[ray * 3 + 2] = c[2]; }
-                    if (io.d_rays_d) { io.d_rays_d[ray * 3] = c[3]; io.d_rays_d[ray * 3 + 1] = c[4]; io.d_rays_d[ray * 3 + 2] = c[5]; }
-                }
-            } else {
-                float* part = lds + LDS_COMP;      // composite scratch is free by now
-                __syncthreads();
-                if (lane == 0) {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) part[wave * 8 + i] = c[i];
-                }
-                __syncthreads();
-                const int waves_per_ray = S / 32;              // 2 or 4
-                const int rays_here = 128 / S;
-                if (tid < rays_here * 6) {
-                    const int r = tid / 6, i = tid % 6;
-                    const long long rr = tile128 * rays_here + r;
-                    if (rr < g.n_rays) {
-                        float s = 0.f;
-                        for (int w = 0; w < waves_per_ray; ++w) s += part[(r * waves_per_ray + w) * 8 + i];
-                        float* dst = i < 3 ? io.d_rays_o : io.d_rays_d;
-                        if (dst) dst[rr * 3 + (i % 3)] = s;
-                    }
-                }
-            }
-        }
-    }
+    SNR32_BSTAMP(13);
+    ray_grad_tail(g, io.d_rays_o, io.d_rays_d, io.d_t, lds + LDS_COMP /* the composite scratch is free by now */, tile128, ray, gp, live, tval, uval, zc,
+                  gx, gy, gz, hx, hy, hz, gzc);
 }
 
 }  // namespace snr

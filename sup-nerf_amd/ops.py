@@ -11,7 +11,7 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16X3, FP32, METRIC_Z, WHITE_BKGD, Z_PER_OBJECT, Z_PER_RAY, Z_SHARED, RenderArgs, SnrError, check
+from ._lib import BF16X3, BOX_DETACH, FP32, METRIC_Z, WHITE_BKGD, Z_BOX, Z_PER_OBJECT, Z_PER_RAY, Z_SHARED, RenderArgs, SnrError, check
 
 _AUTO_DOWNGRADES = set()
 IDENTITY_FRAME = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
@@ -57,7 +57,34 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 def _p(t: Optional[torch.Tensor]):
-    return C.c_void_p(0 if t is None else t.data_ptr())
+    """Device address for the C ABI.  The ABI takes dense buffers and cannot know strides (include/supnerf_hip.h: "contiguous"), so
+    EVERY pointer that crosses it goes through here and a tensor that is not a dense GPU buffer raises instead of being read out
+    of bounds (round 2's fault: ``get_rays``' origins are a stride-0 view of the pose's three numbers)."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise SnrError("supnerf_amd operators need tensors on the GPU (no CPU fallback)")
+    if not t.is_contiguous():
+        raise SnrError(f"internal: a non-contiguous tensor (shape {tuple(t.shape)}, strides {t.stride()}) reached the C ABI; "
+                       "operands must be made dense with _f32c first")
+    return C.c_void_p(t.data_ptr())
+
+
+def _p_rows(t: torch.Tensor):
+    """Address of a 2-D row-major operand that travels WITH its leading dimension (snr_weight_grad's G, X, dW: a column block of a wider
+    buffer is fine there); only the rows must be dense."""
+    if not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32:
+        raise SnrError(f"expected a 2-D fp32 row-major GPU tensor, got shape {tuple(t.shape)} strides {t.stride()} {t.dtype} on {t.device}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=torch.float32) -> int:
+    """Like ``_p`` for struct fields (plain integer address), with the element type checked too."""
+    if t is None:
+        return 0
+    if t.dtype != dtype:
+        raise SnrError(f"internal: a {t.dtype} tensor reached the C ABI where {dtype} is expected")
+    return _p(t).value or 0
 
 
 def _stream(dev):
@@ -141,6 +168,11 @@ def scene_composite(sigmas, rgbs, z_vals, white_bkgd=True, run_length=0):
 
 
 def composite_bwd(sigmas, rgbs, z_vals, z_mode, white_bkgd, rays_per_obj, d_rgb, d_depth, d_acc, need_dz):
+    sigmas, rgbs, z_vals = _f32c(sigmas), _f32c(rgbs), _f32c(z_vals)
+    # dense copies are NAMED so that they live until the launch is enqueued: `_p(_f32c(t))` inside the argument list frees the temporary before
+    # the next argument is evaluated, and the allocator hands the same block to the next temporary (found by tests/test_strided_operands.py)
+    d_rgb, d_depth, d_acc = _f32c(d_rgb), _f32c(d_depth), _f32c(d_acc)
+    _need_gpu(sigmas, rgbs, z_vals, d_rgb, d_depth, d_acc)
     S = rgbs.shape[-2]
     n_rays = rgbs.numel() // (3 * S) if rgbs.numel() else 0
     dev = rgbs.device
@@ -149,7 +181,7 @@ def composite_bwd(sigmas, rgbs, z_vals, z_mode, white_bkgd, rays_per_obj, d_rgb,
     d_z = torch.empty(n_rays, S, device=dev) if need_dz else None
     with torch.cuda.device(dev):
         check(_lib.lib().snr_composite_bwd(_p(sigmas), _p(rgbs), _p(z_vals), z_mode, WHITE_BKGD if white_bkgd else 0, n_rays,
-                                           rays_per_obj, S, _p(_f32c(d_rgb)), _p(_f32c(d_depth)), _p(_f32c(d_acc)),
+                                           rays_per_obj, S, _p(d_rgb), _p(d_depth), _p(d_acc),
                                            _p(d_sig), _p(d_rgbs), _p(d_z), _stream(dev)), "snr_composite_bwd")
     return d_sig, d_rgbs, d_z
 
@@ -222,8 +254,9 @@ class LossTail(torch.autograd.Function):
         d_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[0] else None
         d_acc = torch.empty_like(acc) if ctx.needs_input_grad[1] else None
         if d_rgb is not None or d_acc is not None:
+            g_loss = _f32c(g_loss)
             with torch.cuda.device(dev):
-                check(_lib.lib().snr_loss_tail_bwd(_p(rgb), _p(acc), _p(rgb_tgt), _p(occ), acc.numel(), rpo, coef, _p(_f32c(g_loss)),
+                check(_lib.lib().snr_loss_tail_bwd(_p(rgb), _p(acc), _p(rgb_tgt), _p(occ), acc.numel(), rpo, coef, _p(g_loss),
                                                    _p(d_rgb), _p(d_acc), _stream(dev)), "snr_loss_tail_bwd")
         return d_rgb, d_acc, None, None, None, None
 
@@ -263,9 +296,10 @@ class PoseRays(torch.autograd.Function):
         B, n = cam_dirs.shape[0], cam_dirs.shape[1]
         dev = cam_dirs.device
         d_rot, d_tr = torch.empty_like(rot_vec), torch.empty_like(trans_vec)
+        d_rays_o, d_viewdir, d_cam2opt = _f32c(d_rays_o), _f32c(d_viewdir), _f32c(d_cam2opt)
         with torch.cuda.device(dev):
-            check(_lib.lib().snr_pose_rays_bwd(_p(rot_vec), _p(trans_vec), _p(cam_dirs), B, n, ctx.opt_cam_pose, _p(_f32c(d_rays_o)),
-                                               _p(_f32c(d_viewdir)), _p(_f32c(d_cam2opt)), _p(d_rot), _p(d_tr), _stream(dev)), "snr_pose_rays_bwd")
+            check(_lib.lib().snr_pose_rays_bwd(_p(rot_vec), _p(trans_vec), _p(cam_dirs), B, n, ctx.opt_cam_pose, _p(d_rays_o),
+                                               _p(d_viewdir), _p(d_cam2opt), _p(d_rot), _p(d_tr), _stream(dev)), "snr_pose_rays_bwd")
         return d_rot, d_tr, None, None, None, None, None
 
 
@@ -354,6 +388,11 @@ def decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save
 
 def decoder_bwd(xyz, viewdir, latent, packed, masks, sigmas, d_sig, d_rgb, shape_blocks, texture_blocks,
                 need_latent=True, need_xyz=True, need_dir=True, precision="fp32", layer_grads=None):
+    xyz, viewdir, latent, sigmas = _f32c(xyz), _f32c(viewdir), _f32c(latent), _f32c(sigmas)
+    _need_gpu(xyz, viewdir, latent, packed, masks, sigmas, d_sig, d_rgb, layer_grads)
+    if masks is None or sigmas is None:
+        raise SnrError("decoder_bwd needs the ReLU bits and densities saved by decoder_fwd(..., save_masks=True)")
+    masks, d_sig, d_rgb = masks.contiguous(), _f32c(d_sig), _f32c(d_rgb)
     P, B = xyz.shape[0], latent.shape[0]
     dev = xyz.device
     if need_latent and shape_blocks + texture_blocks > 0 and (P // B) % 32:
@@ -365,8 +404,8 @@ def decoder_bwd(xyz, viewdir, latent, packed, masks, sigmas, d_sig, d_rgb, shape
     ws_bytes = _lib.lib().snr_decoder_bwd_ws_bytes(P, P // B, shape_blocks, texture_blocks)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.lib().snr_decoder_bwd(_p(xyz), _p(viewdir), _p(latent), _p(packed), _p(masks), _p(sigmas), _p(_f32c(d_sig)),
-                                         _p(_f32c(d_rgb)), P, P // B, shape_blocks, texture_blocks, _p(d_latent), _p(d_xyz),
+        check(_lib.lib().snr_decoder_bwd(_p(xyz), _p(viewdir), _p(latent), _p(packed), _p(masks), _p(sigmas), _p(d_sig),
+                                         _p(d_rgb), P, P // B, shape_blocks, texture_blocks, _p(d_latent), _p(d_xyz),
                                          _p(d_dir), _p(layer_grads), _p(ws), ws_bytes, resolve_precision(precision, shape_blocks, texture_blocks, P // B),
                                          _stream(dev)), "snr_decoder_bwd")
     return d_latent, d_xyz, d_dir
@@ -454,7 +493,7 @@ def weight_grad(G, n_out, X, n_in, want_bias=True, out=None, ws=None, precision=
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.lib().snr_weight_grad(_p(G), G.stride(0), n_out, _p(X), X.stride(0), n_in, P, _p(dW), dW.stride(0), _p(db), PRECISIONS[precision],
+        check(_lib.lib().snr_weight_grad(_p_rows(G), G.stride(0), n_out, _p_rows(X), X.stride(0), n_in, P, _p_rows(dW), dW.stride(0), _p(db), PRECISIONS[precision],
                                          _p(ws), ws.numel(), _stream(dev)), "snr_weight_grad")
     return dW, db
 
@@ -547,21 +586,53 @@ class DecoderPointsTrain(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------ fused render
 def _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, frame, xyz_mul, z_mode, flags, rays_per_obj,
-                 n_samples, shape_blocks, texture_blocks, precision=FP32, latent_bias=None):
+                 n_samples, shape_blocks, texture_blocks, precision=FP32, latent_bias=None, box_half=None, rng=None):
     a = RenderArgs()
-    a.rays_o, a.rays_d, a.t_vals = rays_o.data_ptr(), rays_d.data_ptr(), t_vals.data_ptr()
-    a.xyz_div = xyz_div.data_ptr()
-    a.z_scale = z_scale.data_ptr() if z_scale is not None else 0
-    a.latent = latent.data_ptr() if latent is not None else 0
-    a.packed = packed.data_ptr() if packed is not None else 0
+    a.rays_o, a.rays_d, a.t_vals = _ptr(rays_o), _ptr(rays_d), _ptr(t_vals)
+    a.xyz_div, a.z_scale = _ptr(xyz_div), _ptr(z_scale)
+    a.latent, a.packed = _ptr(latent), _ptr(packed)
     a.frame = (C.c_float * 9)(*[float(v) for v in frame])
     a.xyz_mul = float(xyz_mul)
     a.z_mode, a.flags = int(z_mode), int(flags)
     a.n_rays, a.rays_per_obj = int(rays_o.shape[0]), int(rays_per_obj)
     a.n_samples, a.shape_blocks, a.texture_blocks = int(n_samples), int(shape_blocks), int(texture_blocks)
     a.precision = int(precision)
-    a.latent_bias = latent_bias.data_ptr() if latent_bias is not None else 0
+    a.latent_bias = _ptr(latent_bias)
+    a.box_half = _ptr(box_half)
+    a.rng_seed, a.rng_offset, a.rng_threads = [int(v) & 0xFFFFFFFFFFFFFFFF for v in (rng if rng is not None else (0, 0, 0))]
+    # sizes the kernels index with: a short buffer here is an out-of-bounds read on the device
+    N, S, B = a.n_rays, a.n_samples, max(a.n_rays // max(a.rays_per_obj, 1), 1)
+    if rays_o.numel() != 3 * N or rays_d.numel() != 3 * N:
+        raise SnrError(f"render: rays_o {tuple(rays_o.shape)} / rays_d {tuple(rays_d.shape)} are not (N,3)")
+    want_t = {Z_SHARED: S, Z_PER_OBJECT: B * S, Z_PER_RAY: N * S, Z_BOX: N * S}[a.z_mode]
+    if t_vals is not None and t_vals.numel() != want_t:
+        raise SnrError(f"render: depths / jitter hold {t_vals.numel()} values, z_mode {a.z_mode} needs {want_t}")
+    if a.z_mode == Z_BOX:
+        if box_half is None or box_half.numel() != 3 * B or z_scale is None:
+            raise SnrError("render: box sampling needs box_half (B,3) and z_scale (B,)")
+    elif t_vals is None or xyz_div is None:
+        raise SnrError("render: depths and xyz_div are required")
+    for t, name in ((xyz_div, "xyz_div"), (z_scale, "z_scale")):
+        if t is not None and t.numel() < B:
+            raise SnrError(f"render: {name} holds {t.numel()} values for {B} objects")
     return a
+
+
+def reserve_rand_like(dev, numel):
+    """(seed, offset, threads) describing what ``torch.rand_like`` of ``numel`` floats would draw from ``dev``'s default generator
+    right now, and advance the generator exactly as that call would (aten/src/ATen/native/cuda/DistributionTemplates.h:
+    calc_execution_policy).  The box-sampling kernels regenerate those numbers themselves (family B's jitter, src/renderer.py:40), so a
+    seeded run consumes the generator like the reference without an (N,S) tensor or an extra launch."""
+    dev = torch.device(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    gen = torch.cuda.default_generators[idx]
+    props = torch.cuda.get_device_properties(idx)
+    block = 256
+    grid = min(props.multi_processor_count * (props.max_threads_per_multi_processor // block), (numel + block - 1) // block)
+    threads = max(grid, 1) * block
+    seed, offset = gen.initial_seed(), gen.get_offset()
+    gen.set_offset(offset + ((max(numel, 1) - 1) // (threads * 4) + 1) * 4)
+    return seed, offset, threads
 
 
 def fused_supported(n_samples: int) -> bool:
@@ -573,7 +644,7 @@ class RenderCfg:
     """Per-launch constants of the render operators (not tensors)."""
 
     def __init__(self, n_samples, z_mode, rays_per_obj, shape_blocks, texture_blocks, frame=IDENTITY_FRAME, xyz_mul=1.0,
-                 white_bkgd=False, metric_z=False, precision=None):
+                 white_bkgd=False, metric_z=False, precision=None, box_half=None, box_detach=False):
         self.n_samples, self.z_mode, self.rays_per_obj = n_samples, z_mode, rays_per_obj
         # "fp32" | "bf16x3" | "auto" | None.  None = not chosen here: ``model.fused_render`` substitutes the module's ``precision``; the
         # bare operators (render_fwd, encode) treat it as "auto", the library default.  (It used to default to "fp32", which made
@@ -581,10 +652,21 @@ class RenderCfg:
         self.precision = precision
         self.shape_blocks, self.texture_blocks = shape_blocks, texture_blocks
         self.frame, self.xyz_mul = tuple(float(v) for v in frame), float(xyz_mul)
-        self.flags = (WHITE_BKGD if white_bkgd else 0) | (METRIC_Z if metric_z else 0)
+        self.flags = (WHITE_BKGD if white_bkgd else 0) | (METRIC_Z if metric_z else 0) | (BOX_DETACH if box_detach else 0)
         # optional (B, NLAT, 256) fp32 on the device: the latent terms folded into the next layers' biases (model.latent_biases);
         # forward only, no gradient flows through it (the backward kernel returns the gradient of the latent terms themselves)
         self.latent_bias = None
+        # z_mode Z_BOX (family B, src/renderer.py:91-115): (B,3) half extents of the objects' boxes on the device; the depths argument of the
+        # operators then is the (N,S) jitter or None = drawn in the kernel from ``rng`` = (seed, offset, threads), see reserve_rand_like
+        self.box_half = box_half
+        self.rng = None
+
+
+def _box_rng(cfg, t_vals, dev, n_points):
+    """Box sampling without a caller-supplied jitter: fix the generator state the kernels will draw from (once per forward; the
+    backward replays it from the same cfg)."""
+    if cfg.z_mode == Z_BOX and t_vals is None and cfg.rng is None:
+        cfg.rng = reserve_rand_like(dev, n_points)
 
 
 def render_fwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg: RenderCfg, save_for_bwd=False):
@@ -608,8 +690,10 @@ def render_fwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg: Re
         lb = _f32c(lb.detach())
         if lb.shape != latent.shape or lb.device != dev:
             raise SnrError(f"latent_bias must match the latent terms: {tuple(lb.shape)} on {lb.device} vs {tuple(latent.shape)} on {dev}")
+    _box_rng(cfg, t_vals, dev, N * S)
+    bh = _f32c(cfg.box_half)
     a = _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg.frame, cfg.xyz_mul, cfg.z_mode, cfg.flags,
-                     cfg.rays_per_obj, S, cfg.shape_blocks, cfg.texture_blocks, prec, latent_bias=lb)
+                     cfg.rays_per_obj, S, cfg.shape_blocks, cfg.texture_blocks, prec, latent_bias=lb, box_half=bh, rng=cfg.rng)
     with torch.cuda.device(dev):
         check(_lib.lib().snr_render_fwd(C.byref(a), _p(rgb), _p(depth), _p(acc), _p(sig), _p(rgbs), _p(masks), _stream(dev)),
               "snr_render_fwd")
@@ -617,7 +701,9 @@ def render_fwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg: Re
 
 
 class FusedRender(torch.autograd.Function):
-    """rays -> (rgb, depth, acc_trans) in one launch; backward in one launch (+ a small reduction)."""
+    """rays -> (rgb, depth, acc_trans) in one launch; backward in one launch (+ a small reduction).  ``t_vals``: the depths in
+    ``cfg.z_mode``'s layout; for Z_BOX the (N,S) jitter, or None (drawn in the kernel).  Gradients: rays_o, rays_d, latent always; t_vals for
+    per-ray depths; for Z_BOX the gradient through the box bounds is part of d_rays_o / d_rays_d."""
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg):
@@ -630,14 +716,17 @@ class FusedRender(torch.autograd.Function):
         B = rays_o.shape[0] // n if n else 0
         n_pad = _tile_pad(n, cfg.n_samples) if (ctx.needs_input_grad[5] and cfg.shape_blocks + cfg.texture_blocks > 0 and B > 0) else 0
         ctx.pad = (B, n, n_pad)
+        cfg = copy.copy(cfg)                    # (the launch's generator state is recorded in it: one copy per call)
         if n_pad:
             rays_o, rays_d = _pad_rows(rays_o, B, n, n_pad), _pad_rows(rays_d, B, n, n_pad)
-            if cfg.z_mode == Z_PER_RAY:
+            if cfg.z_mode in (Z_PER_RAY, Z_BOX) and t_vals is not None:
                 t_vals = _pad_rows(t_vals, B, n, n_pad)
             if z_scale is not None and z_scale.numel() == B * n:
                 z_scale = _pad_rows(z_scale, B, n, n_pad)
-            cfg = copy.copy(cfg)
             cfg.rays_per_obj = n_pad
+            if cfg.z_mode == Z_BOX:             # (a dummy ray with direction 0 would divide 0 by 0 in the slab test: give it any unit direction)
+                rays_d = rays_d.clone()
+                rays_d.view(B, n_pad, 3)[:, n:, 2] = 1.0
         rgb, depth, acc, sig, rgbs, masks = render_fwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg, save_for_bwd=need)
         if need:
             ctx.save_for_backward(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, sig, rgbs, masks)
@@ -654,7 +743,7 @@ class FusedRender(torch.autograd.Function):
             raise SnrError("xyz_div / z_scale are per-object constants (object size); no gradient is provided")
         need_t = ctx.needs_input_grad[2]
         if need_t and cfg.z_mode != Z_PER_RAY:
-            raise SnrError("gradient wrt shared / per-object depths is not provided (the reference detaches them)")
+            raise SnrError("gradient wrt shared / per-object depths or the box jitter is not provided (the reference detaches them)")
         B, n, n_pad = ctx.pad
         if d_rgb is None and d_depth is None and d_acc is None:
             return None, None, None, None, None, None, None, None
@@ -671,35 +760,49 @@ class FusedRender(torch.autograd.Function):
 def render_bwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg: RenderCfg, sig, rgbs, masks, d_rgb, d_depth, d_acc,
                need_o=True, need_d=True, need_t=False, need_latent=True):
     """Backward of the fused render on what ``render_fwd(..., save_for_bwd=True)`` saved: one launch + the small reduction of the
-    latent-term partials.  Returns (d_rays_o, d_rays_d, d_t, d_latent), None where not asked for."""
-    # (contiguous fp32 like render_fwd made them: get_rays' origins, for one, are a stride-0 view of the pose's 3 numbers)
+    latent-term partials.  Returns (d_rays_o, d_rays_d, d_t, d_latent), None where not asked for.  Any operand may be a strided view
+    (get_rays' origins, for one, are a stride-0 view of the pose's 3 numbers): everything is made dense here."""
     rays_o, rays_d, t_vals, xyz_div, z_scale, latent = [_f32c(t) for t in (rays_o, rays_d, t_vals, xyz_div, z_scale, latent)]
-    _need_gpu(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, sig, rgbs, masks)
+    sig, rgbs, d_rgb, d_depth, d_acc = [_f32c(t) for t in (sig, rgbs, d_rgb, d_depth, d_acc)]
+    _need_gpu(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, sig, rgbs, masks, d_rgb, d_depth, d_acc)
     if sig is None or rgbs is None or masks is None:
         raise SnrError("render_bwd needs what render_fwd(..., save_for_bwd=True) saved: per-point sigmas, rgbs and the ReLU bits")
+    if cfg.z_mode == Z_BOX and t_vals is None and cfg.rng is None:
+        raise SnrError("render_bwd: box sampling with in-kernel jitter needs the cfg the forward ran with (it holds the generator state)")
+    masks, packed = masks.contiguous(), packed.contiguous()
     dev = rays_o.device
+    N, S = rays_o.shape[0], cfg.n_samples
+    if sig.numel() != N * S or rgbs.numel() != 3 * N * S or masks.numel() < _lib.lib().snr_mask_bytes(N * S, cfg.shape_blocks, cfg.texture_blocks):
+        raise SnrError(f"render_bwd: saved sigmas / rgbs / ReLU bits do not belong to {N} rays x {S} samples")
+    for t, k, name in ((d_rgb, 3 * N, "d_rgb"), (d_depth, N, "d_depth"), (d_acc, N, "d_acc")):
+        if t is not None and t.numel() != k:
+            raise SnrError(f"render_bwd: {name} holds {t.numel()} values, expected {k}")
     if need_latent and cfg.shape_blocks + cfg.texture_blocks > 0 and (cfg.rays_per_obj * cfg.n_samples) % 32:
         raise SnrError(f"gradient wrt the latent codes needs whole 32-point wave tiles per object, got {cfg.rays_per_obj} rays x {cfg.n_samples} "
                        "samples per object: pad the ray batch of every object so that rays x samples is a multiple of 32, or detach the codes")
+    if need_t and cfg.z_mode != Z_PER_RAY:
+        raise SnrError("render_bwd: d_t exists for per-ray depths only")
     d_lat = torch.empty_like(latent) if need_latent else None
     d_o = torch.empty_like(rays_o) if need_o else None      # (the kernel writes every ray's gradient exactly once: no memset)
     d_d = torch.empty_like(rays_d) if need_d else None
     d_t = torch.empty_like(t_vals) if need_t else None
+    bh = _f32c(cfg.box_half)
     a = _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg.frame, cfg.xyz_mul, cfg.z_mode, cfg.flags,
                      cfg.rays_per_obj, cfg.n_samples, cfg.shape_blocks, cfg.texture_blocks,
-                     resolve_precision(cfg.precision, cfg.shape_blocks, cfg.texture_blocks, cfg.rays_per_obj * cfg.n_samples))
+                     resolve_precision(cfg.precision, cfg.shape_blocks, cfg.texture_blocks, cfg.rays_per_obj * cfg.n_samples),
+                     box_half=bh, rng=cfg.rng)
     ws_bytes = _lib.lib().snr_render_bwd_ws_bytes(C.byref(a))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.lib().snr_render_bwd(C.byref(a), _p(sig), _p(rgbs), _p(masks), _p(_f32c(d_rgb)), _p(_f32c(d_depth)),
-                                        _p(_f32c(d_acc)), _p(d_lat), _p(d_o), _p(d_d), _p(d_t), _p(ws), ws_bytes, _stream(dev)),
-              "snr_render_bwd")
+        check(_lib.lib().snr_render_bwd(C.byref(a), _p(sig), _p(rgbs), _p(masks), _p(d_rgb), _p(d_depth), _p(d_acc), _p(d_lat), _p(d_o), _p(d_d),
+                                        _p(d_t), _p(ws), ws_bytes, _stream(dev)), "snr_render_bwd")
     return d_o, d_d, d_t, d_lat
 
 
 # ------------------------------------------------------------------------------------ encode
-def encode(rays_o, rays_d, t_vals, xyz_div, z_scale, cfg: RenderCfg, want_pe=False):
-    """Sample points of a ray packet: xyz (N,S,3), viewdir (N,S,3), z (N,S) [, PE(xyz) (N,S,63), PE(dir) (N,27)]."""
+def encode(rays_o, rays_d, t_vals, xyz_div, z_scale, cfg: RenderCfg, want_pe=False, want_hit=False):
+    """Sample points of a ray packet: xyz (N,S,3), viewdir (N,S,3), z (N,S) [, PE(xyz) (N,S,63), PE(dir) (N,27)] [, hit (N) bool: the
+    rays that meet their box, Z_BOX]."""
     rays_o, rays_d, t_vals, xyz_div, z_scale = [_f32c(t) for t in (rays_o, rays_d, t_vals, xyz_div, z_scale)]
     _need_gpu(rays_o, rays_d, t_vals, xyz_div, z_scale)
     dev = rays_o.device
@@ -709,8 +812,12 @@ def encode(rays_o, rays_d, t_vals, xyz_div, z_scale, cfg: RenderCfg, want_pe=Fal
     z = torch.empty(N, S, device=dev)
     pe = torch.empty(N, S, 63, device=dev) if want_pe else None
     ped = torch.empty(N, 27, device=dev) if want_pe else None
+    hit = torch.empty(N, dtype=torch.uint8, device=dev) if want_hit else None
+    _box_rng(cfg, t_vals, dev, N * S)
+    bh = _f32c(cfg.box_half)
     a = _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, None, None, cfg.frame, cfg.xyz_mul, cfg.z_mode, cfg.flags,
-                     cfg.rays_per_obj, S, cfg.shape_blocks, cfg.texture_blocks)
+                     cfg.rays_per_obj, S, cfg.shape_blocks, cfg.texture_blocks, box_half=bh, rng=cfg.rng)
     with torch.cuda.device(dev):
-        check(_lib.lib().snr_encode_fwd(C.byref(a), _p(xyz), _p(vd), _p(z), _p(pe), _p(ped), _stream(dev)), "snr_encode_fwd")
-    return (xyz, vd, z, pe, ped) if want_pe else (xyz, vd, z)
+        check(_lib.lib().snr_encode_fwd(C.byref(a), _p(xyz), _p(vd), _p(z), _p(pe), _p(ped), _p(hit), _stream(dev)), "snr_encode_fwd")
+    out = (xyz, vd, z, pe, ped) if want_pe else (xyz, vd, z)
+    return out + (hit.bool(),) if want_hit else out

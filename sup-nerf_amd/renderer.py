@@ -3,9 +3,13 @@ signatures of the reference's src/renderer.py, on the HIP kernels.
 
 Family B samples between per-ray box entry / exit depths (ray-AABB slab test in the frame where the
 object diagonal is 2), composites against a white background by default and reports metric depth
-``|xyz - o| * diag/2``.  The slab test and the (N,S) depth table are small torch ops (they stay
-differentiable wrt the pose exactly as in ``NeRFRenderer``); points, positional encoding, decoder and
-composite run as one fused launch, with the gradient wrt the depths returned by the kernel.
+``|xyz - o| * diag/2``.  From ``(rays_o, viewdir, obj_sz)`` on, everything is ONE launch (``SNR_Z_BOX``): the slab
+test, the hit / miss bounds, the stratified per-ray depths, points, positional encoding, decoder and composite;
+the backward launch returns the gradient through the box bounds to origins and directions like the reference's
+autograd through ``ray_box_intersection_tensor``.  The jitter is the reference's ``torch.rand_like`` draw from the
+device generator, regenerated inside the kernel (``ops.reserve_rand_like``) -- no (N,S) tensor exists.  Sample counts
+that are not a power of two dividing 128, foreign decoders and CPU inputs take the torch formulation of the same
+arithmetic (slab test and depth table as tensor ops, then the encode / decoder / composite launches).
 """
 import numpy as np
 import torch
@@ -13,7 +17,7 @@ import torch
 from . import ops
 from . import utils as U
 from ._lib import SnrError
-from .ops import Z_PER_RAY
+from .ops import Z_BOX, Z_PER_RAY
 
 
 def volume_rendering3(sigmas, rgbs, z_vals, white_bkgd=False):
@@ -22,6 +26,32 @@ def volume_rendering3(sigmas, rgbs, z_vals, white_bkgd=False):
 
 
 _unit_depths = U._unit_depths     # the stratified per-ray depth table lives beside its module-level twin, utils.sample_from_rays_v2
+
+# True: family B's jitter is drawn inside the kernels from the device generator's state (same numbers torch.rand_like would give, same
+# generator consumption).  False: torch.rand_like makes the (N,S) table and the kernels read it.
+KERNEL_JITTER = True
+_BOX_CONST = {}
+
+
+def _box_constants(obj_sz, B, dev):
+    """(diag, box_half (B,3), z_scale (B,)) on ``dev`` for B objects of size obj_sz = (w, l, h), cached: the half extents
+    (l, w, h) / diag and the frame scale diag / 2 of src/renderer.py:92-103 never change for an object."""
+    sz = np.asarray(obj_sz)
+    key = (tuple(float(v) for v in sz.reshape(-1)), str(sz.dtype), int(B), str(dev))
+    hit = _BOX_CONST.get(key)
+    if hit is None:
+        diag = np.linalg.norm(sz).astype(np.float32)
+        w, l, h = sz
+        half = np.asarray([l / diag, w / diag, h / diag]).astype(np.float32)
+        hit = (diag, torch.from_numpy(half).to(dev)[None, :].repeat(B, 1).contiguous(), torch.full((B,), float(diag / 2), device=dev))
+        if len(_BOX_CONST) >= 64:
+            _BOX_CONST.pop(next(iter(_BOX_CONST)))
+        _BOX_CONST[key] = hit
+    return hit
+
+
+def _pow2(n):
+    return n >= 1 and (n & (n - 1)) == 0
 
 
 def _box_bounds(rays_o_n, viewdir, obj_sz, diag):
@@ -73,6 +103,15 @@ class NeRFRenderer(torch.nn.Module):
 
     def prepare_sampled_rays(self, rays_o, viewdir, obj_sz):
         """src/renderer.py:91-115: xyz (N,S,3), viewdir (N,S,3), metric z_vals (N,S), hit (N,)."""
+        if rays_o.is_cuda and not (rays_o.requires_grad or viewdir.requires_grad) and _pow2(self.n_samples) and rays_o.shape[0] > 0:
+            # one launch: slab test, bounds, depths, points, metric z and the hit map
+            dev = rays_o.device
+            _, half, zs = _box_constants(obj_sz, 1, dev)
+            cfg = ops.RenderCfg(self.n_samples, Z_BOX, rays_o.shape[0], 0, 0, metric_z=True, box_half=half)
+            jitter = U._jitter_override()
+            if jitter is None and not KERNEL_JITTER:
+                jitter = torch.rand(rays_o.shape[0], self.n_samples, device=dev)
+            return ops.encode(rays_o, viewdir, None if jitter is None else jitter.to(dev), None, zs, cfg, want_hit=True)
         o_n, t, hit, diag = self._rays_in_box_frame(rays_o, viewdir, obj_sz)
         if not rays_o.is_cuda or rays_o.requires_grad or viewdir.requires_grad or t.requires_grad:
             xyz = o_n[:, None, :] + t[:, :, None] * viewdir[:, None, :]
@@ -88,11 +127,22 @@ class NeRFRenderer(torch.nn.Module):
                 detach_bounds=False, adjust_scale=1.0, frame=None):
         dev = torch.device(device)
         rays_o, viewdir = rays_o.to(dev), viewdir.to(dev)
-        o_n, t, hit, diag = self._rays_in_box_frame(rays_o, viewdir, obj_sz, jitter, detach_bounds)
         S = self.n_samples
         B = shapecode.shape[0]
         if frame is None:
             frame = U._frame(False, kitti2nusc, False)
+        if U._is_native(model) and ops.fused_supported(S) and _pow2(S) and rays_o.is_cuda and rays_o.shape[0] > 0:
+            # ONE launch from (rays_o, viewdir, obj_sz): box bounds and depths are made in the kernel's prologue (SNR_Z_BOX)
+            _, half, zs = _box_constants(obj_sz, B, dev)
+            cfg = ops.RenderCfg(S, Z_BOX, max(rays_o.shape[0] // B, 1), getattr(model, "shape_blocks", 0), getattr(model, "texture_blocks", 0),
+                                frame=frame, xyz_mul=adjust_scale, white_bkgd=white_bkgd, metric_z=True, precision=None, box_half=half,
+                                box_detach=detach_bounds)
+            if jitter is None:
+                jitter = U._jitter_override()
+            if jitter is None and not KERNEL_JITTER:
+                jitter = torch.rand(rays_o.shape[0], S, device=dev)      # (the reference's rand_like draw, src/renderer.py:40)
+            return model.fused_render(rays_o, viewdir, None if jitter is None else jitter.to(dev), None, zs, shapecode, texturecode, cfg)
+        o_n, t, hit, diag = self._rays_in_box_frame(rays_o, viewdir, obj_sz, jitter, detach_bounds)
         cfg = ops.RenderCfg(S, Z_PER_RAY, max(rays_o.shape[0] // B, 1), getattr(model, "shape_blocks", 0),
                             getattr(model, "texture_blocks", 0), frame=frame, xyz_mul=adjust_scale, white_bkgd=white_bkgd, metric_z=True,
                             precision=None)
@@ -102,7 +152,7 @@ class NeRFRenderer(torch.nn.Module):
             e = torch.empty(0, device=dev)
             return e.view(0, 3), e, e
         if U._is_native(model) and ops.fused_supported(S):
-            return model.fused_render(o_n, viewdir, t, one, zs, shapecode, texturecode, cfg)
+            return model.fused_render(o_n, viewdir, t, one, zs, shapecode, texturecode, cfg)      # (CPU-resident rays are refused there: no fallback)
         m = torch.tensor(frame, device=dev).view(3, 3)
         p = o_n[:, None, :] + t[:, :, None] * viewdir[:, None, :]
         z_vals = torch.norm((p - o_n[:, None, :]) * (diag / 2), p=2, dim=-1)
@@ -115,9 +165,7 @@ class NeRFRenderer(torch.nn.Module):
                     n_rays=None):
         """src/renderer.py:117-167."""
         rays_o, viewdir = U.get_rays(K, cam_pose, roi, uv_steps=[im_sz, im_sz])
-        img, mask_occ = U._resize(img, mask_occ, im_sz)
-        rgb_tgt = img.reshape(-1, 3).to(device)
-        occ_pixels = mask_occ.reshape(-1, 1).to(device)
+        rgb_tgt, occ_pixels = U._resize_to(img, mask_occ, im_sz, device)      # (cached per crop like family A's: the loops pass the same crop every iteration)
         if n_rays is not None:
             n_rays = int(np.minimum(rays_o.shape[0], n_rays))
             ids = np.random.permutation(rays_o.shape[0])[:n_rays]
@@ -188,9 +236,7 @@ def render_rays_v3(model, device, img, mask_occ, cam_pose, obj_wlh, K, roi, n_sa
         raise SnrError("render_rays_v3 only works with n_samples == 64 (reference behaviour, src/renderer.py:393,434-437)")
     renderer = NeRFRenderer()
     rays_o, viewdir = U.get_rays(K, cam_pose, roi, uv_steps=[im_sz, im_sz])
-    img, mask_occ = U._resize(img, mask_occ, im_sz)
-    rgb_tgt = img.reshape(-1, 3).to(device)
-    occ_pixels = mask_occ.reshape(-1, 1).to(device)
+    rgb_tgt, occ_pixels = U._resize_to(img, mask_occ, im_sz, device)
     if n_rays is not None:
         n_rays = int(np.minimum(rays_o.shape[0], n_rays))
         ids = np.random.permutation(rays_o.shape[0])[:n_rays]
