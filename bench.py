@@ -23,7 +23,7 @@ Reported beside `value` (never part of it):
     profile of the same kernel (profiles/, read at run time; null when no profile of this round exists);
   * `api`: the public functions end to end (`utils.render_rays_v2`: ray generation, target resize, depths, per-object layers, render),
     forward and forward + backward to codes and pose;
-  * `optimise_loop`: one object through the fused loop / the API-structured loop / the HIP-graph-replayed loop; `c3_sharded`: BASELINE
+  * `optimise_loop`: one object through the fused loop / the API-structured loop; `c3_sharded`: BASELINE
     config 3, 64 objects sharded over the ranks through driver.optimize_objects_batched + the metric all_gather;
   * `training_step`: BASELINE config 5's per-GPU step (8 objects x 1024 rays x 64 samples, decoder + codes trained);
   * `cpu_baseline`: the CPU oracle (oracle/, a PyTorch restatement of the reference pinned by the reference's own outputs) on this host's
@@ -450,13 +450,11 @@ def main():
             t_f = timed(lambda: D.optimize_object(model, dev, objs[0], hp, sc_l, tc_l, seed=0))
             loop[f"fused_eager_{p}"] = {"ms_per_iteration": t_f / n_it1 * 1e3, "object_iterations_per_s": n_it1 / t_f}
         t_a = timed(lambda: D.optimize_object_api(model, dev, objs[0], hp, sc_l, tc_l, seed=0))
-        t_g = timed(lambda: D.optimize_objects_batched(model, dev, objs, hp, sc_l, tc_l, [0], graph=True))
         loop.update({"api_structured_auto": {"ms_per_iteration": t_a / n_it1 * 1e3, "object_iterations_per_s": n_it1 / t_a},
-                     "hip_graph_auto": {"ms_per_iteration": t_g / n_it1 * 1e3, "object_iterations_per_s": n_it1 / t_g},
                      "iterations": n_it1, "rays_per_object": N_RAYS,
                      "note": "iteration = forward + backward (codes, pose) + 64-pixel depth render + metric row + AdamW at 4096 x 64; fused_eager = driver.optimize_object "
-                             "(~24 launches per iteration, no graph); api_structured = the same loop on the public functions, call for call like the reference (~350 launches); "
-                             "hip_graph = the torch-op iteration recorded once and replayed; set-up (and recording) included everywhere"})
+                             "(~24 launches per iteration, no graph); api_structured = the same loop on the public functions, call for call like the reference; "
+                             "set-up included everywhere"})
     extra["optimise_loop"] = loop
 
     log("config 3: 64 objects sharded")

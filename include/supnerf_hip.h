@@ -87,10 +87,6 @@ const char* snr_last_hip_error(void);
 size_t snr_packed_bytes(int shape_blocks, int texture_blocks);
 int snr_pack_weights(const float* const* tensors, int n_tensors, int shape_blocks, int texture_blocks,
                      float* packed, void* stream);
-/* inverse map for training: scatter a packed-layout gradient buffer back to nn.Linear layout
- * (adds the forward-stream and nothing else); tensors as above. */
-int snr_unpack_weight_grads(const float* packed_grad, float* const* tensors, int n_tensors,
-                            int shape_blocks, int texture_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Decoder on explicit sample points: replaces SUPNeRF.forward / CodeNeRF.forward
@@ -257,11 +253,23 @@ int snr_pose_rays_fwd(const float* rot_vec, const float* trans_vec, const float*
 int snr_pose_rays_bwd(const float* rot_vec, const float* trans_vec, const float* cam_dirs, int64_t n_objects, int64_t rays_per_obj,
                       int opt_cam_pose, const float* d_rays_o, const float* d_viewdir, const float* d_cam2opt,
                       float* d_rot_vec, float* d_trans_vec, void* stream);
-/* The metric row the loop logs every iteration (:739-765): row (B,4) = [PSNR = -10 log10(loss_out[:,3]), mean |depth_pred - depth0| over
- * n_lidar pixels, rotation error rot_dist(pred_R, gt_R) (src/utils.py:713-722), translation error |pred_t - gt_T|]; gt_R (B,3,3), gt_T (B,3)
- * are the true OBJECT pose, cam2opt the current camera-in-object pose.  first != 0: depth0 <- depth_pred. */
+/* The same two launches for a caller that holds the camera pose itself -- what the public get_rays / render_rays_v2 do per call
+ * (src/utils.py:107-135 get_rays, :468-469 sphere bounds, :159-164 sample_from_rays' depth vector): c2w (B,3,4) row-major [R | t]
+ * -> rays_o / unit viewdir (B*n,3) and the stratified depths z_vals (B,S) [z_vals, half_diag, jitter nullable]; backward:
+ * d_rays_o, d_viewdir (B*n,3) [each nullable] -> d_c2w (B,3,4).  The depths are detached from the pose like the reference's. */
+int snr_cam_rays_fwd(const float* c2w, const float* cam_dirs, const float* half_diag, const float* jitter, int64_t n_objects,
+                     int64_t rays_per_obj, int n_samples, float* rays_o, float* viewdir, float* z_vals, void* stream);
+int snr_cam_rays_bwd(const float* c2w, const float* cam_dirs, int64_t n_objects, int64_t rays_per_obj, const float* d_rays_o,
+                     const float* d_viewdir, float* d_c2w, void* stream);
+/* The metric row the loop logs every iteration (:739-765): row (B,4) = [PSNR = -10 log10(loss_out[:,3]), depth error, rotation error
+ * rot_dist(pred_R, gt_R) (src/utils.py:713-722), translation error |pred_t - gt_T|]; gt_R (B,3,3), gt_T (B,3) are the true OBJECT pose,
+ * cam2opt the current camera-in-object pose.  Depth error of object b = sum_i |depth_pred[b,i] - depth0[b,i]| / (count_b + 1e-8) over its
+ * first count_b = lidar_count[b] (int32, nullable = n_lidar for every object) of the n_lidar columns: with depth0 = the lidar
+ * measurements and first = 0 this is log_eval_depth_v2 (src/optimizer_nuscenes.py:751-765,1736-1741); first != 0 stores
+ * depth0 <- depth_pred instead (objects without a depth map: the change of rendered depth against the first iteration is logged). */
 int snr_metric_row(const float* loss_out, const float* depth_pred, float* depth0, int n_lidar, int first, const float* cam2opt,
-                   const float* gt_R, const float* gt_T, int64_t n_objects, int opt_cam_pose, float* row, void* stream);
+                   const float* gt_R, const float* gt_T, int64_t n_objects, int opt_cam_pose, float* row, const int32_t* lidar_count,
+                   void* stream);
 /* torch.optim.AdamW's update (amsgrad off) of up to 4 parameter groups in one launch (:1762-1769): HOST arrays of n_groups device
  * pointers / element counts / learning rates; step = 1 for the first update. */
 int snr_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,

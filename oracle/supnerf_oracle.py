@@ -144,6 +144,25 @@ class _ReluWithGivenMask(torch.autograd.Function):
         return g * mask.to(g.dtype), None
 
 
+_GIVEN_RELU_MASKS = None
+
+
+class given_relu_masks:
+    """``with given_relu_masks(masks): ...`` -- every ``decoder_forward`` call inside (however deep: the render functions call it) takes
+    ``masks`` as its ``relu_masks``.  Tests only."""
+
+    def __init__(self, masks):
+        self.masks = masks
+
+    def __enter__(self):
+        global _GIVEN_RELU_MASKS
+        self.prev, _GIVEN_RELU_MASKS = _GIVEN_RELU_MASKS, self.masks
+
+    def __exit__(self, *exc):
+        global _GIVEN_RELU_MASKS
+        _GIVEN_RELU_MASKS = self.prev
+
+
 def decoder_forward(params: Dict[str, Tensor], xyz: Tensor, viewdir: Tensor,
                     shape_code: Tensor, texture_code: Tensor,
                     num_xyz_freq: int = 10, num_dir_freq: int = 4,
@@ -162,6 +181,8 @@ def decoder_forward(params: Dict[str, Tensor], xyz: Tensor, viewdir: Tensor,
     differentiates the same piecewise-linear function as that implementation, and the comparison can be tight.
     """
     relu_i = [0]
+    if relu_masks is None:
+        relu_masks = _GIVEN_RELU_MASKS
 
     def relu(t):
         if relu_masks is None:

@@ -47,7 +47,6 @@ _SIGS = {
     "snr_last_hip_error": (C.c_char_p, []),
     "snr_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "snr_pack_weights": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, _P, _P]),
-    "snr_unpack_weight_grads": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.c_int, _P]),
     "snr_mask_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "snr_precision_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64]),
     "snr_decoder_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
@@ -67,7 +66,9 @@ _SIGS = {
     "snr_weight_grad": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int, C.c_int64, _P, C.c_int64, _P, C.c_int, _P, C.c_size_t, _P]),
     "snr_pose_rays_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "snr_pose_rays_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P]),
-    "snr_metric_row": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int64, C.c_int, _P, _P]),
+    "snr_cam_rays_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P]),
+    "snr_cam_rays_bwd": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, _P, _P]),
+    "snr_metric_row": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int64, C.c_int, _P, _P, _P]),
     "snr_adamw_step": (C.c_int, [C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_float),
                                  C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
 }

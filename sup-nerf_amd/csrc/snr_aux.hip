@@ -37,17 +37,6 @@ __global__ void copy_pad_kernel(const float* __restrict__ src, int n, float* __r
     if (i < n_pad) dst[i] = (i < n) ? src[i] : 0.f;
 }
 
-// scatter-add of a packed forward-stream gradient back into nn.Linear layout
-__global__ void unpack_fwd_kernel(const float* __restrict__ src, int n_out, int k_in, int n_chunks, float* __restrict__ dW) {
-    const long long total = (long long)n_out * k_in;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % k_in);
-        const int row = (int)(i / k_in);
-        const int c = k / KC, kk = k % KC;
-        dW[i] = src[(long long)c * n_out * KC + chunk_pos(row, kk)];
-    }
-}
-
 // ============================================================================ composite
 __global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                                                             const float* __restrict__ zv, int z_mode, int flags, long long n_rays,
@@ -649,44 +638,6 @@ int snr_pack_weights(const float* const* t, int n_tensors, int sb, int tb, float
         int rc = snr_bf16_pack_(Wl, sb, tb, packed, stream_);
         if (rc != SNR_OK) return rc;
     }
-    return snr_check_launch_();
-}
-
-int snr_unpack_weight_grads(const float* pg, float* const* t, int n_tensors, int sb, int tb, void* stream_) {
-    if (!pg || !t || sb < 0 || tb < 0 || sb > MAX_BLOCKS || tb > MAX_BLOCKS) return SNR_E_ARG;
-    if (n_tensors != 2 * (sb + tb + 6)) return SNR_E_SHAPE;
-    hipStream_t st = (hipStream_t)stream_;
-    const Layout L = make_layout(sb, tb);
-    int ti = 0;
-    const float* f = pg + L.fwd;
-    auto un = [&](int idx, int n_out, int k_in, int n_chunks) {
-        if (t[2 * idx]) unpack_fwd_kernel<<<grid_for((long long)n_out * k_in), 256, 0, st>>>(f, n_out, k_in, n_chunks, t[2 * idx]);
-        f += (long long)n_chunks * n_out * KC;
-    };
-    auto vec = [&](float* dst, int n, long long off) {
-        if (dst) copy_pad_kernel<<<(n + 255) / 256, 256, 0, st>>>(pg + off, n, dst, n);
-    };
-    const int i_xyz = ti++;
-    int i_shape[MAX_BLOCKS]; for (int j = 0; j < sb; ++j) i_shape[j] = ti++;
-    const int i_encshape = ti++, i_sigma = ti++, i_view = ti++;
-    int i_tex[MAX_BLOCKS]; for (int j = 0; j < tb; ++j) i_tex[j] = ti++;
-    const int i_rgb0 = ti++, i_rgb2 = ti++;
-    un(i_xyz, 256, D_XYZ, 2);
-    for (int j = 0; j < sb; ++j) un(i_shape[j], 256, 256, 8);
-    un(i_encshape, 256, 256, 8);
-    un(i_view, 256, 256 + D_DIR, 9);
-    for (int j = 0; j < tb; ++j) un(i_tex[j], 256, 256, 8);
-    un(i_rgb0, 128, 256, 8);
-    vec(t[2 * i_xyz + 1], 256, L.bias + 256ll * layer_enc_xyz());
-    for (int j = 0; j < sb; ++j) vec(t[2 * i_shape[j] + 1], 256, L.bias + 256ll * layer_shape(j));
-    vec(t[2 * i_encshape + 1], 256, L.bias + 256ll * layer_enc_shape(sb));
-    vec(t[2 * i_view + 1], 256, L.bias + 256ll * layer_viewdir(sb));
-    for (int j = 0; j < tb; ++j) vec(t[2 * i_tex[j] + 1], 256, L.bias + 256ll * layer_texture(sb, j));
-    vec(t[2 * i_rgb0 + 1], 128, L.bias + 256ll * layer_rgb0(sb, tb));
-    vec(t[2 * i_sigma], 256, L.sigma_w);
-    vec(t[2 * i_sigma + 1], 1, L.sigma_b);
-    vec(t[2 * i_rgb2], 3 * 128, L.rgb2_w);
-    vec(t[2 * i_rgb2 + 1], 3, L.rgb2_b);
     return snr_check_launch_();
 }
 

@@ -155,11 +155,17 @@ __device__ __forceinline__ float box_jitter_rng(const RayGeom& g, long long i) {
     unsigned long long sub = (unsigned long long)i, round = 0;
     int word = 0;
     if (g.rng_threads) {
-        const unsigned long long per_round = g.rng_threads * 4ull;
-        round = (unsigned long long)i / per_round;
-        const unsigned long long r = (unsigned long long)i - round * per_round;
-        word = (int)(r / g.rng_threads);
-        sub = r - (unsigned long long)word * g.rng_threads;
+        if ((((unsigned long long)i | (g.rng_threads << 2)) >> 32) == 0) {       // every realistic launch: 32-bit divisions (a 64-bit one is ~150 instructions)
+            const uint32_t thr = (uint32_t)g.rng_threads, per_round = thr << 2, i32 = (uint32_t)i;
+            const uint32_t rd = i32 / per_round, r = i32 - rd * per_round, w = r / thr;
+            round = rd; word = (int)w; sub = r - w * thr;
+        } else {
+            const unsigned long long per_round = g.rng_threads * 4ull;
+            round = (unsigned long long)i / per_round;
+            const unsigned long long r = (unsigned long long)i - round * per_round;
+            word = (int)(r / g.rng_threads);
+            sub = r - (unsigned long long)word * g.rng_threads;
+        }
     }
     uint32_t w[4];
     philox4x32_10(g.rng_seed, g.rng_offset / 4ull + round, sub, w);
@@ -245,7 +251,7 @@ __device__ __forceinline__ SamplePoint make_sample(const RayGeom& g, long long r
     if (g.flags & SNR_METRIC_Z) {
         const float zs = g.z_scale[obj];
         float ex = __fmul_rn(__fsub_rn(px, ox), zs), ey = __fmul_rn(__fsub_rn(py, oy), zs), ez = __fmul_rn(__fsub_rn(pz, oz), zs);
-        sp.zc = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)));
+        sp.zc = sqrtf(__fmaf_rn(ez, ez, __fmaf_rn(ey, ey, __fmul_rn(ex, ex))));      // torch.norm's fma chain (CPU), src/renderer.py:114
     } else {
         sp.zc = t;
     }

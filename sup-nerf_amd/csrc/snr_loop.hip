@@ -56,37 +56,58 @@ __device__ __forceinline__ Pose make_pose(const float* rot_vec, const float* tra
     return p;
 }
 
-// one workgroup per object.  cam_dirs (B, n, 3) = [(px - cx)/fx, (py - cy)/fy, 1] of the object's pixels (constant over the loop).
-__global__ void __launch_bounds__(256) pose_rays_fwd_kernel(const float* __restrict__ rot_vec, const float* __restrict__ trans_vec,
+// the pose as the caller holds it: c2w (3,4) row-major = [R | t] (get_rays' argument, src/utils.py:107)
+__device__ __forceinline__ Pose pose_from_c2w(const float* c) {
+    Pose p;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) p.Rc[3 * i + j] = c[4 * i + j];
+        p.tc[i] = c[4 * i + 3];
+    }
+    return p;
+}
+
+// grid (B objects, chunks of RAYS_PER_BLOCK rays).  cam_dirs (B, n, 3) = [(px - cx)/fx, (py - cy)/fy, 1] of the object's pixels (constant over
+// the loop).  DIRECT: `pa` is the camera pose c2w (B,3,4) itself (the public get_rays / render_rays_v2 path); else (pa, pb) = (rot_vec, trans_vec).
+constexpr int RAYS_PER_BLOCK = 1024;
+template <bool DIRECT>
+__global__ void __launch_bounds__(256) pose_rays_fwd_kernel(const float* __restrict__ pa, const float* __restrict__ pb,
                                                             const float* __restrict__ cam_dirs, const float* __restrict__ half_diag,
                                                             const float* __restrict__ jitter, long long n, int S, int opt_cam_pose,
                                                             float* __restrict__ cam2opt, float* __restrict__ rays_o,
                                                             float* __restrict__ viewdir, float* __restrict__ z_vals) {
     const long long b = blockIdx.x;
-    const Pose p = make_pose(rot_vec + 3 * b, trans_vec + 3 * b, opt_cam_pose);
-    if (threadIdx.x < 12 && cam2opt) {
-        const int i = threadIdx.x / 4, j = threadIdx.x % 4;
-        cam2opt[b * 12 + threadIdx.x] = j < 3 ? p.Rc[3 * i + j] : p.tc[i];
+    const Pose p = DIRECT ? pose_from_c2w(pa + 12 * b) : make_pose(pa + 3 * b, pb + 3 * b, opt_cam_pose);
+    if (blockIdx.y == 0) {
+        if (threadIdx.x < 12 && cam2opt) {
+            const int i = threadIdx.x / 4, j = threadIdx.x % 4;
+            cam2opt[b * 12 + threadIdx.x] = j < 3 ? p.Rc[3 * i + j] : p.tc[i];
+        }
+        if (z_vals && threadIdx.x < S) {     // S <= 256 (checked by the launcher)
+            // near / far = |camera centre| -/+ diag/2, detached; two-sided linspace like torch.linspace (utils._linspace)
+            const float dist = sqrtf(p.tc[0] * p.tc[0] + p.tc[1] * p.tc[1] + p.tc[2] * p.tc[2]);
+            const float hd = half_diag[b];
+            const float near = dist - hd, far = dist + hd;
+            const float hw = (far - near) / (2.f * S);
+            const float start = near + hw, end = far - hw;
+            const float step = (end - start) / (float)(S > 1 ? S - 1 : 1);
+            const int k = threadIdx.x;
+            const float lin = (k < S / 2) ? start + step * (float)k : end - step * (float)(S - 1 - k);
+            z_vals[b * S + k] = lin + (jitter ? jitter[b * S + k] : 0.f) * hw;
+        }
     }
-    if (z_vals && threadIdx.x < S) {     // S <= 256 (checked by the launcher)
-        // near / far = |camera centre| -/+ diag/2, detached; two-sided linspace like torch.linspace (utils._linspace)
-        const float dist = sqrtf(p.tc[0] * p.tc[0] + p.tc[1] * p.tc[1] + p.tc[2] * p.tc[2]);
-        const float hd = half_diag[b];
-        const float near = dist - hd, far = dist + hd;
-        const float hw = (far - near) / (2.f * S);
-        const float start = near + hw, end = far - hw;
-        const float step = (end - start) / (float)(S > 1 ? S - 1 : 1);
-        const int k = threadIdx.x;
-        const float lin = (k < S / 2) ? start + step * (float)k : end - step * (float)(S - 1 - k);
-        z_vals[b * S + k] = lin + (jitter ? jitter[b * S + k] : 0.f) * hw;
-    }
-    for (long long i = threadIdx.x; i < n; i += 256) {
+    const long long i0 = (long long)blockIdx.y * RAYS_PER_BLOCK;
+    const long long i1 = i0 + RAYS_PER_BLOCK < n ? i0 + RAYS_PER_BLOCK : n;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
         const float* c = cam_dirs + (b * n + i) * 3;
         const float cx = c[0], cy = c[1], cz = c[2];
         float w[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) w[r] = __fadd_rn(__fadd_rn(__fmul_rn(cx, p.Rc[3 * r]), __fmul_rn(cy, p.Rc[3 * r + 1])), __fmul_rn(cz, p.Rc[3 * r + 2]));
-        const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(w[0], w[0]), __fmul_rn(w[1], w[1])), __fmul_rn(w[2], w[2])));
+        // torch.norm(world, dim=-1) on the CPU accumulates the squares as one fma chain in element order (checked against 1e5 vectors): the same
+        // chain here makes the rays bit-equal to the reference's for the same pose
+        const float nrm = sqrtf(__fmaf_rn(w[2], w[2], __fmaf_rn(w[1], w[1], __fmul_rn(w[0], w[0]))));
         float* vo = viewdir + (b * n + i) * 3;
         float* oo = rays_o + (b * n + i) * 3;
 #pragma unroll
@@ -103,40 +124,65 @@ __device__ __forceinline__ float block_sum256(float v, float* slot) {
     return s;
 }
 
+__device__ __forceinline__ double block_sum256d(double v, double* slot) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double s = (slot[0] + slot[1]) + (slot[2] + slot[3]);
+    __syncthreads();
+    return s;
+}
+
 // d(rays_o), d(viewdir) -> d(rot_vec), d(trans_vec); the depths are detached from the pose like the reference's .tolist() (src/utils.py:468)
+// DIRECT: (rot_vec, d_rot_vec) are the pose c2w (B,3,4) and its gradient (B,3,4) = [dL/dR | dL/dt]; trans_vec / d_trans_vec unused.
+template <bool DIRECT>
 __global__ void __launch_bounds__(256) pose_rays_bwd_kernel(const float* __restrict__ rot_vec, const float* __restrict__ trans_vec,
                                                             const float* __restrict__ cam_dirs, long long n, int opt_cam_pose,
                                                             const float* __restrict__ d_rays_o, const float* __restrict__ d_viewdir,
                                                             const float* __restrict__ d_cam2opt,
                                                             float* __restrict__ d_rot_vec, float* __restrict__ d_trans_vec) {
-    __shared__ float red[4];
+    __shared__ double redd[4];
     const long long b = blockIdx.x;
-    const Pose p = make_pose(rot_vec + 3 * b, trans_vec + 3 * b, opt_cam_pose);
-    float gR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gt[3] = {0.f, 0.f, 0.f};
+    const Pose p = DIRECT ? pose_from_c2w(rot_vec + 12 * b) : make_pose(rot_vec + 3 * b, trans_vec + 3 * b, opt_cam_pose);
+    // The direction's gradient is projected off the direction, gu - u (u . gu): d_viewdir is dominated by its component ALONG u (points are
+    // o + t d), so the projection cancels most of it and fp32 keeps few digits of the rest.  Per-ray math and the sums over the rays run in
+    // double (a few dozen flops per ray: nothing on this chip), so this kernel adds no rounding noise of its own to the pose gradient.
+    double gRd[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.}, gtd[3] = {0., 0., 0.};
     for (long long i = threadIdx.x; i < n; i += 256) {
         const float* c = cam_dirs + (b * n + i) * 3;
-        const float cd[3] = {c[0], c[1], c[2]};
-        float w[3];
+        const double cd[3] = {c[0], c[1], c[2]};
+        double w[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) w[r] = cd[0] * p.Rc[3 * r] + cd[1] * p.Rc[3 * r + 1] + cd[2] * p.Rc[3 * r + 2];
-        const float inv = 1.f / sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-        const float u[3] = {w[0] * inv, w[1] * inv, w[2] * inv};
-        float gu[3] = {0.f, 0.f, 0.f};
+        for (int r = 0; r < 3; ++r) w[r] = cd[0] * (double)p.Rc[3 * r] + cd[1] * (double)p.Rc[3 * r + 1] + cd[2] * (double)p.Rc[3 * r + 2];
+        const double inv = 1.0 / sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        const double u[3] = {w[0] * inv, w[1] * inv, w[2] * inv};
+        double gu[3] = {0., 0., 0.};
         if (d_viewdir) { const float* g = d_viewdir + (b * n + i) * 3; gu[0] = g[0]; gu[1] = g[1]; gu[2] = g[2]; }
-        const float dot = u[0] * gu[0] + u[1] * gu[1] + u[2] * gu[2];
+        const double dot = u[0] * gu[0] + u[1] * gu[1] + u[2] * gu[2];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const float gw = (gu[r] - u[r] * dot) * inv;
+            const double gw = (gu[r] - u[r] * dot) * inv;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) gR[3 * r + j] += gw * cd[j];
+            for (int j = 0; j < 3; ++j) gRd[3 * r + j] += gw * cd[j];
         }
-        if (d_rays_o) { const float* g = d_rays_o + (b * n + i) * 3; gt[0] += g[0]; gt[1] += g[1]; gt[2] += g[2]; }
+        if (d_rays_o) { const float* g = d_rays_o + (b * n + i) * 3; gtd[0] += g[0]; gtd[1] += g[1]; gtd[2] += g[2]; }
     }
+    float gR[9], gt[3];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) gR[i] = block_sum256(gR[i], red);
+    for (int i = 0; i < 9; ++i) gR[i] = (float)block_sum256d(gRd[i], redd);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) gt[i] = block_sum256(gt[i], red);
+    for (int i = 0; i < 3; ++i) gt[i] = (float)block_sum256d(gtd[i], redd);
     if (threadIdx.x != 0) return;
+    if (DIRECT) {         // the pose is the leaf: its gradient is [sum_i gw_i cd_i^T | sum_i d_rays_o_i]
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) d_rot_vec[b * 12 + 4 * i + j] = gR[3 * i + j];
+            d_rot_vec[b * 12 + 4 * i + 3] = gt[i];
+        }
+        return;
+    }
     if (d_cam2opt) {      // a caller that also used the (3,4) pose itself
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -197,11 +243,14 @@ __global__ void __launch_bounds__(256) pose_rays_bwd_kernel(const float* __restr
 __global__ void __launch_bounds__(64) metric_row_kernel(const float* __restrict__ loss_out /* (B,4): mse_fg in column 3 */,
                                                         const float* __restrict__ d_vec, float* __restrict__ depth0, int n_lidar, int first,
                                                         const float* __restrict__ cam2opt, const float* __restrict__ gt_R,
-                                                        const float* __restrict__ gt_T, int opt_cam_pose, float* __restrict__ row) {
+                                                        const float* __restrict__ gt_T, int opt_cam_pose, float* __restrict__ row,
+                                                        const int32_t* __restrict__ lidar_count) {
     const long long b = blockIdx.x;
     const int lane = threadIdx.x;
     float s = 0.f;
-    for (int i = lane; i < n_lidar; i += 64) {
+    // every object averages ITS OWN depth pixels: the first lidar_count[b] of the n_lidar columns (the rest is padding)
+    const int cnt = lidar_count ? min(max(lidar_count[b], 0), n_lidar) : n_lidar;
+    for (int i = lane; i < cnt; i += 64) {
         const float d = d_vec[b * n_lidar + i];
         if (first) depth0[b * n_lidar + i] = d;
         s += fabsf(d - (first ? d : depth0[b * n_lidar + i]));
@@ -224,7 +273,7 @@ __global__ void __launch_bounds__(64) metric_row_kernel(const float* __restrict_
     const float ang = acosf(fminf(fmaxf((tr - 1.f) * 0.5f, -1.f), 1.f));
     const float ex = pt[0] - gt_T[b * 3], ey = pt[1] - gt_T[b * 3 + 1], ez = pt[2] - gt_T[b * 3 + 2];
     row[b * 4 + 0] = -10.f * log10f(loss_out[b * 4 + 3]);
-    row[b * 4 + 1] = n_lidar > 0 ? s / (float)n_lidar : 0.f;
+    row[b * 4 + 1] = s / ((float)cnt + 1e-8f);           // np.sum(depth_errs) / (len(gt_depth_vec) + 1e-8), src/optimizer_nuscenes.py:1741
     row[b * 4 + 2] = ang;
     row[b * 4 + 3] = sqrtf(ex * ex + ey * ey + ez * ez);
 }
@@ -265,8 +314,31 @@ int snr_pose_rays_fwd(const float* rot_vec, const float* trans_vec, const float*
     if (!rot_vec || !trans_vec || !cam_dirs || !rays_o || !viewdir) return SNR_E_ARG;
     if (n_objects < 0 || rays_per_obj < 0) return SNR_E_ARG;
     if (z_vals && (!half_diag || n_samples < 1 || n_samples > 256)) return SNR_E_ARG;
-    pose_rays_fwd_kernel<<<(unsigned)n_objects, 256, 0, (hipStream_t)stream>>>(rot_vec, trans_vec, cam_dirs, half_diag, jitter, rays_per_obj,
-                                                                               n_samples, opt_cam_pose, cam2opt, rays_o, viewdir, z_vals);
+    const unsigned chunks = (unsigned)((rays_per_obj + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
+    pose_rays_fwd_kernel<false><<<dim3((unsigned)n_objects, chunks ? chunks : 1), 256, 0, (hipStream_t)stream>>>(
+        rot_vec, trans_vec, cam_dirs, half_diag, jitter, rays_per_obj, n_samples, opt_cam_pose, cam2opt, rays_o, viewdir, z_vals);
+    return snr_check_launch_();
+}
+
+int snr_cam_rays_fwd(const float* c2w, const float* cam_dirs, const float* half_diag, const float* jitter, int64_t n_objects,
+                     int64_t rays_per_obj, int n_samples, float* rays_o, float* viewdir, float* z_vals, void* stream) {
+    if (n_objects == 0) return SNR_OK;
+    if (!c2w || !cam_dirs || !rays_o || !viewdir) return SNR_E_ARG;
+    if (n_objects < 0 || rays_per_obj < 0) return SNR_E_ARG;
+    if (z_vals && (!half_diag || n_samples < 1 || n_samples > 256)) return SNR_E_ARG;
+    const unsigned chunks = (unsigned)((rays_per_obj + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
+    pose_rays_fwd_kernel<true><<<dim3((unsigned)n_objects, chunks ? chunks : 1), 256, 0, (hipStream_t)stream>>>(
+        c2w, nullptr, cam_dirs, half_diag, jitter, rays_per_obj, n_samples, 1, nullptr, rays_o, viewdir, z_vals);
+    return snr_check_launch_();
+}
+
+int snr_cam_rays_bwd(const float* c2w, const float* cam_dirs, int64_t n_objects, int64_t rays_per_obj, const float* d_rays_o,
+                     const float* d_viewdir, float* d_c2w, void* stream) {
+    if (n_objects == 0) return SNR_OK;
+    if (!c2w || !cam_dirs || !d_c2w) return SNR_E_ARG;
+    if (n_objects < 0 || rays_per_obj < 0) return SNR_E_ARG;
+    pose_rays_bwd_kernel<true><<<(unsigned)n_objects, 256, 0, (hipStream_t)stream>>>(c2w, nullptr, cam_dirs, rays_per_obj, 1, d_rays_o, d_viewdir,
+                                                                                     nullptr, d_c2w, nullptr);
     return snr_check_launch_();
 }
 
@@ -276,18 +348,19 @@ int snr_pose_rays_bwd(const float* rot_vec, const float* trans_vec, const float*
     if (n_objects == 0) return SNR_OK;
     if (!rot_vec || !trans_vec || !cam_dirs || (!d_rot_vec && !d_trans_vec)) return SNR_E_ARG;
     if (n_objects < 0 || rays_per_obj < 0) return SNR_E_ARG;
-    pose_rays_bwd_kernel<<<(unsigned)n_objects, 256, 0, (hipStream_t)stream>>>(rot_vec, trans_vec, cam_dirs, rays_per_obj, opt_cam_pose,
-                                                                               d_rays_o, d_viewdir, d_cam2opt, d_rot_vec, d_trans_vec);
+    pose_rays_bwd_kernel<false><<<(unsigned)n_objects, 256, 0, (hipStream_t)stream>>>(rot_vec, trans_vec, cam_dirs, rays_per_obj, opt_cam_pose,
+                                                                                      d_rays_o, d_viewdir, d_cam2opt, d_rot_vec, d_trans_vec);
     return snr_check_launch_();
 }
 
 int snr_metric_row(const float* loss_out, const float* depth_pred, float* depth0, int n_lidar, int first, const float* cam2opt,
-                   const float* gt_R, const float* gt_T, int64_t n_objects, int opt_cam_pose, float* row, void* stream) {
+                   const float* gt_R, const float* gt_T, int64_t n_objects, int opt_cam_pose, float* row, const int32_t* lidar_count,
+                   void* stream) {
     if (n_objects == 0) return SNR_OK;
     if (!loss_out || !cam2opt || !gt_R || !gt_T || !row || n_objects < 0 || n_lidar < 0) return SNR_E_ARG;
     if (n_lidar > 0 && (!depth_pred || !depth0)) return SNR_E_ARG;
     metric_row_kernel<<<(unsigned)n_objects, 64, 0, (hipStream_t)stream>>>(loss_out, depth_pred, depth0, n_lidar, first, cam2opt, gt_R, gt_T,
-                                                                           opt_cam_pose, row);
+                                                                           opt_cam_pose, row, lidar_count);
     return snr_check_launch_();
 }
 

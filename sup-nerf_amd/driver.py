@@ -39,13 +39,20 @@ DEFAULT_HPAMS = {     # the keys of jsonfiles/supnerf.nusc.vehicle.car.json that
 KITTI_OVERRIDES = {"roi_margin": 15, "dataset": {"name": "kitti", "mask_pixels": 1600, "max_dist": 40, "min_depth": 3}}
 
 
+# jsonfiles/supnerf.waymo.car.json: optimize_waymo.py runs the KITTI-convention loop (labels converted by obj_pose_kitti2nusc,
+# src/optimizer_waymo.py:125,140: roi_margin 15, sq_pad) on 1920 x 1280 images (tests/golden/waymo.json holds the reference file's values)
+WAYMO_OVERRIDES = {"roi_margin": 15, "dataset": {"name": "waymo", "mask_pixels": 2500, "max_dist": 40, "min_depth": 3, "min_lidar_cnt": 10}}
+
+
 def load_hpams(path: Optional[str] = None, dataset: str = "nusc") -> dict:
     """Read a reference config file (jsonfiles/*.json) -- same keys, verbatim -- or the shipped defaults of ``dataset``
-    ('nusc' | 'kitti')."""
+    ('nusc' | 'kitti' | 'waymo')."""
     if path is None:
         hp = json.loads(json.dumps(DEFAULT_HPAMS))
         if dataset == "kitti":
             hp.update(json.loads(json.dumps(KITTI_OVERRIDES)))
+        elif dataset == "waymo":
+            hp.update(json.loads(json.dumps(WAYMO_OVERRIDES)))
         elif dataset != "nusc":
             raise ValueError(f"unknown dataset {dataset!r}")
         return hp
@@ -143,7 +150,7 @@ def losses(rgb_rays, acc_trans_rays, rgb_tgt, occ_pixels, loss_occ_coef):
 
 
 def optimize_object(model, device, obj: Dict, hpams: dict, shapecode0, texturecode0, pose_noise=(0.05, 0.3), reg_iters=3,
-                    n_lidar=64, seed=0, log=None, jitter=None):
+                    n_lidar=64, seed=0, log=None, jitter=None, info: Optional[dict] = None):
     """Optimise codes and object pose of one object against its (synthetic) target.  Returns a metric tensor
     (num_opts, 4) = [psnr, depth_err, rot_err, trans_err] per iteration, and the final codes / pose.
 
@@ -152,17 +159,17 @@ def optimize_object(model, device, obj: Dict, hpams: dict, shapecode0, textureco
     CPU generator, in order.  ``optimize_object_api`` is the same loop written against the public functions, call for call like the
     reference (needed for ``sym_aug``, which flips a python coin inside every render call, for foreign decoders and for ``log``)."""
     if not U._is_native(model) or hpams.get("sym_aug", 0) or log is not None or not U.ops.fused_supported(hpams["n_samples"]):
-        return optimize_object_api(model, device, obj, hpams, shapecode0, texturecode0, pose_noise, reg_iters, n_lidar, seed, log, jitter)
+        return optimize_object_api(model, device, obj, hpams, shapecode0, texturecode0, pose_noise, reg_iters, n_lidar, seed, log, jitter, info)
     T, S = hpams["optimize"]["num_opts"], hpams["n_samples"]
     if jitter is None:
         jitter = torch.stack([torch.stack([torch.rand(S), torch.rand(S)]) for _ in range(T)]) if T else torch.zeros(0, 2, S)
     m, sc, tc, pose = optimize_objects_batched(model, device, [obj], hpams, shapecode0, texturecode0, [seed], pose_noise, reg_iters, n_lidar,
-                                               jitter=jitter[:, :, None, :])
+                                               jitter=jitter[:, :, None, :], info=info)
     return m[0].cpu(), sc, tc, pose[0]
 
 
 def optimize_object_api(model, device, obj: Dict, hpams: dict, shapecode0, texturecode0, pose_noise=(0.05, 0.3), reg_iters=3,
-                        n_lidar=64, seed=0, log=None, jitter=None):
+                        n_lidar=64, seed=0, log=None, jitter=None, info: Optional[dict] = None):
     """``optimize_object`` through the public render API, one call per reference call (src/optimizer_nuscenes.py:674-783): ~350 launches
     per iteration, host-bound at one object."""
     opt = hpams["optimize"]
@@ -183,14 +190,14 @@ def optimize_object_api(model, device, obj: Dict, hpams: dict, shapecode0, textu
     texturecode = texturecode0.detach().clone().to(dev).requires_grad_()
     lr = {k: opt[k] for k in ("lr_shape", "lr_texture", "lr_pose")}
     optim = make_optimizer(shapecode, texturecode, rot_vec, trans_vec, lr)
-    # synthetic "lidar" pixels inside the foreground mask, with the true depth along the ray unknown offline: the
-    # metric logged is the change of rendered depth against the first iteration (keeps the 2nd forward of the loop)
-    ys, xs = np.where(mask[:, :, 0].numpy() > 0)
-    pick = rs.permutation(len(ys))[:n_lidar]
-    y_vec, x_vec = ys[pick], xs[pick]
+    # the depth pixels: the object's lidar returns with their measured depths (the reference's metric, :751-765), or -- synthetic objects
+    # without a depth map -- random foreground pixels, the metric then being the change of rendered depth against the first iteration
+    x_vec, y_vec, gt_depth = _lidar_pixels(obj, rs, n_lidar)
+    if info is not None:
+        info["lidar_count"] = torch.tensor([len(x_vec)], dtype=torch.int32)
     metrics = torch.zeros(opt["num_opts"], 4, device=dev)      # stays on the device: the reference's per-iteration .item() logging
     gt_dev = gt_pose.to(dev)                                    # would put three host syncs into every iteration
-    depth0 = None
+    depth0 = None if gt_depth is None else torch.from_numpy(gt_depth).to(dev)
     for it in range(opt["num_opts"]):
         optim.zero_grad()
         if jitter is not None:                                   # (num_opts, 2, S): the two draws of this iteration (tests)
@@ -215,7 +222,7 @@ def optimize_object_api(model, device, obj: Dict, hpams: dict, shapecode0, textu
                 depth0 = d_vec.clone()
             pred_R = cam2opt[:, :3].detach().T if not opt.get("opt_cam_pose", 0) else cam2opt[:, :3].detach()
             pred_t = (-pred_R @ cam2opt[:, 3:].detach()) if not opt.get("opt_cam_pose", 0) else cam2opt[:, 3:].detach()
-            row = torch.stack([-10 * torch.log10(mse_fg.detach()), (d_vec - depth0).abs().mean(),
+            row = torch.stack([-10 * torch.log10(mse_fg.detach()), (d_vec - depth0).abs().sum() / (len(x_vec) + 1e-8),     # (log_eval_depth_v2, :1736-1741)
                                rot_dist(pred_R, gt_dev[:, :3]), (pred_t - gt_dev[:, 3:]).norm()])
         metrics[it] = row
         if it > reg_iters:
@@ -232,177 +239,46 @@ def optimize_object_api(model, device, obj: Dict, hpams: dict, shapecode0, textu
 
 
 # ------------------------------------------------------------------ many objects per launch (BASELINE config 3)
-def _rays_batch(K, c2w, px, py):
-    """Batched twin of utils._pixel_dirs: K (B,3,3), c2w (B,3,4), pixel coordinates px, py (B,n) -> rays_o, viewdir (B*n,3)."""
-    cx, cy, fx, fy = K[:, 0, 2:3], K[:, 1, 2:3], K[:, 0, 0:1], K[:, 1, 1:2]
-    cam = torch.stack([(px - cx) / fx, (py - cy) / fy, torch.ones_like(px)], -1)                  # (B,n,3)
-    world = (cam[:, :, None, :] * c2w[:, None, :3, :3]).sum(-1)
-    unit = world / torch.norm(world, dim=-1, keepdim=True)
-    origin = c2w[:, None, :3, 3].expand(world.shape)
-    return origin.reshape(-1, 3), unit.reshape(-1, 3)
-
-
 def optimize_objects_batched(model, device, objs: List[Dict], hpams: dict, shapecodes0, texturecodes0, seeds: Sequence[int],
-                             pose_noise=(0.05, 0.3), reg_iters=3, n_lidar=64, jitter=None, graph=False, device_optimizer=None):
-    """The iteration of ``optimize_object`` for B objects at once: ONE fused forward, one backward and one 64-pixel
-    depth render per iteration for all of them (per-object codes, poses, depth tables and targets; the loss is the sum
-    of the per-object losses, so every object sees exactly its own gradient), AdamW over the stacked leaves, metrics
-    kept on the device until the end -- no host round trip inside the loop.  Jitter: ``jitter`` (num_opts, 2, B, S) or,
-    by default, drawn up front from one CPU generator per object (seeded like the per-object loop seeds its RandomState).
-    ``graph=True`` records the iteration once as a HIP graph (``torch.cuda.graphs``; two graphs: without and with the AdamW step)
-    and replays it -- at small B the eager loop is bound by the ~150 host-side launches of an iteration, not by the GPU.  The
-    graphed loop uses a capturable AdamW (learning rates and step count on the device) whose state is reset in place where the
-    reference re-creates its optimiser; ``device_optimizer=True`` selects that optimiser without the graph (its arithmetic differs
-    from the host-side AdamW in the last bits, which twenty optimisation steps amplify: the tests compare like with like).
-    Returns metrics (B, num_opts, 4), shape codes, texture codes, poses (B,3,4)."""
-    opt = hpams["optimize"]
-    S, im_sz, T = hpams["n_samples"], hpams["render_im_sz"], opt["num_opts"]
+                             pose_noise=(0.05, 0.3), reg_iters=3, n_lidar=64, jitter=None, info: Optional[dict] = None):
+    """The iteration of ``optimize_object`` for B objects at once: ONE fused forward, one backward and one depth render of the lidar pixels
+    per iteration for all of them (per-object codes, poses, depth tables and targets; the loss is the sum of the per-object losses, so
+    every object sees exactly its own gradient), AdamW over the stacked leaves in one launch, metrics kept on the device until the end --
+    no host round trip inside the loop (``_optimize_fused``: ~24 launches per iteration for any B).  Jitter: ``jitter``
+    (num_opts, 2, B, S) or, by default, drawn up front from one CPU generator per object (seeded like the per-object loop seeds its
+    RandomState).  ``info`` (optional dict) receives ``lidar_count`` (B,): the number of depth pixels behind every object's depth metric.
+    Returns metrics (B, num_opts, 4), shape codes, texture codes, poses (B,3,4).
+    (Round 2 also carried a HIP-graph replay of the torch-op iteration; it lost to this eager fused loop, 2.3 vs 1.3 ms per iteration, and
+    is gone.)"""
     dev = torch.device(device)
-    B, n = len(objs), im_sz * im_sz
     if hpams.get("sym_aug", 0):
         raise U.SnrError("optimize_objects_batched: sym_aug draws one python coin per object and iteration; use optimize_object")
-    if not graph and not device_optimizer:
-        return _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, pose_noise, reg_iters, n_lidar, jitter)
-    rot0, tr0, gtR, gtT, px, py, lx, ly, tgt, occ = [], [], [], [], [], [], [], [], [], []
-    for ob, seed in zip(objs, seeds):
-        rs = np.random.RandomState(seed)
-        R_gt = ob["cam_pose"][:, :3].T
-        t_gt = -R_gt @ ob["cam_pose"][:, 3:]
-        rot0.append(matrix_to_axis_angle(R_gt[None]) + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[0])
-        tr0.append(t_gt.T + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[1])
-        gtR.append(R_gt); gtT.append(t_gt)
-        ys, xs = np.where(ob["mask"][:, :, 0].numpy() > 0)
-        pick = rs.permutation(len(ys))[:n_lidar]
-        x0, y0, x1, y1 = [int(v) for v in ob["roi"]]
-        lx.append(torch.from_numpy((xs[pick] + x0).astype(np.float32))); ly.append(torch.from_numpy((ys[pick] + y0).astype(np.float32)))
-        gx, gy = torch.linspace(x0, x1 - 1, im_sz), torch.linspace(y0, y1 - 1, im_sz)
-        px.append(gx[None, :].expand(im_sz, im_sz).reshape(-1)); py.append(gy[:, None].expand(im_sz, im_sz).reshape(-1))
-        im, mk = U._resize(ob["img"], ob["mask"], im_sz)
-        tgt.append(im.reshape(-1, 3)); occ.append(mk.reshape(-1, 1))
-    n_lidar = min(len(v) for v in lx)            # one launch needs the same count for every object: the smallest foreground decides
-    if n_lidar == 0:
-        raise U.SnrError("optimize_objects_batched: an object has no foreground pixel")
-    lx, ly = [v[:n_lidar] for v in lx], [v[:n_lidar] for v in ly]
-    st = lambda xs_: torch.stack(xs_).to(dev)
-    K = st([ob["K"] for ob in objs]); diag = torch.tensor([float(ob["obj_diag"]) for ob in objs], device=dev)
-    px, py, lx, ly, tgt, occ, gtR, gtT = st(px), st(py), st(lx), st(ly), st(tgt), st(occ), st(gtR), st(gtT)
-    rot_vec = torch.cat(rot0).to(dev).requires_grad_(); trans_vec = torch.cat(tr0).to(dev).requires_grad_()
-    shapecode = shapecodes0.detach().clone().to(dev).requires_grad_(); texturecode = texturecodes0.detach().clone().to(dev).requires_grad_()
-    if jitter is None:
-        gens = [torch.Generator().manual_seed(int(s_)) for s_ in seeds]
-        jitter = torch.stack([torch.rand(T, 2, S, generator=g) for g in gens], dim=2)
-    jitter = jitter.to(dev)
-    lr = {k: opt[k] for k in ("lr_shape", "lr_texture", "lr_pose")}
-    dev_opt = graph if device_optimizer is None else (device_optimizer or graph)
-    if dev_opt:     # lr as device tensors so that the halvings reach the recorded optimiser step
-        optim = torch.optim.AdamW([{"params": shapecode, "lr": torch.tensor(float(lr["lr_shape"]), device=dev)},
-                                   {"params": texturecode, "lr": torch.tensor(float(lr["lr_texture"]), device=dev)},
-                                   {"params": rot_vec, "lr": torch.tensor(float(lr["lr_pose"]), device=dev)},
-                                   {"params": trans_vec, "lr": torch.tensor(float(lr["lr_pose"]), device=dev)}], capturable=True)
-    else:
-        optim = make_optimizer(shapecode, texturecode, rot_vec, trans_vec, lr)
-    frame = U._frame(False, False, hpams["shapenet_obj_cood"])
-    sb, tb = getattr(model, "shape_blocks", 0), getattr(model, "texture_blocks", 0)
-    a = torch.abs(occ); denom = a.sum(dim=(1, 2)) + 1e-9; fg = occ.clamp_min(0); fg_denom = fg.sum(dim=(1, 2)) + 1e-9
-    metrics = torch.zeros(T, B, 4, device=dev)
-    half = diag / 2
-    idx = torch.arange(S, device=dev, dtype=torch.float32)[None, :]
-    jit_cur = torch.empty(2, B, S, device=dev)            # this iteration's two jitter draws (a fixed address for the recorded graph)
-    depth0 = torch.zeros(B, n_lidar, device=dev)
-    row = torch.zeros(B, 4, device=dev)
-    pose = torch.zeros(B, 3, 4, device=dev)
+    return _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, pose_noise, reg_iters, n_lidar, jitter, info)
 
-    def iteration(first: bool, do_step: bool):
-        optim.zero_grad(set_to_none=not dev_opt)
-        R = axis_angle_to_matrix(rot_vec)
-        t = trans_vec.unsqueeze(-1)
-        if not opt.get("opt_cam_pose", 0):
-            Rc = R.transpose(-2, -1)
-            cam2opt = torch.cat([Rc, -Rc @ t], -1)
-        else:
-            cam2opt = torch.cat([R, t], -1)
-        dist = cam2opt[:, :, 3].detach().norm(dim=-1)
-        near, far = (dist - half)[:, None], (dist + half)[:, None]
 
-        def render(pxx, pyy, jit, rays_per_obj):
-            rays_o, viewdir = _rays_batch(K, cam2opt, pxx, pyy)
-            hw = (far - near) / (2 * S)                          # (B,S) twin of utils._shared_depths incl. its two-sided linspace
-            start, end = near + hw, far - hw
-            step = (end - start) / max(S - 1, 1)
-            z = torch.where(idx < S // 2, start + step * idx, end - step * (S - 1 - idx)) + jit * hw
-            cfg = U.ops.RenderCfg(S, U.ops.Z_PER_OBJECT, rays_per_obj, sb, tb, frame=frame, precision=None)
-            return model.fused_render(rays_o, viewdir, z.contiguous(), diag, None, shapecode, texturecode, cfg)
-        rgb, depth, acc = render(px, py, jit_cur[0], n)
-        rgb, acc = rgb.view(B, n, 3), acc.view(B, n, 1)
-        sq = (rgb - tgt) ** 2
-        loss_rgb = (sq * a).sum(dim=(1, 2)) / denom
-        loss_occ = (torch.exp(-occ * (0.5 - acc)) * a).sum(dim=(1, 2)) / denom
-        (loss_rgb + hpams["loss_occ_coef"] * loss_occ).sum().backward()
-        with torch.no_grad():
-            mse_fg = (sq.detach() * fg).sum(dim=(1, 2)) / fg_denom
-            d_vec = render(lx, ly, jit_cur[1], n_lidar)[1].view(B, n_lidar)
-            if first:
-                depth0.copy_(d_vec)
-            c = cam2opt.detach()
-            pred_R = c[:, :, :3].transpose(-2, -1) if not opt.get("opt_cam_pose", 0) else c[:, :, :3]
-            pred_t = -pred_R @ c[:, :, 3:] if not opt.get("opt_cam_pose", 0) else c[:, :, 3:]
-            row.copy_(torch.stack([-10 * torch.log10(mse_fg), (d_vec - depth0).abs().mean(dim=1), rot_dist(pred_R, gtR),
-                                   (pred_t - gtT).flatten(1).norm(dim=1)], dim=1))
-            pose.copy_(c)
-        if do_step:
-            optim.step()
-
-    def restart_optimizer(scale: float):
-        """What re-creating the optimiser does (src/optimizer_nuscenes.py:1771-1775), in place: fresh moments and step count,
-        every learning rate times ``scale``."""
-        for grp in optim.param_groups:
-            grp["lr"].mul_(scale)
-        for st_ in optim.state.values():
-            st_["step"].zero_(); st_["exp_avg"].zero_(); st_["exp_avg_sq"].zero_()
-
-    graphs = {}
-    for it in range(T):
-        jit_cur.copy_(jitter[it])
-        do_step = it > reg_iters
-        if not graph or it == 0:
-            iteration(it == 0, do_step)
-        else:
-            if do_step not in graphs:
-                if do_step and not optim.state:          # create the AdamW state outside the recording: a step with lr = 0 changes nothing
-                    saved = [grp["lr"].clone() for grp in optim.param_groups]
-                    for grp in optim.param_groups:
-                        grp["lr"].zero_()
-                    optim.step()
-                    for grp, v in zip(optim.param_groups, saved):
-                        grp["lr"].copy_(v)
-                    restart_optimizer(1.0)
-                g_ = torch.cuda.CUDAGraph()
-                torch.cuda.synchronize()
-                with torch.cuda.graph(g_):
-                    iteration(False, do_step)
-                graphs[do_step] = g_
-            graphs[do_step].replay()
-        metrics[it].copy_(row)
-        if (it + 1) % opt["lr_half_interval"] == 0:
-            halvings = (it + 1) // opt["lr_half_interval"]
-            if dev_opt:
-                if optim.state:
-                    restart_optimizer(2.0 ** (-halvings))
-                else:
-                    for grp in optim.param_groups:
-                        grp["lr"].mul_(2.0 ** (-halvings))
-            else:
-                lr = {k: v * 2 ** (-halvings) for k, v in lr.items()}
-                optim = make_optimizer(shapecode, texturecode, rot_vec, trans_vec, lr)
-    return metrics.permute(1, 0, 2).contiguous(), shapecode.detach(), texturecode.detach(), pose.clone()
+def _lidar_pixels(ob, rs, n_lidar):
+    """The pixels of the crop whose depth the loop logs every iteration, and their measured depths when the object carries them.
+    With ``ob["lidar_xy"]`` (n,2 integer crop pixels x, y) and ``ob["lidar_depth"]`` (n,): the reference's metric -- every lidar return
+    on the foreground mask, depth L1 against the measurement (src/optimizer_nuscenes.py:751-765,1736-1741).  Without (synthetic objects
+    with no depth map): ``n_lidar`` random foreground pixels, and the metric is the change of rendered depth against iteration 0."""
+    if ob.get("lidar_xy") is not None:
+        xy = np.asarray(ob["lidar_xy"]).reshape(-1, 2).astype(np.int64)
+        depth = np.asarray(ob["lidar_depth"], dtype=np.float32).reshape(-1)
+        if depth.shape[0] != xy.shape[0]:
+            raise U.SnrError("object: lidar_xy (n,2) and lidar_depth (n,) disagree")
+        return xy[:, 0], xy[:, 1], depth
+    ys, xs = np.where(ob["mask"][:, :, 0].numpy() > 0)
+    pick = rs.permutation(len(ys))[:n_lidar]
+    return xs[pick], ys[pick], None
 
 
 def _loop_inputs(objs, seeds, hpams, pose_noise, n_lidar, dev):
     """Per-object constants of the loop, built once on the host and moved to the device: perturbed start pose, ground truth, the pixel
-    direction tables [(px-cx)/fx, (py-cy)/fy, 1] of the render grid and of the "lidar" pixels, resized targets (the reference resizes
-    the same crop again in every iteration, src/utils.py:447-456)."""
+    direction tables [(px-cx)/fx, (py-cy)/fy, 1] of the render grid and of the lidar pixels (every object keeps ITS OWN count: the tables
+    are padded to the largest, the metric kernel averages each object's first ``lid_cnt`` entries), measured depths when the objects
+    carry them, resized targets (the reference resizes the same crop again in every iteration, src/utils.py:447-456)."""
     im_sz = hpams["render_im_sz"]
-    rot0, tr0, gtR, gtT, cam, lid, tgt, occ = [], [], [], [], [], [], [], []
+    rot0, tr0, gtR, gtT, cam, lid, lid_d, tgt, occ = [], [], [], [], [], [], [], [], []
     for ob, seed in zip(objs, seeds):
         rs = np.random.RandomState(seed)
         R_gt = ob["cam_pose"][:, :3].T
@@ -410,27 +286,36 @@ def _loop_inputs(objs, seeds, hpams, pose_noise, n_lidar, dev):
         rot0.append(matrix_to_axis_angle(R_gt[None]) + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[0])
         tr0.append(t_gt.T + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[1])
         gtR.append(R_gt); gtT.append(t_gt.reshape(3))
-        ys, xs = np.where(ob["mask"][:, :, 0].numpy() > 0)
-        pick = rs.permutation(len(ys))[:n_lidar]
+        x_vec, y_vec, depth = _lidar_pixels(ob, rs, n_lidar)
         x0, y0, x1, y1 = [int(v) for v in ob["roi"]]
         K = ob["K"]
         cx, cy, fx, fy = K[0, 2], K[1, 2], K[0, 0], K[1, 1]
         gx, gy = torch.linspace(x0, x1 - 1, im_sz), torch.linspace(y0, y1 - 1, im_sz)
         px, py = gx[None, :].expand(im_sz, im_sz).reshape(-1), gy[:, None].expand(im_sz, im_sz).reshape(-1)
         cam.append(torch.stack([(px - cx) / fx, (py - cy) / fy, torch.ones_like(px)], -1))
-        lx, ly = torch.from_numpy(xs[pick] + x0), torch.from_numpy(ys[pick] + y0)         # integer pixels, like get_rays_specified
-        lid.append(torch.stack([(lx - cx) / fx, (ly - cy) / fy, torch.ones_like(lx, dtype=torch.float32)], -1))
+        lx, ly = torch.from_numpy(x_vec + x0), torch.from_numpy(y_vec + y0)         # integer pixels, like get_rays_specified
+        lid.append(torch.stack([(lx - cx) / fx, (ly - cy) / fy, torch.ones_like(lx, dtype=torch.float32)], -1).float().reshape(-1, 3))
+        lid_d.append(None if depth is None else torch.from_numpy(depth))
         im, mk = U._resize(ob["img"], ob["mask"], im_sz)
         tgt.append(im.reshape(-1, 3)); occ.append(mk.reshape(-1))
-    n_l = min(v.shape[0] for v in lid)           # one launch needs the same count for every object: the smallest foreground decides
+    has_depth = [d is not None for d in lid_d]
+    if any(has_depth) and not all(has_depth):
+        raise U.SnrError("optimize_objects_batched: either every object of a batch carries lidar_xy / lidar_depth or none does")
+    cnt = [v.shape[0] for v in lid]
+    n_l = max(cnt) if cnt else 0
     if n_l == 0:
-        raise U.SnrError("optimize_objects_batched: an object has no foreground pixel")
+        raise U.SnrError("optimize_objects_batched: no object has a depth pixel (empty foreground / no lidar return)")
+    one_ray = torch.tensor([[0.0, 0.0, 1.0]])
+
+    def pad(v, width):          # (the padding rays are rendered and ignored: a valid direction, depth 0)
+        return torch.cat([v, (one_ray if width == 3 else torch.zeros(1)).expand(n_l - v.shape[0], *([3] if width == 3 else []))]) if v.shape[0] < n_l else v
     st = lambda xs_: torch.stack(xs_).to(dev).contiguous()
-    return dict(rot0=torch.cat(rot0).to(dev), tr0=torch.cat(tr0).to(dev), gtR=st(gtR), gtT=st(gtT), cam=st(cam), lid=st([v[:n_l] for v in lid]),
+    return dict(rot0=torch.cat(rot0).to(dev), tr0=torch.cat(tr0).to(dev), gtR=st(gtR), gtT=st(gtT), cam=st(cam), lid=st([pad(v, 3) for v in lid]),
+                lid_depth=st([pad(d, 1) for d in lid_d]) if all(has_depth) else None, lid_cnt=torch.tensor(cnt, dtype=torch.int32, device=dev),
                 tgt=st(tgt), occ=st(occ), diag=torch.tensor([float(ob["obj_diag"]) for ob in objs], device=dev), n_lidar=n_l)
 
 
-def _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, pose_noise, reg_iters, n_lidar, jitter):
+def _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, pose_noise, reg_iters, n_lidar, jitter, info=None):
     """The iteration as ~30 launches for any number of objects: pose -> rays + depths (one launch), the per-object layers (two GEMMs),
     fused render, loss tail (one launch), backward = their four backward launches, the 64-pixel depth render, the metric row (one
     launch), AdamW over the four parameter groups (one launch).  Nothing reads back until the loop has finished."""
@@ -455,7 +340,10 @@ def _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, 
     opt_cam = int(bool(opt.get("opt_cam_pose", 0)))
     coef = float(hpams["loss_occ_coef"])
     metrics = torch.zeros(T, B, 4, device=dev)
-    depth0 = torch.zeros(B, n_l, device=dev)
+    measured = c["lid_depth"] is not None
+    depth0 = c["lid_depth"] if measured else torch.zeros(B, n_l, device=dev)       # measured depths, or the rendered depths of iteration 0
+    if info is not None:
+        info["lidar_count"] = c["lid_cnt"].clone()
     ones = torch.ones(B, device=dev)
     pose = torch.zeros(B, 3, 4, device=dev)
     cfg = ops.RenderCfg(S, ops.Z_PER_OBJECT, n, sb, tb, frame=frame, precision=model.precision)
@@ -476,7 +364,8 @@ def _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, 
                 c2o, lo, lv, lz = ops.PoseRays.apply(rot_vec.detach(), trans_vec.detach(), c["lid"], half, jitter[it, 1], S, opt_cam)
                 d_vec = ops.render_fwd(lo, lv, lz, c["diag"], None, lat.detach(), packed, cfg_l)[1]
                 out4 = torch.cat([loss.detach()[:, None], lm], dim=1)
-                ops.metric_row(out4, d_vec.view(B, n_l), depth0, it == 0, c2o, c["gtR"], c["gtT"], opt_cam, metrics[it])
+                ops.metric_row(out4, d_vec.view(B, n_l), depth0, it == 0 and not measured, c2o, c["gtR"], c["gtT"], opt_cam, metrics[it],
+                               lidar_count=c["lid_cnt"])
                 if it == T - 1:
                     pose.copy_(c2o)
             if it > reg_iters:
@@ -490,7 +379,9 @@ def _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, 
     return metrics.permute(1, 0, 2).contiguous(), shapecode.detach(), texturecode.detach(), pose
 
 
-def make_objects(ids: Sequence[int], im_sz: int) -> List[Dict]:
+def make_objects(ids: Sequence[int], im_sz: int, lidar: bool = False) -> List[Dict]:
+    """Synthetic nuScenes-like objects.  ``lidar``: also a synthetic set of lidar returns on the foreground (``lidar_xy`` (n,2) crop pixels,
+    ``lidar_depth`` (n,) metres; n differs from object to object like real sweeps), which switches the loop's depth metric to the reference's."""
     out = []
     for i in ids:
         ob = synthetic.synthetic_object(i)
@@ -498,6 +389,9 @@ def make_objects(ids: Sequence[int], im_sz: int) -> List[Dict]:
         # the reference whitens the background of the crop (src/optimizer_nuscenes.py:711-713)
         img = img * (mask > 0) + (mask <= 0)
         ob.update(img=img, mask=mask, index=i)
+        if lidar:
+            xy, depth = synthetic.synthetic_lidar(i, mask, ob)
+            ob.update(lidar_xy=xy, lidar_depth=depth)
         out.append(ob)
     return out
 
@@ -510,8 +404,10 @@ def make_kitti_objects(ids: Sequence[int], hpams: dict) -> List[Dict]:
     after that the render path is the nuScenes one (the ``kitti2nusc=`` flag of the render functions stays False)."""
     out = []
     margin = hpams.get("roi_margin", 15)
+    waymo = hpams.get("dataset", {}).get("name") == "waymo"      # the same loop on 1920 x 1280 images (src/optimizer_waymo.py:125-140)
     for i in ids:
-        ob = synthetic.synthetic_kitti_object(i)
+        ob = synthetic.synthetic_kitti_object(i, K=synthetic.WAYMO_K, im_w=synthetic.WAYMO_IM_W, im_h=synthetic.WAYMO_IM_H) if waymo \
+            else synthetic.synthetic_kitti_object(i)
         pose_nusc = U.obj_pose_kitti2nusc(ob["obj_pose"][None].clone(), torch.tensor([float(ob["wlh"][2])]))[0]
         R_c2o = pose_nusc[:, :3].T
         cam_pose = torch.cat([R_c2o, -R_c2o @ pose_nusc[:, 3:]], -1)
@@ -525,14 +421,16 @@ def make_kitti_objects(ids: Sequence[int], hpams: dict) -> List[Dict]:
 
 
 def optimize_objects(model, device, n_objects: int, hpams: Optional[dict] = None, rank: int = 0, world_size: int = 1, seed: int = 0,
-                     group=None, batch: int = 64, dataset: str = "nusc"):
+                     group=None, batch: int = 64, dataset: str = "nusc", return_counts: bool = False, lidar: bool = False):
     """Shard ``n_objects`` synthetic objects over the ranks, optimise the local slice ``batch`` objects per launch
     (``batch=1``: the reference's one-object-at-a-time loop with its global random streams), all-gather the metric rows.
-    Returns (n_objects, num_opts*4) on every rank."""
+    Returns (n_objects, num_opts*4) on every rank; with ``return_counts`` a last column holds every object's depth-pixel count (the
+    ``lidar_pts_cnt`` of the saved results).  ``lidar``: the synthetic objects carry lidar returns with measured depths, so the depth
+    column is the reference's depth L1 (src/optimizer_nuscenes.py:751-765)."""
     hpams = hpams or load_hpams(dataset=dataset)
     mine = list(shard_slice(n_objects, world_size, rank))
-    objs = make_kitti_objects(mine, hpams) if dataset == "kitti" else make_objects(mine, hpams["render_im_sz"])
-    rows = []
+    objs = make_kitti_objects(mine, hpams) if dataset in ("kitti", "waymo") else make_objects(mine, hpams["render_im_sz"], lidar=lidar)
+    rows, counts = [], []
 
     def start_codes(index):
         g = torch.Generator().manual_seed(seed * 7919 + index)
@@ -540,16 +438,20 @@ def optimize_objects(model, device, n_objects: int, hpams: Optional[dict] = None
     if batch <= 1 or hpams.get("sym_aug", 0) or not U._is_native(model):
         for ob in objs:
             sc, tc = start_codes(ob["index"])
-            m, *_ = optimize_object(model, device, ob, hpams, sc, tc, seed=seed * 7919 + ob["index"])
-            rows.append(m.reshape(-1))
+            info = {}
+            m, *_ = optimize_object(model, device, ob, hpams, sc, tc, seed=seed * 7919 + ob["index"], info=info)
+            rows.append(m.reshape(-1)); counts += info["lidar_count"].tolist()
     else:
         for i in range(0, len(objs), batch):
             part = objs[i:i + batch]
             codes = [start_codes(ob["index"]) for ob in part]
+            info = {}
             m, *_ = optimize_objects_batched(model, device, part, hpams, torch.cat([c[0] for c in codes]), torch.cat([c[1] for c in codes]),
-                                             [seed * 7919 + ob["index"] for ob in part])
-            rows += list(m.reshape(len(part), -1).cpu())
-    n_cols = hpams["optimize"]["num_opts"] * 4
+                                             [seed * 7919 + ob["index"] for ob in part], info=info)
+            rows += list(m.reshape(len(part), -1).cpu()); counts += info["lidar_count"].tolist()
+    n_cols = hpams["optimize"]["num_opts"] * 4 + (1 if return_counts else 0)
     dev = torch.device(device)
+    if return_counts:
+        rows = [torch.cat([r, torch.tensor([float(c)])]) for r, c in zip(rows, counts)]
     local = torch.stack(rows).to(dev) if rows else torch.zeros(0, n_cols, device=dev)
     return gather_metric_rows(local, torch.tensor(mine, device=dev, dtype=torch.float32), n_objects, group)

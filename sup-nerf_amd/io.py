@@ -56,24 +56,31 @@ def save_opts_w_pose(save_dir: str, num_obj: int, shapecodes: dict, texturecodes
     return path
 
 
-def metric_rows_to_eval_dicts(metrics: torch.Tensor, ids, cam_id: int = 0, n_lidar: int = 64):
+def metric_rows_to_eval_dicts(metrics: torch.Tensor, ids, cam_id: int = 0, n_lidar=64):
     """(n_objects, num_opts*4) rows of ``driver.optimize_objects`` -> the per-iteration metric dicts of the reference, with the element
     types its reader relies on (``collect_eval_results``, src/utils.py:786-880): ``psnr_eval`` / ``depth_err_mean`` lists of floats
     (``np.array(list)[:max_iter]``), ``R_eval`` / ``T_eval`` lists of 0-dim tensors (``torch.stack(list)``, they come from
-    ``calc_pose_err``, src/optimizer_nuscenes.py:1694-1702), ``lidar_pts_cnt`` one count per key (the weights of the depth-error mean).
-    Returns (psnr_eval, depth_err_mean, R_eval, T_eval, lidar_pts_cnt)."""
+    ``calc_pose_err``, src/optimizer_nuscenes.py:1694-1702), ``lidar_pts_cnt`` one count per key (the weights of the depth-error mean:
+    ``n_lidar`` is the per-object count array the driver reports -- ``info["lidar_count"]`` / ``optimize_objects(return_counts=True)`` --
+    or one integer for all).  Returns (psnr_eval, depth_err_mean, R_eval, T_eval, lidar_pts_cnt)."""
+    ids = list(ids)
     m = metrics.view(metrics.shape[0], -1, 4).cpu()
+    counts = [int(n_lidar)] * len(ids) if isinstance(n_lidar, (int, float)) else [int(v) for v in torch.as_tensor(n_lidar).reshape(-1).tolist()]
+    if len(counts) != len(ids) or m.shape[0] != len(ids):
+        raise ValueError(f"metric_rows_to_eval_dicts: {m.shape[0]} metric rows, {len(ids)} ids, {len(counts)} lidar counts")
     psnr, depth, R, T, cnt = {}, {}, {}, {}, {}
-    for row, i in zip(m, ids):
+    for row, i, n_i in zip(m, ids, counts):
         key = f"{i}_{cam_id}"
         psnr[key], depth[key] = row[:, 0].tolist(), row[:, 1].tolist()
         R[key], T[key] = list(row[:, 2].clone().unbind(0)), list(row[:, 3].clone().unbind(0))
-        cnt[key] = int(n_lidar)
+        cnt[key] = n_i
     return psnr, depth, R, T, cnt
 
 
 def save_driver_results(save_dir: str, metrics: torch.Tensor, ids, shapecodes=None, texturecodes=None, poses=None, cam_id: int = 0,
-                        n_lidar: int = 64) -> str:
-    """``driver.optimize_objects`` output -> ``codes+poses.pth`` that ``scripts/eval_saved_result.py`` plots unchanged."""
+                        n_lidar=64) -> str:
+    """``driver.optimize_objects`` output -> ``codes+poses.pth`` that ``scripts/eval_saved_result.py`` plots unchanged.  ``n_lidar``: the
+    per-object depth-pixel counts the driver reports (or one integer for all)."""
+    ids = list(ids)                          # (a generator would be empty after the first pass)
     psnr, depth, R, T, cnt = metric_rows_to_eval_dicts(metrics, ids, cam_id, n_lidar)
-    return save_opts_w_pose(save_dir, len(list(ids)), shapecodes or {}, texturecodes or {}, poses or {}, psnr, depth, R, T, lidar_pts_cnt=cnt)
+    return save_opts_w_pose(save_dir, len(ids), shapecodes or {}, texturecodes or {}, poses or {}, psnr, depth, R, T, lidar_pts_cnt=cnt)

@@ -303,18 +303,67 @@ class PoseRays(torch.autograd.Function):
         return d_rot, d_tr, None, None, None, None, None
 
 
-def metric_row(loss_out, depth_pred, depth0, first, cam2opt, gt_R, gt_T, opt_cam_pose, row):
-    """row (B,4) <- [PSNR, mean |depth_pred - depth0|, rotation error, translation error] (src/optimizer_nuscenes.py:739-765)."""
-    _need_gpu(loss_out, depth_pred, depth0, cam2opt, gt_R, gt_T, row)
+class CamRays(torch.autograd.Function):
+    """Camera pose -> rays of a pixel table (+ the stratified depth vector), one launch; backward one launch.  What the public
+    ``get_rays`` / ``render_rays_v2`` need per call (src/utils.py:107-135,159-164,468-469) when the pose lives on the GPU.
+    c2w (B,3,4); cam_dirs (B,n,3) = [(px-cx)/fx, (py-cy)/fy, 1]; half_diag (B,) or None; jitter (B,S) or None
+    -> rays_o (B*n,3), viewdir (B*n,3), z_vals (B,S) [None when half_diag is None; detached from the pose like the reference's]."""
+
+    @staticmethod
+    def forward(ctx, c2w, cam_dirs, half_diag, jitter, n_samples):
+        c2w, cam_dirs, half_diag, jitter = [_f32c(t) for t in (c2w, cam_dirs, half_diag, jitter)]
+        _need_gpu(c2w, cam_dirs, half_diag, jitter)
+        B, n = cam_dirs.shape[0], cam_dirs.shape[1]
+        if c2w.shape != (B, 3, 4) or cam_dirs.shape[-1] != 3 or (half_diag is not None and half_diag.numel() != B) or \
+                (jitter is not None and jitter.shape != (B, n_samples)):
+            raise SnrError("cam_rays: expected c2w (B,3,4), cam_dirs (B,n,3), half_diag (B,), jitter (B,S)")
+        dev = cam_dirs.device
+        ctx.set_materialize_grads(False)
+        rays_o, viewdir = torch.empty(B * n, 3, device=dev), torch.empty(B * n, 3, device=dev)
+        z = torch.empty(B, n_samples, device=dev) if half_diag is not None else None
+        with torch.cuda.device(dev):
+            check(_lib.lib().snr_cam_rays_fwd(_p(c2w), _p(cam_dirs), _p(half_diag), _p(jitter), B, n, int(n_samples), _p(rays_o), _p(viewdir), _p(z),
+                                              _stream(dev)), "snr_cam_rays_fwd")
+        ctx.save_for_backward(c2w, cam_dirs)
+        if z is not None:
+            ctx.mark_non_differentiable(z)
+        return rays_o, viewdir, z
+
+    @staticmethod
+    def backward(ctx, d_rays_o, d_viewdir, _d_z):
+        c2w, cam_dirs = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise SnrError("cam_rays: the pixel direction table is data, no gradient is provided")
+        if d_rays_o is None and d_viewdir is None:
+            return None, None, None, None, None
+        B, n = cam_dirs.shape[0], cam_dirs.shape[1]
+        dev = cam_dirs.device
+        d_rays_o, d_viewdir = _f32c(d_rays_o), _f32c(d_viewdir)
+        d_c2w = torch.empty_like(c2w)
+        with torch.cuda.device(dev):
+            check(_lib.lib().snr_cam_rays_bwd(_p(c2w), _p(cam_dirs), B, n, _p(d_rays_o), _p(d_viewdir), _p(d_c2w), _stream(dev)), "snr_cam_rays_bwd")
+        return d_c2w, None, None, None, None
+
+
+def metric_row(loss_out, depth_pred, depth0, first, cam2opt, gt_R, gt_T, opt_cam_pose, row, lidar_count=None):
+    """row (B,4) <- [PSNR, depth error over each object's first ``lidar_count`` pixels, rotation error, translation error]
+    (src/optimizer_nuscenes.py:739-765); depth0 = the measured depths (first = False) or a buffer that receives the rendered depths of
+    the first iteration (first = True)."""
+    _need_gpu(loss_out, depth_pred, depth0, cam2opt, gt_R, gt_T, row, lidar_count)
     B = cam2opt.shape[0]
     n_lidar = depth_pred.shape[-1] if depth_pred is not None else 0
     for t in (loss_out, depth_pred, depth0, cam2opt, gt_R, gt_T, row):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
             raise SnrError("metric_row: fp32 contiguous tensors expected")
+    if lidar_count is not None and (lidar_count.dtype != torch.int32 or lidar_count.numel() != B or not lidar_count.is_contiguous()):
+        raise SnrError("metric_row: lidar_count must be a contiguous int32 (B,) tensor")
+    if n_lidar and (depth_pred.numel() != B * n_lidar or depth0 is None or depth0.numel() != B * n_lidar):
+        raise SnrError("metric_row: depth_pred / depth0 must both be (B, n_lidar)")
     dev = cam2opt.device
     with torch.cuda.device(dev):
         check(_lib.lib().snr_metric_row(_p(loss_out), _p(depth_pred), _p(depth0), int(n_lidar), int(bool(first)), _p(cam2opt), _p(gt_R), _p(gt_T),
-                                        B, int(bool(opt_cam_pose)), _p(row), _stream(dev)), "snr_metric_row")
+                                        B, int(bool(opt_cam_pose)), _p(row), C.c_void_p(0 if lidar_count is None else lidar_count.data_ptr()),
+                                        _stream(dev)), "snr_metric_row")
     return row
 
 

@@ -11,6 +11,8 @@ WLH_MEAN = np.array([1.94, 4.64, 1.71], dtype=np.float32)      # src/optimizer_n
 WLH_STD = np.array([0.19, 0.46, 0.25], dtype=np.float32)
 NUSC_K = np.array([[1266.4, 0.0, 816.3], [0.0, 1266.4, 491.5], [0.0, 0.0, 1.0]], dtype=np.float32)
 KITTI_K = np.array([[721.5, 0.0, 609.6], [0.0, 721.5, 172.9], [0.0, 0.0, 1.0]], dtype=np.float32)
+WAYMO_K = np.array([[2055.6, 0.0, 939.7], [0.0, 2055.6, 641.1], [0.0, 0.0, 1.0]], dtype=np.float32)      # a typical FRONT camera, 1920 x 1280
+WAYMO_IM_W, WAYMO_IM_H = 1920, 1280
 
 
 def decoder_layer_shapes(shape_blocks=3, texture_blocks=1, W=256, latent_dim=256, d_xyz=63, d_dir=27):
@@ -119,3 +121,20 @@ def synthetic_crop_targets(index, h, w):
     mask = torch.where(r < 1.0, torch.ones_like(r), -torch.ones_like(r))
     mask = torch.where((r >= 1.0) & (r < 1.3), torch.zeros_like(r), mask)
     return img, mask[..., None]
+
+
+def synthetic_lidar(index, mask, ob):
+    """Synthetic lidar returns on the foreground of a crop: ``xy`` (n,2) integer crop pixels (x, y) and ``depth`` (n,) metres, what the
+    reference cuts out of its projected depth map (src/optimizer_nuscenes.py:751-754: ``gt_depth_map > 0`` on the mask).  The count differs
+    from object to object like real sweeps (40 + 13 (index mod 5), capped by the foreground); depths lie on a smooth bump in front of the
+    object's centre plus 2 cm of range noise."""
+    rs = np.random.RandomState(9000 + index)
+    ys, xs = np.where(mask[:, :, 0].numpy() > 0)
+    n = min(40 + 13 * (index % 5), len(ys))
+    pick = rs.permutation(len(ys))[:n]
+    x, y = xs[pick], ys[pick]
+    h, w = mask.shape[0], mask.shape[1]
+    r2 = ((x / max(w - 1, 1)) * 2 - 1) ** 2 + ((y / max(h - 1, 1)) * 2 - 1) ** 2
+    dist = float(np.linalg.norm(ob["cam_pose"][:, 3].numpy()))
+    depth = dist - 0.3 * float(ob["obj_diag"]) * (1.0 - 0.5 * r2) + 0.02 * rs.randn(n)
+    return np.stack([x, y], axis=1).astype(np.int64), depth.astype(np.float32)

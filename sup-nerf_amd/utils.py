@@ -51,8 +51,17 @@ def _cam_table(K, px, py, like, key=None):
     return cam if key is None else _cache_put(_CAM_CACHE, key, cam)
 
 
+def _fusable_pose(c2w):
+    """The one-launch ray kernels take a single fp32 (3,4) / (4,4) pose that lives on the GPU."""
+    return torch.is_tensor(c2w) and c2w.is_cuda and c2w.dim() == 2 and c2w.shape[0] >= 3 and c2w.shape[1] == 4 and c2w.dtype == torch.float32
+
+
 def _pixel_dirs(K, c2w, px, py, key=None):
     cam = _cam_table(K, px, py, c2w, key)
+    if _fusable_pose(c2w) and cam.numel() > 0:
+        # pose on the GPU: rotate + normalise + broadcast the origin in ONE launch (backward: one launch), instead of ~6 + ~10 torch launches
+        rays_o, viewdir, _ = ops.CamRays.apply(c2w[:3, :].unsqueeze(0), cam.reshape(1, -1, 3), None, None, 0)
+        return rays_o, viewdir
     world = (cam[..., None, :] * c2w[..., :3, :3]).sum(-1)
     unit = world / torch.norm(world, dim=-1, keepdim=True)
     origin = c2w[..., :3, -1].expand(world.shape)
@@ -179,6 +188,56 @@ def _sym_coin(sym_aug):
     return bool(sym_aug) and random.uniform(0, 1) > 0.5
 
 
+_CONST_CACHE = {}
+
+
+def _const(value, n, device):
+    """(n,) fp32 device tensor filled with ``value``, cached (object sizes do not change between the calls of a loop)."""
+    key = (float(value), int(n), str(device))
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        if len(_CONST_CACHE) >= 256:
+            _CONST_CACHE.pop(next(iter(_CONST_CACHE)))
+        t = _CONST_CACHE[key] = torch.full((int(n),), float(value), device=device)
+    return t
+
+
+def clear_caches():
+    """Drop the cached camera tables, resized targets and per-object constants (they pin device memory)."""
+    _CAM_CACHE.clear(); _TGT_CACHE.clear(); _CONST_CACHE.clear()
+
+
+def _draw_jitter(n_samples, device):
+    """The ``torch.rand(S)`` draw of ``sample_from_rays`` (src/utils.py:162) from the same CPU generator, uploaded without a host sync."""
+    jitter = _jitter_override()
+    if jitter is None:
+        jitter = torch.rand(n_samples, pin_memory=torch.device(device).type == "cuda")
+    return jitter.to(device, non_blocking=True)
+
+
+def _rays_and_depths(K, cam_pose, roi, uv_steps, obj_diag, n_samples, ids=None):
+    """Rays of the roi's pixel grid (optionally the subset ``ids``) and the shared depth vector: what render_rays{,_v2} / render_full_img
+    compute before the render (src/utils.py:445,462-470 + sample_from_rays :159-164).  Pose on the GPU: ONE launch (camera table cached,
+    rotation + normalisation + sphere bounds + two-sided linspace + jitter in ``snr_cam_rays_fwd``, backward one launch)."""
+    if _fusable_pose(cam_pose):
+        x0, y0, x1, y1 = [int(v) for v in roi]
+        nx, ny = (int(uv_steps[0]), int(uv_steps[1])) if uv_steps is not None else (x1 - x0, y1 - y0)
+        xs, ys = torch.linspace(x0, x1 - 1, nx), torch.linspace(y0, y1 - 1, ny)
+        cam = _cam_table(K, xs[None, :].expand(ny, nx), ys[:, None].expand(ny, nx), cam_pose, key=("grid", x0, y0, x1, y1, nx, ny)).reshape(-1, 3)
+        if ids is not None:
+            cam = cam[torch.as_tensor(ids, device=cam.device)]
+        if cam.shape[0] > 0:
+            dev = cam_pose.device
+            rays_o, viewdir, z = ops.CamRays.apply(cam_pose[:3, :].unsqueeze(0), cam.unsqueeze(0), _const(float(obj_diag) / 2, 1, dev),
+                                                   _draw_jitter(n_samples, dev).reshape(1, n_samples), n_samples)
+            return rays_o, viewdir, z[0]
+    rays_o, viewdir = get_rays(K, cam_pose, roi, uv_steps=uv_steps)
+    if ids is not None:
+        rays_o, viewdir = rays_o[ids], viewdir[ids]
+    near, far = _sphere_bounds(cam_pose, obj_diag)
+    return rays_o, viewdir, _shared_depths(near, far, n_samples, rays_o.device)
+
+
 # ------------------------------------------------------------------------------------ composite
 def _composite(sigmas, rgbs, z_vals, z_mode, white_bkgd, rays_per_obj=0):
     sig = sigmas.squeeze(-1) if sigmas.dim() == rgbs.dim() else sigmas
@@ -238,7 +297,7 @@ def _render_shared_z(model, device, rays_o, viewdir, z, obj_diag, frame, shapeco
     dev = torch.device(device)
     rays_o, viewdir, z = rays_o.to(dev), viewdir.to(dev), z.to(dev)
     B = shapecode.shape[0]
-    div = torch.full((B,), float(obj_diag), device=dev)
+    div = _const(obj_diag, B, dev)
     cfg = ops.RenderCfg(S, Z_SHARED, rays_o.shape[0] // B, getattr(model, "shape_blocks", 0), getattr(model, "texture_blocks", 0),
                         frame=frame, precision=None)
     if rays_o.shape[0] == 0:
@@ -260,14 +319,12 @@ def _render_shared_z(model, device, rays_o, viewdir, z, obj_diag, frame, shapeco
 def render_rays(model, device, img, mask_occ, cam_pose, obj_diag, K, roi, n_samples, shapecode, texturecode, shapenet_obj_cood,
                 sym_aug, kitti2nusc=False, n_rays=2500):
     """src/utils.py:380-432: a random subset of n_rays pixels of the full roi."""
-    rays_o, viewdir = get_rays(K, cam_pose, roi)
-    n_rays = int(np.minimum(rays_o.shape[0], n_rays))
-    ids = np.random.permutation(rays_o.shape[0])[:n_rays]
-    rays_o, viewdir = rays_o[ids], viewdir[ids]
+    n_all = int(roi[2] - roi[0]) * int(roi[3] - roi[1])
+    n_rays = int(np.minimum(n_all, n_rays))
+    ids = np.random.permutation(n_all)[:n_rays]
+    rays_o, viewdir, z = _rays_and_depths(K, cam_pose, roi, None, obj_diag, n_samples, ids=ids)
     rgb_tgt = img.reshape(-1, 3)[ids].to(device)
     occ_pixels = mask_occ.reshape(-1, 1)[ids].to(device)
-    near, far = _sphere_bounds(cam_pose, obj_diag)
-    z = _shared_depths(near, far, n_samples, rays_o.device)
     frame = _frame(_sym_coin(sym_aug), kitti2nusc, shapenet_obj_cood)
     rgb, depth, acc = _render_shared_z(model, device, rays_o, viewdir, z, obj_diag, frame, shapecode, texturecode)
     return rgb, depth, acc, rgb_tgt, occ_pixels
@@ -276,14 +333,14 @@ def render_rays(model, device, img, mask_occ, cam_pose, obj_diag, K, roi, n_samp
 def render_rays_v2(model, device, img, mask_occ, cam_pose, obj_diag, K, roi, n_samples, shapecode, texturecode, shapenet_obj_cood,
                    sym_aug, kitti2nusc=False, im_sz=64, n_rays=None):
     """src/utils.py:435-502: im_sz x im_sz grid over the roi (the optimisers' render call)."""
-    rays_o, viewdir = get_rays(K, cam_pose, roi, uv_steps=[im_sz, im_sz])
     rgb_tgt, occ_pixels = _resize_to(img, mask_occ, im_sz, device)
+    ids = None
     if n_rays is not None:
-        n_rays = int(np.minimum(rays_o.shape[0], n_rays))
-        ids = np.random.permutation(rays_o.shape[0])[:n_rays]
-        rays_o, viewdir, rgb_tgt, occ_pixels = rays_o[ids], viewdir[ids], rgb_tgt[ids], occ_pixels[ids]
-    near, far = _sphere_bounds(cam_pose, obj_diag)
-    z = _shared_depths(near, far, n_samples, rays_o.device)
+        n_all = int(im_sz) * int(im_sz)
+        n_rays = int(np.minimum(n_all, n_rays))
+        ids = np.random.permutation(n_all)[:n_rays]
+        rgb_tgt, occ_pixels = rgb_tgt[ids], occ_pixels[ids]
+    rays_o, viewdir, z = _rays_and_depths(K, cam_pose, roi, [im_sz, im_sz], obj_diag, n_samples, ids=ids)
     frame = _frame(_sym_coin(sym_aug), kitti2nusc, shapenet_obj_cood)
     rgb, depth, acc = _render_shared_z(model, device, rays_o, viewdir, z, obj_diag, frame, shapecode, texturecode)
     return rgb, depth, acc, rgb_tgt, occ_pixels
@@ -335,11 +392,9 @@ def render_full_img(model, device, cam_pose, obj_sz, K, roi, n_samples, shapecod
     slabs of max(roi_w, roi_h) rays to bound activation memory; the fused kernel keeps activations in registers, so
     the whole roi is one launch."""
     obj_diag = np.linalg.norm(obj_sz).astype(np.float32)
-    rays_o, viewdir = get_rays(K, cam_pose, roi)
-    near, far = _sphere_bounds(cam_pose, obj_diag)
-    z = _shared_depths(near, far, n_samples, rays_o.device)
     frame = _frame(False, kitti2nusc, shapenet_obj_cood)
     with torch.no_grad():
+        rays_o, viewdir, z = _rays_and_depths(K, cam_pose, roi, None, obj_diag, n_samples)
         rgb, depth, acc = _render_shared_z(model, device, rays_o, viewdir, z, obj_diag, frame, shapecode, texturecode)
     h, w = int(roi[3] - roi[1]), int(roi[2] - roi[0])
     if debug_occ:

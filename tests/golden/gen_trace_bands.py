@@ -1,0 +1,53 @@
+"""Generates tests/golden/trace_bands.npz: 100-iteration optimise traces of 8 synthetic objects on the CPU oracle (16 x 16 rays x 64
+samples, the reference's loop: tests/loop_oracle.py) in float64 and in float32, same start pose, same jitter.
+
+Why: the loop is chaotic in the last bits (Adam divides by the running gradient magnitude; the pose has a soft direction), so two correct
+fp32 implementations drift apart over 100 iterations.  How far is measured here instead of guessed: |fp32 oracle - fp64 oracle| per object
+and iteration is what fp32 rounding alone does to the trace of the REFERENCE's own arithmetic.  tests/test_full_size.py holds the GPU
+loops (both arithmetics) to a band derived from these numbers, against the float64 traces.
+
+Run from the repository root (CPU only, ~5 minutes on 8 cores):   python tests/golden/gen_trace_bands.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from loop_oracle import oracle_loop          # noqa: E402
+from oracle import supnerf_oracle as O        # noqa: E402
+import supnerf_amd                            # noqa: E402
+
+OBJECTS = list(range(21, 29))
+IM, N_IT, SEED, REG = 16, 100, 9, 3
+
+
+def main():
+    D = supnerf_amd.driver
+    params = O.init_decoder_params(seed=0, sigma_bias=-2.0)
+    hp = D.load_hpams(); hp["render_im_sz"] = IM; hp["optimize"]["num_opts"] = N_IT
+    out = {"objects": np.array(OBJECTS), "im_sz": np.array(IM), "seed": np.array(SEED), "reg_iters": np.array(REG)}
+    for k, idx in enumerate(OBJECTS):
+        obj = D.make_objects([idx], IM)[0]
+        g = torch.Generator().manual_seed(6 + k)
+        sc0, tc0 = torch.randn(1, 256, generator=g) * 0.3, torch.randn(1, 256, generator=g) * 0.3
+        jit = torch.rand(N_IT, 2, 64, generator=g)
+        t0 = time.time()
+        r32 = oracle_loop(params, obj, hp, sc0, tc0, SEED, REG, (0.05, 0.3), D, jit, dtype=torch.float32)
+        r64 = oracle_loop(params, obj, hp, sc0, tc0, SEED, REG, (0.05, 0.3), D, jit, dtype=torch.float64)
+        d = np.abs(r32 - r64).max(axis=0)
+        print(f"object {idx}: fp32 vs fp64 oracle loop, max over 100 iterations: PSNR {d[0]:.3e} dB, rot {d[1]:.3e} rad, trans {d[2]:.3e} m "
+              f"(PSNR {r64[0, 0]:.2f} -> {r64[-1, 0]:.2f} dB)  [{time.time() - t0:.0f} s]", flush=True)
+        out[f"trace32_{idx}"], out[f"trace64_{idx}"] = r32, r64
+        out[f"shapecode_{idx}"], out[f"texturecode_{idx}"], out[f"jitter_{idx}"] = sc0.numpy(), tc0.numpy(), jit.numpy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "trace_bands.npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    main()

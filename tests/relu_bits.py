@@ -19,3 +19,27 @@ def decode_relu_bits(masks_u8: torch.Tensor, n_points: int, shape_blocks: int, t
         out[:, :, :, 32 * T + 8 * (r >> 2) + 4 * h + (r & 3)] = bits[:, :, h]
     out = out.permute(1, 0, 2, 3).reshape(n_relu, tiles * 32, 256)[:, :n_points]
     return [out[s] if s < n_relu - 1 else out[s][:, :128] for s in range(n_relu)]
+
+
+def relu_bits_of(out: torch.Tensor, shape_blocks: int, texture_blocks: int, n_samples: int = 1):
+    """The ReLU bits saved by the autograd operator that produced ``out`` (``ops.DecoderPoints`` / ``DecoderPointsTrain``: n_samples = 1;
+    ``ops.FusedRender``: the samples per ray), decoded per ReLU layer for the caller's UNPADDED points (the operators pad ragged objects to
+    whole wave tiles; the dummy points are dropped here)."""
+    node, todo = None, [out.grad_fn]
+    while todo:
+        f = todo.pop()
+        if f is None:
+            continue
+        if type(f).__name__.startswith(("DecoderPoints", "FusedRender")):
+            node = f
+            break
+        todo.extend(g for g, _ in f.next_functions)
+    assert node is not None, "no supnerf_amd operator behind this tensor"
+    masks = [t for t in node.saved_tensors if t is not None and t.dtype == torch.uint8]
+    assert len(masks) == 1
+    B, n, n_pad = node.pad
+    per_obj, kept = (n_pad or n) * n_samples, n * n_samples
+    layers = decode_relu_bits(masks[0], B * per_obj, shape_blocks, texture_blocks)
+    if n_pad:
+        layers = [m.reshape(B, per_obj, -1)[:, :kept].reshape(B * kept, -1) for m in layers]
+    return layers

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import supnerf_oracle as O
+from relu_bits import relu_bits_of
 
 pytestmark = pytest.mark.gpu
 
@@ -205,6 +206,14 @@ def test_model_forward(amd, dev, model, golden, tag):
     assert md(sig, g["sigmas"]) < 2e-5 and md(rgb, g["rgbs"]) < 2e-5
 
 
+# Gradient tests below are MASK-MATCHED: the oracle differentiates with the ReLU bits the GPU forward saved (tests/relu_bits.py,
+# oracle.decoder_forward(relu_masks=...)).  A hidden unit whose pre-activation is within rounding of zero lands on either side of the ReLU
+# depending on the summation order, which moves that point's gradient by percents between ANY two correct implementations; rounds 1-2
+# therefore accepted 3e-2 ... 1e-1 at small shapes, a band that cannot see a mis-indexed tile.  On the same piecewise-linear function the
+# bound is 1e-4 of the gradient's largest entry for both arithmetics.
+MASKED_REL = 1e-4
+
+
 def test_model_forward_backward_vs_oracle_autograd(amd, dev, model, oracle_params):
     gen = torch.Generator().manual_seed(77)
     N, S, B = 8, 16, 2            # 64 points per object: whole wave tiles per object
@@ -213,13 +222,14 @@ def test_model_forward_backward_vs_oracle_autograd(amd, dev, model, oracle_param
     sc = (torch.randn(B, 256, generator=gen) * 0.3).requires_grad_()
     tc = (torch.randn(B, 256, generator=gen) * 0.3).requires_grad_()
     ws, wr = torch.randn(N, S, 1, generator=gen), torch.randn(N, S, 3, generator=gen)
-    sig_o, rgb_o = O.decoder_forward(oracle_params, xyz, vd, sc, tc)
-    ((sig_o * ws).sum() + (rgb_o * wr).sum()).backward()
     leaves = [t.detach().to(dev).requires_grad_() for t in (xyz, vd, sc, tc)]
     sig, rgb = model(*leaves)
     ((sig * ws.to(dev)).sum() + (rgb * wr.to(dev)).sum()).backward()
+    sig_o, rgb_o = O.decoder_forward(oracle_params, xyz, vd, sc, tc, relu_masks=relu_bits_of(sig, 3, 1))
+    ((sig_o * ws).sum() + (rgb_o * wr).sum()).backward()
+    assert md(sig, sig_o) < 2e-5 and md(rgb, rgb_o) < 2e-5
     for a, b, name in zip(leaves, (xyz, vd, sc, tc), ("xyz", "viewdir", "shapecode", "texturecode")):
-        assert close_grad(a.grad, b.grad), name
+        assert close_grad(a.grad, b.grad, rel=MASKED_REL), name
 
 
 @pytest.mark.parametrize("N,S,B", [(10, 7, 2), (3, 5, 3), (1, 33, 1), (6, 16, 2)])
@@ -232,24 +242,16 @@ def test_model_backward_ragged_points_per_object(amd, dev, model, oracle_params,
     sc = (torch.randn(B, 256, generator=gen) * 0.3).requires_grad_()
     tc = (torch.randn(B, 256, generator=gen) * 0.3).requires_grad_()
     ws, wr = torch.randn(B * N, S, 1, generator=gen), torch.randn(B * N, S, 3, generator=gen)
-    sig_o, rgb_o = O.decoder_forward(oracle_params, xyz, vd, sc, tc)
-    ((sig_o * ws).sum() + (rgb_o * wr).sum()).backward()
     leaves = [t.detach().to(dev).requires_grad_() for t in (xyz, vd, sc, tc)]
     sig, rgb = model(*leaves)
+    ((sig * ws.to(dev)).sum() + (rgb * wr.to(dev)).sum()).backward()
+    sig_o, rgb_o = O.decoder_forward(oracle_params, xyz, vd, sc, tc, relu_masks=relu_bits_of(sig, 3, 1))      # (mask-matched, see above)
+    ((sig_o * ws).sum() + (rgb_o * wr).sum()).backward()
     assert sig.shape == sig_o.shape and rgb.shape == rgb_o.shape
     assert md(sig, sig_o) < 2e-5 and md(rgb, rgb_o) < 2e-5
-    ((sig * ws.to(dev)).sum() + (rgb * wr.to(dev)).sum()).backward()
     for a, b, name in zip(leaves, (xyz, vd, sc, tc), ("xyz", "viewdir", "shapecode", "texturecode")):
         assert a.grad.shape == b.grad.shape
-        if model.precision == "fp32" or name in ("shapecode", "texturecode"):
-            # (split-bf16: a code gradient sums the object's N x S points, so ONE point on the other side of a ReLU kink, see below, shows
-            # as ~1 % at 64 points and as several % at 15)
-            rel = 2e-4 if model.precision == "fp32" else (3e-2 if N * S >= 64 else 1e-1)
-            assert close_grad(a.grad, b.grad, rel=rel), (name, md(a.grad, b.grad), float(b.grad.abs().max()))
-        else:       # split-bf16: a point whose hidden unit sits within rounding of the ReLU's kink may differ by percents
-            err = (a.grad.detach().cpu() - b.grad).abs().reshape(-1, 3).max(dim=1).values
-            off = int((err > 2e-3 * float(b.grad.abs().max())).sum())
-            assert off <= 2 and float(err.max()) < 0.1 * float(b.grad.abs().max()), (name, off, float(err.max()))
+        assert close_grad(a.grad, b.grad, rel=MASKED_REL), (name, md(a.grad, b.grad), float(b.grad.abs().max()))
 
 
 @pytest.mark.parametrize("blocks", [(2, 1), (1, 2), (2, 2), (4, 0), (0, 4), (0, 0), (1, 0)])
@@ -265,32 +267,32 @@ def test_model_backward_other_block_counts(amd, dev, blocks):
     sc = (torch.randn(B, 256, generator=gen) * 0.3).requires_grad_()
     tc = (torch.randn(B, 256, generator=gen) * 0.3).requires_grad_()
     ws, wr = torch.randn(N, S, 1, generator=gen), torch.randn(N, S, 3, generator=gen)
-    sig_o, rgb_o = O.decoder_forward(params, xyz, vd, sc, tc)
-    ((sig_o * ws).sum() + (rgb_o * wr).sum()).backward()
-    for prec, rel in (("fp32", 2e-4), ("bf16x3", 2e-3)):
+    for prec in ("fp32", "bf16x3"):
         m = amd.CodeNeRF(shape_blocks=sb, texture_blocks=tb)
         m.load_state_dict(params, strict=True)
         m = m.to(dev); m.precision = prec
         leaves = [t.detach().to(dev).requires_grad_() for t in (xyz, vd, sc, tc)]
         sig, rgb = m(*leaves)
-        assert md(sig, sig_o) < 2e-5 and md(rgb, rgb_o) < 2e-5, (blocks, prec)
         ((sig * ws.to(dev)).sum() + (rgb * wr.to(dev)).sum()).backward()
+        for t in (xyz, vd, sc, tc):
+            t.grad = None
+        sig_o, rgb_o = O.decoder_forward(params, xyz, vd, sc, tc, relu_masks=relu_bits_of(sig, sb, tb))      # (mask-matched, see above)
+        ((sig_o * ws).sum() + (rgb_o * wr).sum()).backward()
+        assert md(sig, sig_o) < 2e-5 and md(rgb, rgb_o) < 2e-5, (blocks, prec)
         for a, b, name in zip(leaves, (xyz, vd, sc, tc), ("xyz", "viewdir", "shapecode", "texturecode")):
             if b.grad is None or (name == "shapecode" and sb == 0) or (name == "texturecode" and tb == 0):
                 continue
-            if prec == "fp32" or name in ("shapecode", "texturecode"):
-                # (a code gradient sums 64 points here, so one flipped point of the split-bf16 mode, see below, shows as ~1 %)
-                assert close_grad(a.grad, b.grad, rel=rel if prec == "fp32" else 3e-2), (blocks, prec, name, md(a.grad, b.grad), float(b.grad.abs().max()))
-            else:
-                # split-bf16: a hidden unit whose pre-activation sits within ~1e-6 of zero may land on the other side of the ReLU
-                # than in fp32 arithmetic, which moves THAT point's gradient by percents; all other points must agree
-                err = (a.grad.detach().cpu() - b.grad).abs().reshape(-1, 3).max(dim=1).values
-                off = int((err > rel * float(b.grad.abs().max())).sum())
-                assert off <= 2 and float(err.max()) < 0.1 * float(b.grad.abs().max()), (blocks, prec, name, off, float(err.max()))
+            assert close_grad(a.grad, b.grad, rel=MASKED_REL), (blocks, prec, name, md(a.grad, b.grad), float(b.grad.abs().max()))
 
 
 # ------------------------------------------------------------------ gradients of the render path
-def test_gradients_family_a(amd, dev, model, golden, jitter):
+# The two fixtures below hold the REFERENCE's own gradients (8 x 8 rays).  Against them a ReLU flip of one of the 4096 / 2048 points shows
+# in the aggregates, so the kernels are held (a) to the mask-matched oracle at 1e-4 (codes) -- the oracle itself is pinned to these very
+# fixtures by tests/test_oracle_golden.py -- and (b) to the reference's numbers within FIXTURE_REL, the size of such a flip.
+FIXTURE_REL = 2e-3
+
+
+def test_gradients_family_a(amd, dev, model, golden, jitter, oracle_params):
     g = golden("grads_family_a")
     jitter(g["jitter"])
     sc = g["shapecode"].to(dev).requires_grad_()
@@ -301,11 +303,18 @@ def test_gradients_family_a(amd, dev, model, golden, jitter):
     loss, l_rgb, l_occ, ps = O.optimise_losses(out[0], out[2], out[3], out[4], 0.1)
     loss.backward()
     assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5 and abs(float(ps.detach()) - float(g["psnr"])) < TOL_PSNR_DB
-    assert close_grad(sc.grad, g["d_shapecode"]) and close_grad(tc.grad, g["d_texturecode"])
-    assert close_grad(pose.grad, g["d_cam_pose"], rel=5e-4)
+    assert close_grad(sc.grad, g["d_shapecode"], rel=FIXTURE_REL) and close_grad(tc.grad, g["d_texturecode"], rel=FIXTURE_REL)
+    assert close_grad(pose.grad, g["d_cam_pose"], rel=FIXTURE_REL)
+    sc_o, tc_o, pose_o = g["shapecode"].clone().requires_grad_(), g["texturecode"].clone().requires_grad_(), g["cam_pose"].clone().requires_grad_()
+    with O.given_relu_masks(relu_bits_of(out[0], 3, 1, n_samples=64)):
+        ref = O.render_rays_v2(oracle_params, g["img"], g["mask_occ"], pose_o, np.float32(g["obj_diag"]), g["K"], g["roi"], 64, sc_o, tc_o, True, im_sz=8,
+                               jitter=g["jitter"])
+        O.optimise_losses(ref[0], ref[2], ref[3], ref[4], 0.1)[0].backward()
+    assert close_grad(sc.grad, sc_o.grad, rel=MASKED_REL) and close_grad(tc.grad, tc_o.grad, rel=MASKED_REL)
+    assert close_grad(pose.grad, pose_o.grad, rel=5e-4)
 
 
-def test_gradients_family_b(amd, dev, model, golden, jitter):
+def test_gradients_family_b(amd, dev, model, golden, jitter, oracle_params):
     g = golden("grads_family_b")
     jitter(g["jitter"])
     sc = g["shapecode"].to(dev).requires_grad_()
@@ -316,8 +325,15 @@ def test_gradients_family_b(amd, dev, model, golden, jitter):
     loss = O.optimise_losses(out[0], out[2], out[3], out[4], 0.1)[0] + 0.01 * out[1].sum()
     loss.backward()
     assert abs(float(loss) - float(g["loss"])) < 5e-5
-    assert close_grad(sc.grad, g["d_shapecode"]) and close_grad(tc.grad, g["d_texturecode"])
-    assert close_grad(pose.grad, g["d_cam_pose"], rel=5e-4)
+    assert close_grad(sc.grad, g["d_shapecode"], rel=FIXTURE_REL) and close_grad(tc.grad, g["d_texturecode"], rel=FIXTURE_REL)
+    assert close_grad(pose.grad, g["d_cam_pose"], rel=FIXTURE_REL)
+    sc_o, tc_o, pose_o = g["shapecode"].clone().requires_grad_(), g["texturecode"].clone().requires_grad_(), g["cam_pose"].clone().requires_grad_()
+    with O.given_relu_masks(relu_bits_of(out[0], 3, 1, n_samples=32)):
+        ref = O.nerf_renderer_render_rays(oracle_params, g["img"], g["mask_occ"], pose_o, g["wlh"].numpy(), g["K"], g["roi"], sc_o, tc_o, n_samples=32,
+                                          white_bkgd=True, im_sz=8, jitter=g["jitter"])
+        (O.optimise_losses(ref[0], ref[2], ref[3], ref[4], 0.1)[0] + 0.01 * ref[1].sum()).backward()
+    assert close_grad(sc.grad, sc_o.grad, rel=MASKED_REL) and close_grad(tc.grad, tc_o.grad, rel=MASKED_REL)
+    assert close_grad(pose.grad, pose_o.grad, rel=5e-4)
 
 
 @pytest.mark.parametrize("S,N", [(4, 24), (8, 24), (16, 24), (32, 24), (128, 24), (4, 7), (16, 3), (8, 1)])
@@ -335,30 +351,23 @@ def test_fused_render_gradients_other_sample_counts(amd, dev, model, oracle_para
     tc = (torch.randn(1, 256, generator=gen) * 0.3).requires_grad_()
     wts = [torch.randn(N, 3, generator=gen), torch.randn(N, generator=gen) * 0.1, torch.randn(N, generator=gen)]
     diag = 5.2
-    xyz = ro[:, None, :] + vd[:, None, :] * t[:, :, None]
-    z_metric = torch.norm(xyz - ro[:, None, :], dim=-1) * (diag / 2)
-    xyz_o, vd_o = O.object_frame_transforms(xyz, vd[:, None, :].repeat(1, S, 1), False, False, True)
-    sig, rgb = O.decoder_forward(oracle_params, xyz_o, vd_o, sc, tc)
-    ref = O.composite(sig, rgb, z_metric, white_bkgd=True)
-    sum((a * b).sum() for a, b in zip(ref, wts)).backward()
     leaves = [x.detach().to(dev).requires_grad_() for x in (ro, vd, t, sc, tc)]
     cfg = ops.RenderCfg(S, ops.Z_PER_RAY, N, 3, 1, frame=amd.utils._frame(False, False, True), white_bkgd=True, metric_z=True, precision=None)
     out = model.fused_render(leaves[0], leaves[1], leaves[2], torch.ones(1, device=dev), torch.full((1,), diag / 2, device=dev),
                              leaves[3], leaves[4], cfg)
     sum((a * b.to(dev)).sum() for a, b in zip(out, wts)).backward()
+    xyz = ro[:, None, :] + vd[:, None, :] * t[:, :, None]
+    z_metric = torch.norm(xyz - ro[:, None, :], dim=-1) * (diag / 2)
+    xyz_o, vd_o = O.object_frame_transforms(xyz, vd[:, None, :].repeat(1, S, 1), False, False, True)
+    sig, rgb = O.decoder_forward(oracle_params, xyz_o, vd_o, sc, tc, relu_masks=relu_bits_of(out[0], 3, 1, n_samples=S))      # (mask-matched, see above)
+    ref = O.composite(sig, rgb, z_metric, white_bkgd=True)
+    sum((a * b).sum() for a, b in zip(ref, wts)).backward()
     assert md(out[0], ref[0]) < TOL_RGB and md(out[1], ref[1]) < TOL_DEPTH_MAX and md(out[2], ref[2]) < TOL_ACC
-    exact = model.precision == "fp32"
-    for k, (got, want, rel) in enumerate(zip(leaves, (ro, vd, t, sc, tc), (3e-3, 3e-3, 3e-3, 2e-3, 2e-3))):   # few rays, few samples: nothing averages out
+    # few rays, few samples: nothing averages out, and the depth / direction gradients are differences of large terms -- 5e-4 of the largest
+    # entry in fp32 arithmetic on either side; the codes' gradients (sums over all points) are held to the mask-matched 1e-4
+    for k, (got, want, rel) in enumerate(zip(leaves, (ro, vd, t, sc, tc), (5e-4, 5e-4, 5e-4, MASKED_REL, MASKED_REL))):
         err, top = (got.grad.cpu() - want.grad).abs(), float(want.grad.abs().max())
-        if exact:
-            assert close_grad(got.grad, want.grad, rel=rel), (S, float(err.max()), top)
-        elif k < 3:
-            # split-bf16: a hidden unit within rounding of zero may land on the other side of its ReLU than in fp32 arithmetic, which
-            # moves THAT ray's gradient by a percent or so; every other ray must agree
-            rows_off = int((err.reshape(N, -1).max(dim=1).values > rel * top + 1e-7).sum())
-            assert rows_off <= 1 and float(err.max()) < 0.05 * top, (S, rows_off, float(err.max()), top)
-        else:
-            assert close_grad(got.grad, want.grad, rel=2e-2), (S, float(err.max()), top)      # (a code gradient sums all rays: one flip shows)
+        assert close_grad(got.grad, want.grad, rel=rel), (S, k, float(err.max()), top)
 
 
 def test_training_shapes_volume_rendering_batch(amd, dev, model, golden):

@@ -17,6 +17,7 @@ import numpy as np
 import pytest
 import torch
 
+from loop_oracle import oracle_loop
 from oracle import supnerf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -74,8 +75,14 @@ def c2_oracle(oracle_params):
     loss = O.optimise_losses(out[0], out[2], out[3], out[4], 0.1)[0]
     loss.backward()
     assert out[0].shape == (N_RAYS, 3)
+    # the same computation in float64: what the fp32 pose gradient is a rounded evaluation OF (the bound on the pose gradient is derived from it)
+    d = lambda t: t.double()
+    pose64 = d(ob["cam_pose"]).clone().requires_grad_()
+    out64 = O.render_rays_v2({k: d(v) for k, v in oracle_params.items()}, d(img), d(mask), pose64, ob["obj_diag"], d(ob["K"]), ob["roi"], S, d(sc0), d(tc0),
+                             True, im_sz=IM, jitter=d(jit))
+    O.optimise_losses(out64[0], out64[2], out64[3], out64[4], 0.1)[0].backward()
     return dict(ob=ob, img=img, mask=mask, sc0=sc0, tc0=tc0, jit=jit, out=[t.detach() for t in out], loss=float(loss),
-                g_sc=sc.grad.clone(), g_tc=tc.grad.clone(), g_pose=pose.grad.clone())
+                g_sc=sc.grad.clone(), g_tc=tc.grad.clone(), g_pose=pose.grad.clone(), g_pose64=pose64.grad.clone())
 
 
 @pytest.mark.parametrize("precision", ["fp32", "auto"])
@@ -102,9 +109,15 @@ def test_config2_full_size_against_oracle(amd, dev, oracle_params, c2_oracle, pr
     loss.backward()
     assert abs(float(loss) - r["loss"]) < 2e-6
     e = dict(sc=rel(sc.grad, r["g_sc"]), tc=rel(tc.grad, r["g_tc"]), pose=rel(pose.grad, r["g_pose"]))
+    floor, e_true = rel(r["g_pose"], r["g_pose64"]), rel(pose.grad, r["g_pose64"])
     print(f"[config 2, {precision}] rgb {md(out[0], ref[0]):.2e} depth mean {float((out[1].detach().cpu() - ref[1]).abs().mean()):.2e} "
-          f"grad rel err codes {e['sc']:.2e}/{e['tc']:.2e} pose {e['pose']:.2e}")
-    assert max(e.values()) < GRAD_REL[precision], e
+          f"grad rel err codes {e['sc']:.2e}/{e['tc']:.2e} pose {e['pose']:.2e} (pose vs the float64 oracle: kernels {e_true:.2e}, "
+          f"the fp32 oracle itself {floor:.2e})")
+    assert max(e["sc"], e["tc"]) < GRAD_REL[precision], e
+    # pose: the direction part of this gradient is what is left after projecting a vector off its dominant component (d_viewdir is mostly
+    # along the ray), so an fp32 evaluation keeps few digits -- the reference's own (the fp32 oracle) is `floor` away from the float64 value.
+    # The kernels' distance from the float64 value may be at most that much again plus GRAD_REL (the pose -> rays backward runs in double).
+    assert e_true < floor + GRAD_REL[precision], (e_true, floor)
 
 
 # ------------------------------------------------------------------ config 3
@@ -252,35 +265,6 @@ def test_config4_kitti_render_matches_reference(amd, dev, oracle_params, golden,
     assert md(out[3], g["e2e_tgt"]) == 0.0 and md(out[4], g["e2e_occ"]) == 0.0
 
 
-def oracle_loop(params, obj, hpams, sc0, tc0, seed, reg_iters, pose_noise, D, jitter):
-    """The reference iteration (src/optimizer_nuscenes.py:674-783 == src/optimizer_kitti.py:731-866) with the oracle renderer, CPU;
-    ``jitter`` (num_opts, 2, S) are the two depth draws of every iteration."""
-    opt = hpams["optimize"]
-    rs = np.random.RandomState(seed)
-    R_gt = obj["cam_pose"][:, :3].T
-    t_gt = -R_gt @ obj["cam_pose"][:, 3:]
-    rot_vec = (D.matrix_to_axis_angle(R_gt[None]) + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[0]).requires_grad_()
-    trans_vec = (t_gt.T + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[1]).requires_grad_()
-    sc, tc = sc0.clone().requires_grad_(), tc0.clone().requires_grad_()
-    optim = D.make_optimizer(sc, tc, rot_vec, trans_vec, {k: opt[k] for k in ("lr_shape", "lr_texture", "lr_pose")})
-    rows = []
-    for it in range(opt["num_opts"]):
-        optim.zero_grad()
-        R = D.axis_angle_to_matrix(rot_vec[0]); t = trans_vec[0].unsqueeze(-1)
-        Rc = R.transpose(-2, -1)
-        cam2opt = torch.cat([Rc, -Rc @ t], -1)
-        out = O.render_rays_v2(params, obj["img"], obj["mask"], cam2opt, obj["obj_diag"], obj["K"], obj["roi"], hpams["n_samples"], sc, tc,
-                               True, im_sz=hpams["render_im_sz"], jitter=jitter[it, 0])
-        loss, _, _, ps = O.optimise_losses(out[0], out[2], out[3], out[4], hpams["loss_occ_coef"])
-        loss.backward()
-        pred_R = cam2opt[:, :3].detach().T
-        pred_t = -pred_R @ cam2opt[:, 3:].detach()
-        rows.append([float(ps), float(D.rot_dist(pred_R, R_gt)), float((pred_t - t_gt).norm())])
-        if it > reg_iters:
-            optim.step()
-    return np.array(rows)
-
-
 def gpu_loop(amd, dev, model, obj, hp, sc0, tc0, seed, reg_iters, jitter):
     m, sc, tc, pose = amd.driver.optimize_object(model, dev, obj, hp, sc0, tc0, pose_noise=(0.05, 0.3), reg_iters=reg_iters, seed=seed, jitter=jitter)
     return m[:, [0, 2, 3]].numpy()
@@ -311,19 +295,56 @@ def test_config4_kitti_loop_trace_matches_oracle_loop(amd, dev, oracle_params, p
 
 # ------------------------------------------------------------------ 100-iteration outcomes: what the bf16x3 gradient tolerance means for a run
 # The loop is chaotic in the last bits: Adam divides by the running gradient magnitude, so a component whose gradient is ~0 moves by ~lr in a
-# direction decided by round-off, and the pose has a soft direction (translation along the viewing ray barely changes the image).  Measured on
-# MI355X over 100 iterations: the GPU's exact-fp32 kernels against the CPU oracle loop (both fp32 arithmetic, different summation orders)
-# drift apart by 0.013 dB / 0.018 rad / 0.10 m at 256 rays; bf16x3 against fp32 kernels at 4096 rays by 0.005 dB / 0.003 rad / 0.05 m.
-# The acceptance band is therefore on outcomes, the same for both arithmetics: PSNR trace within 0.05 dB at every iteration, rotation within
-# 0.04 rad (2.3 deg, the reference reports 7 deg errors), translation within 0.2 m (the reference reports 0.7 m) -- and split-bf16 must not
-# sit further from the oracle than exact fp32 does by more than that band.
-BAND_PSNR_DB, BAND_ROT_RAD, BAND_TRANS_M = 0.05, 0.04, 0.2
+# direction decided by round-off, and the pose has a soft direction (translation along the viewing ray barely changes the image).  How far
+# that carries a trace is MEASURED, not guessed (round 2 fitted a band to one run): tests/golden/gen_trace_bands.py runs the reference's loop
+# on the CPU oracle for 8 objects in float64 and in float32 (same start, same jitter) and commits both traces (trace_bands.npz).
+# |fp32 oracle - fp64 oracle| is what fp32 rounding alone does to the REFERENCE's own arithmetic: up to 5e-3 dB / 1e-2 rad / 0.32 m over
+# 100 iterations.  The GPU loops are held to the float64 traces with
+#   * every object inside 1.5 x the worst of the 8 fp32-oracle deviations (the band), and
+#   * the median object inside 2 x the median fp32-oracle deviation (typical behaviour, not only the tail),
+# the same for both arithmetics.
+def _trace_bands():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trace_bands.npz"))
+    objs = [int(i) for i in z["objects"]]
+    dev32 = np.stack([np.abs(z[f"trace32_{i}"] - z[f"trace64_{i}"]).max(axis=0) for i in objs])       # (objects, [psnr, rot, trans])
+    return z, objs, dev32
+
+
+def test_100_iteration_traces_against_float64_oracle_loops(amd, dev, oracle_params):
+    """100 iterations of the loop (16 x 16 rays x 64 samples) on both kernel families for the 8 objects of trace_bands.npz, against the
+    float64 oracle loops committed there; bands derived from the fp32 oracle loops of the same file (see above)."""
+    D = amd.driver
+    z, objs, dev32 = _trace_bands()
+    band, typical = 1.5 * dev32.max(axis=0), 2.0 * np.median(dev32, axis=0)
+    hp = D.load_hpams(); hp["render_im_sz"] = int(z["im_sz"]); hp["optimize"]["num_opts"] = 100
+    for precision in ("fp32", "bf16x3"):
+        model = make_model(amd, dev, oracle_params, precision)
+        devs = []
+        for idx in objs:
+            obj = D.make_objects([idx], int(z["im_sz"]))[0]
+            sc0, tc0, jit = [torch.from_numpy(z[f"{k}_{idx}"]) for k in ("shapecode", "texturecode", "jitter")]
+            got = gpu_loop(amd, dev, model, obj, hp, sc0, tc0, int(z["seed"]), int(z["reg_iters"]), jit)
+            d = np.abs(got - z[f"trace64_{idx}"])
+            assert d[:5, 0].max() < 1e-3, (precision, idx)          # before the first optimiser steps: the same numbers
+            assert got[-1, 0] > got[0, 0] + 1.0, (precision, idx)   # and the loop does its job
+            devs.append(d.max(axis=0))
+        devs = np.stack(devs)
+        print(f"[100 iterations, 8 objects, {precision} vs float64 oracle loops] worst object: psnr {devs[:, 0].max():.2e} dB, rot {devs[:, 1].max():.2e} rad, "
+              f"trans {devs[:, 2].max():.2e} m (fp32 oracle: {dev32[:, 0].max():.2e} / {dev32[:, 1].max():.2e} / {dev32[:, 2].max():.2e}); median object: "
+              f"{np.median(devs[:, 0]):.2e} / {np.median(devs[:, 1]):.2e} / {np.median(devs[:, 2]):.2e} (fp32 oracle: {np.median(dev32[:, 0]):.2e} / "
+              f"{np.median(dev32[:, 1]):.2e} / {np.median(dev32[:, 2]):.2e})")
+        assert (devs.max(axis=0) < band).all(), (precision, devs.max(axis=0), band)
+        assert (np.median(devs, axis=0) < typical).all(), (precision, np.median(devs, axis=0), typical)
 
 
 def test_100_iteration_traces_fp32_vs_bf16x3_full_size(amd, dev, oracle_params):
     """The reference runs 100 iterations per object (num_opts).  Same object, same jitter, 4096 x 64: the exact-fp32 kernels and the
-    split-bf16 kernels must tell the same story."""
+    split-bf16 kernels must tell the same story -- within the band that fp32 rounding alone opens between two runs of the reference's
+    loop (derived above; two fp32-rounded runs may each sit a band away from the truth)."""
     D = amd.driver
+    _, _, dev32 = _trace_bands()
+    band = 1.5 * dev32.max(axis=0)
     hp = D.load_hpams(); hp["render_im_sz"] = IM; hp["optimize"]["num_opts"] = 100
     obj = D.make_objects([41], IM)[0]
     g = torch.Generator().manual_seed(8)
@@ -335,31 +356,7 @@ def test_100_iteration_traces_fp32_vs_bf16x3_full_size(amd, dev, oracle_params):
         tr[precision] = gpu_loop(amd, dev, model, obj, hp, sc0, tc0, 3, 3, jit)
     d = np.abs(tr["fp32"] - tr["bf16x3"])
     print(f"[100 iterations, 4096x64] fp32 vs bf16x3: max |dPSNR| {d[:, 0].max():.3e} dB (final {d[-1, 0]:.3e}), rot {d[:, 1].max():.2e} rad, "
-          f"trans {d[:, 2].max():.2e} m; PSNR {tr['fp32'][0, 0]:.2f} -> {tr['fp32'][-1, 0]:.2f} dB")
+          f"trans {d[:, 2].max():.2e} m; PSNR {tr['fp32'][0, 0]:.2f} -> {tr['fp32'][-1, 0]:.2f} dB; band {band}")
     assert d[:5, 0].max() < 1e-4                         # the first iterations (no optimiser step yet, then one): the same numbers
-    assert d[:, 0].max() < BAND_PSNR_DB and d[:, 1].max() < BAND_ROT_RAD and d[:, 2].max() < BAND_TRANS_M
+    assert (d.max(axis=0) < band).all(), (d.max(axis=0), band)
     assert tr["bf16x3"][-1, 0] > tr["bf16x3"][0, 0] + 1.0
-
-
-def test_100_iteration_traces_against_oracle_loop(amd, dev, oracle_params):
-    """100 iterations of the loop on the oracle renderer (CPU, 16 x 16 rays x 64 samples) against the same loop on both kernel families."""
-    D = amd.driver
-    hp = D.load_hpams(); hp["render_im_sz"] = 16; hp["optimize"]["num_opts"] = 100
-    obj = D.make_objects([21], 16)[0]
-    g = torch.Generator().manual_seed(6)
-    sc0, tc0 = torch.randn(1, 256, generator=g) * 0.3, torch.randn(1, 256, generator=g) * 0.3
-    jit = torch.rand(100, 2, 64, generator=g)
-    ref = oracle_loop(oracle_params, obj, hp, sc0, tc0, seed=9, reg_iters=3, pose_noise=(0.05, 0.3), D=D, jitter=jit)
-    worst = {}
-    for precision in ("fp32", "bf16x3"):
-        model = make_model(amd, dev, oracle_params, precision)
-        got = gpu_loop(amd, dev, model, obj, hp, sc0, tc0, 9, 3, jit)
-        d = np.abs(got - ref)
-        worst[precision] = d.max(axis=0)
-        print(f"[100 iterations, 256x64, {precision} vs oracle loop] max |dPSNR| {d[:, 0].max():.3e} dB (final {d[-1, 0]:.3e}), rot {d[:, 1].max():.2e} rad, "
-              f"trans {d[:, 2].max():.2e} m; PSNR {ref[0, 0]:.2f} -> {ref[-1, 0]:.2f} dB")
-        assert d[:5, 0].max() < 1e-3
-    for precision in ("fp32", "bf16x3"):
-        w = worst[precision]
-        assert w[0] < BAND_PSNR_DB and w[1] < BAND_ROT_RAD and w[2] < BAND_TRANS_M, (precision, w)
-    assert ref[-1, 0] > ref[0, 0] + 1.0

@@ -214,6 +214,33 @@ def test_hpams_reader(amd, tmp_path):
     p = tmp_path / "c.json"
     p.write_text('{"n_samples": 32, "optimize": {"num_opts": 5}}')
     assert amd.driver.load_hpams(str(p))["n_samples"] == 32
+    # the shipped defaults of every dataset hold the values of the reference's json files (fixtures written from those files by
+    # tests/golden/gen_golden_r2.py / gen_golden_r3.py)
+    import json, os
+    for name, fixture in (("kitti", "kitti.json"), ("nusc", "kitti.json"), ("waymo", "waymo.json")):
+        want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", fixture)))[name]
+        got = amd.driver.load_hpams(dataset=name)
+        for k, v in want.items():
+            if isinstance(v, dict):
+                for kk, vv in v.items():
+                    assert got[k][kk] == vv, (name, k, kk)
+            else:
+                assert got[k] == v, (name, k)
+    with pytest.raises(ValueError):
+        amd.driver.load_hpams(dataset="argoverse")
+
+
+def test_result_file_carries_per_object_lidar_counts(amd, tmp_path):
+    """codes+poses.pth: ``lidar_pts_cnt`` is the weight of every object's depth error in the reference's evaluation
+    (collect_eval_results, src/utils.py:786): the writer takes the per-object counts the driver reports, and a generator of ids."""
+    rows = torch.rand(3, 2 * 4)
+    psnr, depth, R, T, cnt = amd.io.metric_rows_to_eval_dicts(rows, (i for i in (7, 8, 9)), n_lidar=torch.tensor([40, 53, 66]))
+    assert cnt == {"7_0": 40, "8_0": 53, "9_0": 66} and len(psnr) == 3
+    path = amd.io.save_driver_results(str(tmp_path / "r"), rows, (i for i in (7, 8, 9)), n_lidar=[40, 53, 66])
+    saved = torch.load(path, weights_only=False)
+    assert saved["num_obj"] == 3 and saved["lidar_pts_cnt"] == cnt
+    with pytest.raises(ValueError):
+        amd.io.metric_rows_to_eval_dicts(rows, [1, 2, 3], n_lidar=[1, 2])
 
 
 _GLOO_WORKER = r"""

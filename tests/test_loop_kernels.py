@@ -154,6 +154,11 @@ def test_metric_row(amd, dev, opt_cam_pose):
     assert md(torch.cos(row[:, 2]), torch.cos(want[:, 2])) < 2e-6
     amd.ops.metric_row(f(loss_out), f(d_vec), d0_d, True, f(c2o), f(gtR), f(gtT), opt_cam_pose, row)       # first iteration: depth0 <- depth
     assert float(row[:, 1].abs().max()) == 0.0 and torch.equal(d0_d.cpu(), d_vec)
+    # per-object depth-pixel counts (src/optimizer_nuscenes.py:1736-1741: sum |d - gt| / (len + 1e-8) over THAT object's lidar returns)
+    cnt = torch.tensor([37, 5, 0, 20], dtype=torch.int32)
+    want_d = torch.stack([(d_vec[b, :int(c)] - d0[b, :int(c)]).abs().sum() / (int(c) + 1e-8) for b, c in enumerate(cnt)])
+    amd.ops.metric_row(f(loss_out), f(d_vec), f(d0), False, f(c2o), f(gtR), f(gtT), opt_cam_pose, row, lidar_count=cnt.to(dev))
+    assert md(row[:, 1], want_d) < 2e-5 and float(row[2, 1]) == 0.0
 
 
 # ------------------------------------------------------------------ AdamW (src/optimizer_nuscenes.py:1762-1769: torch.optim.AdamW defaults)
@@ -245,3 +250,46 @@ def test_fused_loop_equals_api_loop(amd, dev, oracle_params, precision):
     torch.manual_seed(77); a2 = D.optimize_object_api(model, dev, obj, hp, sc0, tc0, reg_iters=1, seed=9)
     torch.manual_seed(77); b2 = D.optimize_object(model, dev, obj, hp, sc0, tc0, reg_iters=1, seed=9)
     assert float((a2[0][:3] - b2[0][:3]).abs().max()) < 2e-4
+
+
+# ------------------------------------------------------------------ public get_rays / depths as one launch (src/utils.py:107-135,159-164,468-469)
+@pytest.mark.parametrize("im_sz,subset", [(64, None), (24, None), (33, 700), (5, None)])
+def test_public_rays_and_depths_one_launch(amd, dev, im_sz, subset):
+    """``utils.get_rays`` and the rays + depth vector of ``render_rays_v2`` with the pose on the GPU (``snr_cam_rays_fwd/bwd``) against the
+    torch formulation the same functions run for a CPU pose (the reference's own lines), values and the gradient wrt the pose; ray
+    counts that leave partial 1024-ray chunks and a ray subset included."""
+    U = amd.utils
+    ob = O.synthetic_object(3)
+    S = 64
+    g = torch.Generator().manual_seed(im_sz)
+    jit = torch.rand(S, generator=g)
+    ids = None if subset is None else np.random.RandomState(0).permutation(im_sz * im_sz)[:subset]
+    n = im_sz * im_sz if ids is None else subset
+    w_o, w_d = torch.rand(n, 3, generator=g, dtype=torch.float64), torch.rand(n, 3, generator=g, dtype=torch.float64)
+
+    pose64 = ob["cam_pose"].double().requires_grad_()
+    ro64, vd64 = O.pixel_rays(ob["K"].double(), pose64, ob["roi"], uv_steps=[im_sz, im_sz])
+    if ids is not None:
+        ro64, vd64 = ro64[ids], vd64[ids]
+    ((ro64 * w_o).sum() + (vd64 * w_d).sum()).backward()
+    near, far = O.sphere_bounds(ob["cam_pose"], ob["obj_diag"])
+    z_ref = O.shared_depth_samples(near, far, S, jit)
+
+    pose_d = ob["cam_pose"].to(dev).requires_grad_()
+    U.JITTER_OVERRIDE = jit
+    try:
+        ro, vd, z = U._rays_and_depths(ob["K"], pose_d, ob["roi"], [im_sz, im_sz], ob["obj_diag"], S, ids=ids)
+    finally:
+        U.JITTER_OVERRIDE = None
+    assert ro.is_contiguous() and ro.shape == (n, 3) and z.shape == (S,)
+    assert md(ro, ro64) < 1e-6 and md(vd, vd64) < 2e-7 and md(z, z_ref) < 4e-6
+    ro32, vd32 = O.pixel_rays(ob["K"], ob["cam_pose"], ob["roi"], uv_steps=[im_sz, im_sz])       # the reference's fp32 rays, bit for bit
+    if ids is not None:
+        ro32, vd32 = ro32[ids], vd32[ids]
+    assert md(ro, ro32) == 0.0 and md(vd, vd32) == 0.0
+    ((ro * w_o.float().to(dev)).sum() + (vd * w_d.float().to(dev)).sum()).backward()
+    assert rel(pose_d.grad, pose64.grad) < 2e-5
+    # the bare public function takes the same path
+    if ids is None:
+        ro2, vd2 = U.get_rays(ob["K"], ob["cam_pose"].to(dev), ob["roi"], uv_steps=[im_sz, im_sz])
+        assert torch.equal(ro2, ro.detach()) and torch.equal(vd2, vd.detach())

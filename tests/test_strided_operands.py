@@ -61,8 +61,9 @@ def test_render_bwd_takes_strided_views(amd, dev, oracle_params, precision):
     N, S = 256, 64
     pose = ob["cam_pose"].to(dev)
     with torch.no_grad():
-        rays_o, viewdir = U.get_rays(ob["K"], pose, ob["roi"], uv_steps=[16, 16])
-        assert rays_o.stride(0) == 0                          # THE operand of the round-2 fault: an expand of the pose's translation
+        _, viewdir = U.get_rays(ob["K"], pose, ob["roi"], uv_steps=[16, 16])
+        rays_o = pose[:, 3].expand(N, 3)                      # THE operand of the round-2 fault: get_rays' origins used to be this stride-0 view
+        assert rays_o.stride(0) == 0
         near, far = U._sphere_bounds(pose, ob["obj_diag"])
         z = U._shared_depths(near, far, S, dev, jitter=torch.rand(S))
         g = torch.Generator().manual_seed(0)
