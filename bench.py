@@ -490,7 +490,7 @@ def main():
         m_t = A.CodeNeRF(3, 1); m_t.load_state_dict(w["params"]); m_t = m_t.to(dev); m_t.train_decoder_weights = True
         m_t.precision = p_t
         codes = T.CodeTables(64, 256, seed=1).to(dev)
-        bucket = T.GradBucket(list(m_t.parameters()) + list(codes.parameters()))
+        bucket = T.GradBucket(list(m_t.parameters()) + list(codes.parameters()), row_sparse=list(codes.parameters()))
         opt_t = T.make_optimizer(m_t, codes, hp_t)
         n_t = 10
         t_t = clock.wall(lambda: T.train_step(m_t, codes, opt_t, bucket, batch, 0.1), n_t, 3)

@@ -4,8 +4,12 @@ The reference trains with ``torch.nn.DataParallel`` over one process (src/traine
 iteration scatters the batch, replicates the module, gathers the per-replica losses and calls
 ``loss_total.mean().backward()`` (:334).  Here each rank owns one MI355X and its slice of the batch; the decoder
 forward/backward is the HIP training path (``model.train_decoder_weights = True``: per-layer activations / gradients are
-written by the kernels, dW on the library BLAS), and the only exchange is ONE all-reduce per step over a flat gradient
-bucket (RCCL over xGMI; decoder weights ~1-4 MB plus the code tables), which reproduces the mean-over-replicas gradient.
+written by the kernels, the weight gradients come from the library's own split-K MFMA kernels, ``snr_weight_grad``), and the exchange
+per step is ONE all-reduce over a flat gradient bucket (RCCL over xGMI; the decoder and latent layers, ~3-16 MB) plus, for the two code
+tables, an all-gather of the FEW ROWS each rank touched (B rows of 256 floats per table and rank: at the full nuScenes train split
+the tables hold tens of thousands of instances, ~100 MB as a dense bucket, of which a step touches B rows) -- together they reproduce
+the mean-over-replicas gradient.  The optimiser still updates every row of the tables like the reference's dense AdamW (weight decay
+and the momentum tails of earlier steps act on untouched rows too, src/trainer_unified_nuscenes.py:414-422).
 
 Functions mirror the NeRF half of ``ParallelModel.forward`` (:117-148) and of ``training_epoch`` (:259-344); the image
 encoder / pose-refinement half of that forward is stock PyTorch and outside this package.
@@ -63,26 +67,45 @@ class CodeTables(nn.Module):
 
 
 class GradBucket:
-    """All trainable gradients as views into ONE flat fp32 buffer, so a step costs one all-reduce.
+    """Gradients of one training step, exchanged the cheap way:
 
-    ``optimizer.zero_grad(set_to_none=True)`` would drop the views: use ``bucket.zero()`` instead."""
+    * dense parameters (decoder, latent layers): views into ONE flat fp32 buffer, so a step costs one all-reduce;
+    * ``row_sparse`` parameters (the code tables, (n_instances, 256)): a step touches the few rows of its batch, so every rank keeps the
+      table's dense ``.grad`` (zeros elsewhere, the optimiser wants it dense) and the ranks exchange ONLY THE TOUCHED ROWS: one all-gather
+      of (row index, gradient rows) -- world x B x 256 floats per table instead of an all-reduce over the whole table.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
-        self.params = [p for p in params if p.requires_grad]
+    ``optimizer.zero_grad(set_to_none=True)`` would drop the views: use ``bucket.zero()`` instead (it clears the flat buffer and only
+    the rows of the tables that the last step touched)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, row_sparse: Iterable[torch.nn.Parameter] = ()):
+        self.rows = [p for p in row_sparse if p.requires_grad]
+        sparse_ids = {id(p) for p in self.rows}
+        self.params = [p for p in params if p.requires_grad and id(p) not in sparse_ids]
         if not self.params:
             raise ValueError("GradBucket: no trainable parameters")
         dev = self.params[0].device
-        if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+        if any(p.device != dev or p.dtype != torch.float32 for p in self.params + self.rows):
             raise ValueError("GradBucket: parameters must be fp32 and live on one device")
+        if any(p.dim() != 2 for p in self.rows):
+            raise ValueError("GradBucket: row_sparse parameters are 2-D tables")
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
         self.group = group
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
+        for p in self.rows:
+            p.grad = torch.zeros_like(p)
+        self._touched = None
 
     def zero(self):
         self.flat.zero_()
+        for p in self.rows:
+            if self._touched is None:
+                p.grad.zero_()
+            else:
+                p.grad[self._touched] = 0
+        self._touched = None
 
     def check_views(self):
         base = self.flat.untyped_storage().data_ptr()
@@ -90,13 +113,48 @@ class GradBucket:
             if p.grad is None or p.grad.untyped_storage().data_ptr() != base:
                 raise RuntimeError("GradBucket: a .grad was replaced (zero_grad(set_to_none=True)?); call bucket.zero() instead")
 
-    def allreduce_mean(self):
-        """Sum over ranks / world size == gradient of the mean of the per-rank losses (:334)."""
+    def allreduce_mean(self, rows: Optional[torch.Tensor] = None):
+        """Sum over ranks / world size == gradient of the mean of the per-rank losses (:334).  ``rows``: the table rows this rank's
+        batch touched (``batch["code_idx"]``; needed when the bucket has row-sparse tables)."""
         import torch.distributed as dist
         self.check_views()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(dist.get_world_size(self.group))
+        if self.rows and rows is None:
+            raise ValueError("GradBucket.allreduce_mean: row-sparse tables need the rows of this step (batch['code_idx'])")
+        if self.rows:
+            self._touched = torch.unique(rows.to(self.flat.device).long())
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return
+        world = dist.get_world_size(self.group)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.div_(world)
+        if not self.rows:
+            return
+        # every rank sends its unique touched rows, padded to the common length with index -1 (zero rows); one all-gather of the indices
+        # and one of the [table 0 | table 1 | ...] gradient rows
+        dev = self.flat.device
+        uniq = self._touched
+        n_mine = torch.tensor([uniq.numel()], device=dev, dtype=torch.int64)
+        sizes = [torch.zeros_like(n_mine) for _ in range(world)]
+        dist.all_gather(sizes, n_mine, group=self.group)
+        width = int(max(int(v) for v in sizes))
+        idx = torch.full((width,), -1, dtype=torch.int64, device=dev)
+        idx[:uniq.numel()] = uniq
+        cols = sum(p.shape[1] for p in self.rows)
+        payload = torch.zeros(width, cols, device=dev)
+        payload[:uniq.numel()] = torch.cat([p.grad[uniq] for p in self.rows], dim=1)
+        all_idx = [torch.empty_like(idx) for _ in range(world)]
+        all_rows = [torch.empty_like(payload) for _ in range(world)]
+        dist.all_gather(all_idx, idx, group=self.group)
+        dist.all_gather(all_rows, payload, group=self.group)
+        idx_cat, rows_cat = torch.cat(all_idx), torch.cat(all_rows)
+        keep = idx_cat >= 0
+        idx_cat, rows_cat = idx_cat[keep], rows_cat[keep]
+        off = 0
+        for p in self.rows:
+            p.grad[uniq] = 0                                              # (this rank's own rows come back with everybody's)
+            p.grad.index_add_(0, idx_cat, rows_cat[:, off:off + p.shape[1]] / world)      # rank order: the same sum on every rank
+            off += p.shape[1]
+        self._touched = torch.unique(idx_cat)
 
 
 def learning_rates(hpams: dict, niter: int):
@@ -123,7 +181,7 @@ def train_step(model, codes: CodeTables, opt, bucket: GradBucket, batch: Dict[st
     losses_all, loss_total = nerf_losses(model, batch["xyz"], batch["viewdir"], sc, tc, batch["z_vals"], batch["rgb_tgt"],
                                          batch["occ_pixels"], loss_occ_coef, composite)
     loss_total.backward()
-    bucket.allreduce_mean()
+    bucket.allreduce_mean(rows=batch["code_idx"] if bucket.rows else None)
     opt.step()
     bucket.zero()
     return {k: v.detach() for k, v in losses_all.items()}

@@ -224,8 +224,9 @@ def test_model_forward_backward_vs_oracle_autograd(amd, dev, model, oracle_param
     ws, wr = torch.randn(N, S, 1, generator=gen), torch.randn(N, S, 3, generator=gen)
     leaves = [t.detach().to(dev).requires_grad_() for t in (xyz, vd, sc, tc)]
     sig, rgb = model(*leaves)
+    masks = relu_bits_of(sig, 3, 1)                       # (before backward: autograd frees what the operator saved)
     ((sig * ws.to(dev)).sum() + (rgb * wr.to(dev)).sum()).backward()
-    sig_o, rgb_o = O.decoder_forward(oracle_params, xyz, vd, sc, tc, relu_masks=relu_bits_of(sig, 3, 1))
+    sig_o, rgb_o = O.decoder_forward(oracle_params, xyz, vd, sc, tc, relu_masks=masks)
     ((sig_o * ws).sum() + (rgb_o * wr).sum()).backward()
     assert md(sig, sig_o) < 2e-5 and md(rgb, rgb_o) < 2e-5
     for a, b, name in zip(leaves, (xyz, vd, sc, tc), ("xyz", "viewdir", "shapecode", "texturecode")):
@@ -244,8 +245,9 @@ def test_model_backward_ragged_points_per_object(amd, dev, model, oracle_params,
     ws, wr = torch.randn(B * N, S, 1, generator=gen), torch.randn(B * N, S, 3, generator=gen)
     leaves = [t.detach().to(dev).requires_grad_() for t in (xyz, vd, sc, tc)]
     sig, rgb = model(*leaves)
+    masks = relu_bits_of(sig, 3, 1)
     ((sig * ws.to(dev)).sum() + (rgb * wr.to(dev)).sum()).backward()
-    sig_o, rgb_o = O.decoder_forward(oracle_params, xyz, vd, sc, tc, relu_masks=relu_bits_of(sig, 3, 1))      # (mask-matched, see above)
+    sig_o, rgb_o = O.decoder_forward(oracle_params, xyz, vd, sc, tc, relu_masks=masks)      # (mask-matched, see above)
     ((sig_o * ws).sum() + (rgb_o * wr).sum()).backward()
     assert sig.shape == sig_o.shape and rgb.shape == rgb_o.shape
     assert md(sig, sig_o) < 2e-5 and md(rgb, rgb_o) < 2e-5
@@ -273,10 +275,11 @@ def test_model_backward_other_block_counts(amd, dev, blocks):
         m = m.to(dev); m.precision = prec
         leaves = [t.detach().to(dev).requires_grad_() for t in (xyz, vd, sc, tc)]
         sig, rgb = m(*leaves)
+        masks = relu_bits_of(sig, sb, tb)
         ((sig * ws.to(dev)).sum() + (rgb * wr.to(dev)).sum()).backward()
         for t in (xyz, vd, sc, tc):
             t.grad = None
-        sig_o, rgb_o = O.decoder_forward(params, xyz, vd, sc, tc, relu_masks=relu_bits_of(sig, sb, tb))      # (mask-matched, see above)
+        sig_o, rgb_o = O.decoder_forward(params, xyz, vd, sc, tc, relu_masks=masks)      # (mask-matched, see above)
         ((sig_o * ws).sum() + (rgb_o * wr).sum()).backward()
         assert md(sig, sig_o) < 2e-5 and md(rgb, rgb_o) < 2e-5, (blocks, prec)
         for a, b, name in zip(leaves, (xyz, vd, sc, tc), ("xyz", "viewdir", "shapecode", "texturecode")):
@@ -300,13 +303,14 @@ def test_gradients_family_a(amd, dev, model, golden, jitter, oracle_params):
     pose = g["cam_pose"].to(dev).requires_grad_()
     out = amd.utils.render_rays_v2(model, dev, g["img"], g["mask_occ"], pose, np.float32(g["obj_diag"]), g["K"], g["roi"], 64, sc, tc, 1, 0,
                                    im_sz=8)
+    masks = relu_bits_of(out[0], 3, 1, n_samples=64)
     loss, l_rgb, l_occ, ps = O.optimise_losses(out[0], out[2], out[3], out[4], 0.1)
     loss.backward()
     assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5 and abs(float(ps.detach()) - float(g["psnr"])) < TOL_PSNR_DB
     assert close_grad(sc.grad, g["d_shapecode"], rel=FIXTURE_REL) and close_grad(tc.grad, g["d_texturecode"], rel=FIXTURE_REL)
     assert close_grad(pose.grad, g["d_cam_pose"], rel=FIXTURE_REL)
     sc_o, tc_o, pose_o = g["shapecode"].clone().requires_grad_(), g["texturecode"].clone().requires_grad_(), g["cam_pose"].clone().requires_grad_()
-    with O.given_relu_masks(relu_bits_of(out[0], 3, 1, n_samples=64)):
+    with O.given_relu_masks(masks):
         ref = O.render_rays_v2(oracle_params, g["img"], g["mask_occ"], pose_o, np.float32(g["obj_diag"]), g["K"], g["roi"], 64, sc_o, tc_o, True, im_sz=8,
                                jitter=g["jitter"])
         O.optimise_losses(ref[0], ref[2], ref[3], ref[4], 0.1)[0].backward()
@@ -322,13 +326,14 @@ def test_gradients_family_b(amd, dev, model, golden, jitter, oracle_params):
     pose = g["cam_pose"].to(dev).requires_grad_()
     rend = amd.NeRFRenderer(n_samples=32, white_bkgd=True)
     out = rend.render_rays(model, dev, g["img"], g["mask_occ"], pose, g["wlh"].numpy(), g["K"], g["roi"], sc, tc, im_sz=8)
+    masks = relu_bits_of(out[0], 3, 1, n_samples=32)
     loss = O.optimise_losses(out[0], out[2], out[3], out[4], 0.1)[0] + 0.01 * out[1].sum()
     loss.backward()
     assert abs(float(loss) - float(g["loss"])) < 5e-5
     assert close_grad(sc.grad, g["d_shapecode"], rel=FIXTURE_REL) and close_grad(tc.grad, g["d_texturecode"], rel=FIXTURE_REL)
     assert close_grad(pose.grad, g["d_cam_pose"], rel=FIXTURE_REL)
     sc_o, tc_o, pose_o = g["shapecode"].clone().requires_grad_(), g["texturecode"].clone().requires_grad_(), g["cam_pose"].clone().requires_grad_()
-    with O.given_relu_masks(relu_bits_of(out[0], 3, 1, n_samples=32)):
+    with O.given_relu_masks(masks):
         ref = O.nerf_renderer_render_rays(oracle_params, g["img"], g["mask_occ"], pose_o, g["wlh"].numpy(), g["K"], g["roi"], sc_o, tc_o, n_samples=32,
                                           white_bkgd=True, im_sz=8, jitter=g["jitter"])
         (O.optimise_losses(ref[0], ref[2], ref[3], ref[4], 0.1)[0] + 0.01 * ref[1].sum()).backward()
@@ -355,11 +360,12 @@ def test_fused_render_gradients_other_sample_counts(amd, dev, model, oracle_para
     cfg = ops.RenderCfg(S, ops.Z_PER_RAY, N, 3, 1, frame=amd.utils._frame(False, False, True), white_bkgd=True, metric_z=True, precision=None)
     out = model.fused_render(leaves[0], leaves[1], leaves[2], torch.ones(1, device=dev), torch.full((1,), diag / 2, device=dev),
                              leaves[3], leaves[4], cfg)
+    masks = relu_bits_of(out[0], 3, 1, n_samples=S)
     sum((a * b.to(dev)).sum() for a, b in zip(out, wts)).backward()
     xyz = ro[:, None, :] + vd[:, None, :] * t[:, :, None]
     z_metric = torch.norm(xyz - ro[:, None, :], dim=-1) * (diag / 2)
     xyz_o, vd_o = O.object_frame_transforms(xyz, vd[:, None, :].repeat(1, S, 1), False, False, True)
-    sig, rgb = O.decoder_forward(oracle_params, xyz_o, vd_o, sc, tc, relu_masks=relu_bits_of(out[0], 3, 1, n_samples=S))      # (mask-matched, see above)
+    sig, rgb = O.decoder_forward(oracle_params, xyz_o, vd_o, sc, tc, relu_masks=masks)      # (mask-matched, see above)
     ref = O.composite(sig, rgb, z_metric, white_bkgd=True)
     sum((a * b).sum() for a, b in zip(ref, wts)).backward()
     assert md(out[0], ref[0]) < TOL_RGB and md(out[1], ref[1]) < TOL_DEPTH_MAX and md(out[2], ref[2]) < TOL_ACC

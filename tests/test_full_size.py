@@ -300,7 +300,8 @@ def test_config4_kitti_loop_trace_matches_oracle_loop(amd, dev, oracle_params, p
 # on the CPU oracle for 8 objects in float64 and in float32 (same start, same jitter) and commits both traces (trace_bands.npz).
 # |fp32 oracle - fp64 oracle| is what fp32 rounding alone does to the REFERENCE's own arithmetic: up to 5e-3 dB / 1e-2 rad / 0.32 m over
 # 100 iterations.  The GPU loops are held to the float64 traces with
-#   * every object inside 1.5 x the worst of the 8 fp32-oracle deviations (the band), and
+#   * every object inside 2 x the worst of the 8 fp32-oracle deviations (the band; the largest of 8 samples underestimates the tail of a
+#     heavy-tailed spread, hence the factor), and
 #   * the median object inside 2 x the median fp32-oracle deviation (typical behaviour, not only the tail),
 # the same for both arithmetics.
 def _trace_bands():
@@ -316,7 +317,7 @@ def test_100_iteration_traces_against_float64_oracle_loops(amd, dev, oracle_para
     float64 oracle loops committed there; bands derived from the fp32 oracle loops of the same file (see above)."""
     D = amd.driver
     z, objs, dev32 = _trace_bands()
-    band, typical = 1.5 * dev32.max(axis=0), 2.0 * np.median(dev32, axis=0)
+    band, typical = 2.0 * dev32.max(axis=0), 2.0 * np.median(dev32, axis=0)
     hp = D.load_hpams(); hp["render_im_sz"] = int(z["im_sz"]); hp["optimize"]["num_opts"] = 100
     for precision in ("fp32", "bf16x3"):
         model = make_model(amd, dev, oracle_params, precision)
@@ -344,7 +345,7 @@ def test_100_iteration_traces_fp32_vs_bf16x3_full_size(amd, dev, oracle_params):
     loop (derived above; two fp32-rounded runs may each sit a band away from the truth)."""
     D = amd.driver
     _, _, dev32 = _trace_bands()
-    band = 1.5 * dev32.max(axis=0)
+    band = 2.0 * dev32.max(axis=0)
     hp = D.load_hpams(); hp["render_im_sz"] = IM; hp["optimize"]["num_opts"] = 100
     obj = D.make_objects([41], IM)[0]
     g = torch.Generator().manual_seed(8)

@@ -284,10 +284,13 @@ torch.set_num_threads(2)
 hp = dict(lr_schedule=[dict(lr=1e-3, interval=100), dict(lr=1e-2, interval=100)])
 
 
+N_INST = {n_inst}
+
+
 def world(seed_codes=3):
     m = supnerf_amd.CodeNeRF(shape_blocks=1, texture_blocks=1)          # parameters only; the CPU forward below is the oracle's
     m.load_state_dict(O.init_decoder_params(seed=0, shape_blocks=1, texture_blocks=1), strict=True)
-    codes = T.CodeTables(4, 256, seed=seed_codes)
+    codes = T.CodeTables(N_INST, 256, seed=seed_codes)
     fwd = lambda xyz, vd, sc, tc: O.decoder_forward(dict(m.named_parameters()), xyz, vd, sc, tc)
     params = list(m.parameters()) + list(codes.parameters())
     return m, codes, fwd, params
@@ -295,7 +298,7 @@ def world(seed_codes=3):
 
 g = torch.Generator().manual_seed(11)
 B, n, S = 2, 6, 8
-full = dict(code_idx=torch.tensor([2, 0]), xyz=torch.rand(B, n, S, 3, generator=g) - 0.5,
+full = dict(code_idx=torch.tensor({code_idx}), xyz=torch.rand(B, n, S, 3, generator=g) - 0.5,
             viewdir=torch.nn.functional.normalize(torch.randn(B, n, 1, 3, generator=g), dim=-1).repeat(1, 1, S, 1),
             z_vals=torch.sort(torch.rand(B, S, generator=g) * 4 + 9, dim=-1)[0], rgb_tgt=torch.rand(B, n, 3, generator=g),
             occ_pixels=torch.tensor([1., -1., 0., 1., 1., -1.]).view(1, n, 1).repeat(B, 1, 1))
@@ -303,7 +306,7 @@ mine = {{k: v[rank:rank + 1] for k, v in full.items()}}
 
 # two ranks, one object each, two iterations
 m, codes, fwd, params = world()
-bucket = T.GradBucket(params)
+bucket = T.GradBucket(params, row_sparse=list(codes.parameters()) if {row_sparse} else ())
 opt = T.make_optimizer(m, codes, hp)
 for it in range(2):
     out = T.train_step(fwd, codes, opt, bucket, mine, 0.1, composite=O.volume_rendering_batch)
@@ -325,17 +328,24 @@ other = [torch.empty_like(flat) for _ in range(2)]
 dist.all_gather(other, flat)
 assert torch.equal(other[0], other[1])                      # replicas stay bit-identical
 assert float(bucket.flat.abs().max()) == 0.0                # zeroed for the next iteration, views intact
+assert all(float(p.grad.abs().max()) == 0.0 for p in bucket.rows)
+if {row_sparse}:
+    assert bucket.flat.numel() == sum(p.numel() for p in m.parameters())      # the tables are NOT in the all-reduced bucket
 bucket.check_views()
 dist.destroy_process_group()
 print("ok", rank, worst)
 """
 
 
-def test_training_step_two_ranks_gloo(tmp_path):
-    """DDP-style step: per-rank batch slice + one bucket all-reduce == single-process step on the full batch."""
-    port = 31500 + (os.getpid() % 2000)
+@pytest.mark.parametrize("n_inst,code_idx,row_sparse", [(4, [2, 0], False), (4, [2, 0], True), (10000, [9731, 12], True), (10000, [77, 77], True)])
+def test_training_step_two_ranks_gloo(tmp_path, n_inst, code_idx, row_sparse):
+    """DDP-style step: per-rank batch slice + one bucket all-reduce (+ the row exchange of the code tables) == single-process
+    step on the full batch -- with the tables inside the dense bucket (small table) and with the row-sparse exchange, at 4 and at 10 000
+    instances (src/trainer_unified_nuscenes.py:276-285: a step touches B rows; :414-422: AdamW still decays every row), and with both
+    ranks touching the SAME row."""
+    port = 31500 + (os.getpid() % 2000) + (7 if row_sparse else 0) + (13 if n_inst > 4 else 0) + code_idx[0] % 5
     script = tmp_path / "t.py"
-    script.write_text(_TRAIN_WORKER.format(root=ROOT, port=port))
+    script.write_text(_TRAIN_WORKER.format(root=ROOT, port=port, n_inst=n_inst, code_idx=code_idx, row_sparse=row_sparse))
     procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
