@@ -98,9 +98,9 @@ int snr_pack_weights(const float* const* tensors, int n_tensors, int shape_block
  *   relu_masks   : NULL, or snr_mask_bytes(P,...) bytes that the backward pass needs
  *   activations  : NULL, or (shape_blocks+texture_blocks+4, P, 256) floats: training mode, receives the INPUT of every
  *                  MFMA layer after the first (slot l = input of layer l+1; the last slot = input of rgb.2, 128 columns
- *                  used).  Needs relu_masks; both precisions.  Together with `layer_grads` of snr_decoder_bwd it turns the weight gradients
- *                  into the products dW_l = G_l^T X_l of snr_weight_grad (the weight half of the backward of
- *                  src/trainer_unified_nuscenes.py:334).
+ *                  used).  Needs relu_masks; both precisions.  Together with `layer_grads` of snr_decoder_bwd and the encodings of
+ *                  snr_pe_points they are the X operands of the weight-gradient products dW_l = G_l^T X_l of snr_weight_grad (the weight
+ *                  half of the backward of src/trainer_unified_nuscenes.py:334).
  * ---------------------------------------------------------------------------------- */
 size_t snr_mask_bytes(int64_t n_points, int shape_blocks, int texture_blocks);
 int snr_decoder_fwd(const float* xyz, const float* viewdir, const float* latent, const float* packed,
@@ -218,6 +218,10 @@ int snr_composite_bwd(const float* sigmas, const float* rgbs, const float* z_val
  * ---------------------------------------------------------------------------------- */
 int snr_encode_fwd(const snr_render_args* a, float* xyz, float* viewdir, float* z_out,
                    float* pe_xyz, float* pe_dir, uint8_t* hit, void* stream);
+/* Positional encodings of explicit points (PE, src/model_supnerf.py:155-161) in the layout the training step's weight-gradient products
+ * read: xyz, viewdir (P,3) -> out (P,96), 16-byte aligned: columns 0..62 = PE(xyz, 10 frequencies), 63 = 0, 64..90 = PE(viewdir, 4
+ * frequencies), 91..95 = 0 -- the input of encoding_xyz and the direction features of encoding_viewdir (X of their dW = G^T X). */
+int snr_pe_points(const float* xyz, const float* viewdir, int64_t n_points, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Loss / metric tail of one optimise iteration: replaces the three masked reductions the callers run right after the render

@@ -60,6 +60,7 @@ _SIGS = {
     "snr_composite_fwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P]),
     "snr_composite_bwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "snr_encode_fwd": (C.c_int, [C.POINTER(RenderArgs), _P, _P, _P, _P, _P, _P, _P]),
+    "snr_pe_points": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "snr_loss_tail_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, _P, _P]),
     "snr_loss_tail_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, _P, _P, _P, _P]),
     "snr_weight_grad_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),

@@ -487,6 +487,44 @@ __global__ void __launch_bounds__(256) encode_kernel(RayGeom g, float* __restric
     }
 }
 
+// Positional encodings of explicit points, as the weight-gradient products of the training step read them: out [P][96] = PE(xyz) (63 columns
+// + 1 zero) | PE(dir) (27 + 5 zeros).  128 points per block; every angle is evaluated once (sine and cosine), the block's rows are assembled
+// in LDS and leave with 16-byte stores.
+__global__ void __launch_bounds__(256) pe_points_kernel(const float* __restrict__ xyz, const float* __restrict__ viewdir, long long P,
+                                                        float* __restrict__ out) {
+    constexpr int W = 96, NP = 128;
+    __shared__ __attribute__((aligned(16))) float row[NP * W];
+    __shared__ float pt[NP][6];
+    const long long base = blockIdx.x * (long long)NP;
+    const int n_here = (int)((P - base) < NP ? (P - base) : NP);
+    for (int i = threadIdx.x; i < n_here * 6; i += 256) {
+        const int p = i / 6, a = i - 6 * p;
+        pt[p][a] = a < 3 ? xyz[(base + p) * 3 + a] : viewdir[(base + p) * 3 + a - 3];
+    }
+    __syncthreads();
+    constexpr int NQ = 3 * XYZ_FREQ + 3 * DIR_FREQ;        // 30 + 12 (frequency, axis) pairs per point
+    for (int i = threadIdx.x; i < n_here * NQ; i += 256) {
+        const int p = i / NQ, q = i - p * NQ;
+        float sn, cs;
+        if (q < 3 * XYZ_FREQ) {
+            pe_sincos(ldexpf(pt[p][q % 3], q / 3), &sn, &cs);
+            row[p * W + 3 + q] = sn; row[p * W + 3 + 3 * XYZ_FREQ + q] = cs;
+        } else {
+            const int qd = q - 3 * XYZ_FREQ;
+            pe_sincos(ldexpf(pt[p][3 + qd % 3], qd / 3), &sn, &cs);
+            row[p * W + 64 + 3 + qd] = sn; row[p * W + 64 + 3 + 3 * DIR_FREQ + qd] = cs;
+        }
+    }
+    for (int i = threadIdx.x; i < n_here * 12; i += 256) {      // the raw coordinates and the zero padding: columns 0..2, 63, 64..66, 91..95
+        const int p = i / 12, k = i - 12 * p;
+        const int col = k < 3 ? k : (k == 3 ? 63 : (k < 7 ? 64 + k - 4 : 91 + k - 7));
+        row[p * W + col] = k < 3 ? pt[p][k] : (k >= 4 && k < 7 ? pt[p][3 + k - 4] : 0.f);
+    }
+    __syncthreads();
+    f32x4* dst = reinterpret_cast<f32x4*>(out + base * W);      // base * 96 floats: 16-byte aligned with `out`
+    for (int i = threadIdx.x; i < n_here * (W / 4); i += 256) dst[i] = reinterpret_cast<const f32x4*>(row)[i];
+}
+
 __global__ void encode_dir_kernel(RayGeom g, float* __restrict__ pe_dir) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= g.n_rays * D_DIR) return;
@@ -701,6 +739,13 @@ int snr_composite_bwd(const float* sigmas, const float* rgbs, const float* z_val
                                                                         d_rgb, d_depth, d_acc, d_sigmas, d_rgbs, d_z)
     if (S <= 64) SNR_LAUNCH_CB(1); else if (S <= 128) SNR_LAUNCH_CB(2); else if (S <= 192) SNR_LAUNCH_CB(3); else SNR_LAUNCH_CB(4);
 #undef SNR_LAUNCH_CB
+    return snr_check_launch_();
+}
+
+int snr_pe_points(const float* xyz, const float* viewdir, int64_t n_points, float* out, void* stream_) {
+    if (n_points == 0) return SNR_OK;
+    if (!xyz || !viewdir || !out || n_points < 0 || (((uintptr_t)out) & 15)) return SNR_E_ARG;
+    pe_points_kernel<<<(unsigned)((n_points + 127) / 128), 256, 0, (hipStream_t)stream_>>>(xyz, viewdir, n_points, out);
     return snr_check_launch_();
 }
 

@@ -6,8 +6,8 @@ checkpoints (``saved['model_params']``) load with ``load_state_dict``.  The ResN
 SUPNeRF is out of scope (it stays a stock PyTorch module supplied by the caller).
 
 What runs where:
-  * per-object latent layers ``*_latent_layer_*`` -- stock PyTorch (B x 256 GEMMs, autograd gives the code
-    and latent-weight gradients);
+  * per-object latent layers ``*_latent_layer_*`` -- stock PyTorch (B x 256 GEMMs; autograd gives the code gradients,
+    and the latent-weight gradients in training mode);
   * the per-point decoder (8 GEMMs per sample point) -- ``libsupnerf_hip.so``;
   * ``fused_render`` additionally fuses sampling, frame transforms, positional encoding and the
     alpha composite into the same launch (used by ``supnerf_amd.utils`` / ``supnerf_amd.renderer``).
@@ -50,8 +50,10 @@ class _DecoderBase(nn.Module):
         self._packed_key = None
         # arithmetic of the per-point GEMMs: "fp32" (exact), "bf16x3" (split-bf16) or "auto" (bf16x3 where supported)
         self.precision = "auto"
-        # False (optimise / inference, the default): codes, latent layers and poses receive gradients, the per-point decoder
-        # weights are constants.  True (training): forward() also differentiates the per-point weights (fp32 kernels).
+        # False (optimise / inference, the default): the DECODER is a constant -- codes and poses receive gradients, no decoder weight does
+        # (neither the per-point layers nor the per-object latent layers).  That is what the reference's optimisers use: their AdamW
+        # holds codes and pose only (src/optimizer_nuscenes.py:1762-1769); the weight gradients torch computes there are never read.
+        # True (training): forward() also differentiates every decoder weight, in the arithmetic ``precision`` selects.
         self.train_decoder_weights = False
 
     # ---- packed per-point weights, re-packed only when a tensor changed
@@ -98,12 +100,14 @@ class _DecoderBase(nn.Module):
     def latent_terms(self, shape_latent: torch.Tensor, texture_latent: torch.Tensor) -> torch.Tensor:
         """(B, shape_blocks+texture_blocks, 256): z_j = ReLU(Lin_j(code)) (src/model_supnerf.py:253,261), hoisted out
         of the per-ray loop.  With no blocks at all a dummy (B,1,256) of zeros is returned.  When the latent layers' weights are
-        constants (optimise / inference: frozen, or no gradient being recorded) all of them are ONE GEMM over [shape code | texture code];
-        gradients still reach the codes."""
+        constants (``train_decoder_weights`` False, frozen parameters, or no gradient being recorded) all of them are ONE GEMM over
+        [shape code | texture code]: two launches forward, two backward (the per-layer form costs ~35 small launches per call with its
+        weight gradients); gradients still reach the codes."""
         n_lat = self.shape_blocks + self.texture_blocks
         if n_lat and shape_latent.is_cuda:
             lat_layers, _ = self._latent_params()
-            if not torch.is_grad_enabled() or not any(q.requires_grad for l in lat_layers for q in (l.weight, l.bias)):
+            if not self.train_decoder_weights or not torch.is_grad_enabled() or \
+                    not any(q.requires_grad for l in lat_layers for q in (l.weight, l.bias)):
                 w_lat, b_lat, _, _ = self._stacked()
                 codes = torch.cat([shape_latent, texture_latent], dim=-1)
                 return torch.relu(torch.addmm(b_lat, codes, w_lat)).view(shape_latent.shape[0], n_lat, 256)

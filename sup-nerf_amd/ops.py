@@ -547,6 +547,34 @@ def weight_grad(G, n_out, X, n_in, want_bias=True, out=None, ws=None, precision=
     return dW, db
 
 
+def pe_points(xyz, viewdir):
+    """(P,96) = PE(xyz) (63 columns, 1 zero) | PE(viewdir) (27 columns, 5 zeros): include/supnerf_hip.h snr_pe_points."""
+    xyz, viewdir = _f32c(xyz), _f32c(viewdir)
+    _need_gpu(xyz, viewdir)
+    P, dev = xyz.shape[0], xyz.device
+    if xyz.shape != (P, 3) or viewdir.shape != (P, 3):
+        raise SnrError("pe_points: xyz and viewdir must both be (P,3)")
+    out = torch.empty(P, 96, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().snr_pe_points(_p(xyz), _p(viewdir), P, _p(out), _stream(dev)), "snr_pe_points")
+    return out
+
+
+_PACK_CACHE = {}
+
+
+def _packed_for(names, weights, shape_blocks, texture_blocks):
+    """The packed stream of these per-point weights, re-packed only when a tensor changed (every optimiser step bumps the versions; an
+    evaluation pass between two steps, or a second forward before the update, re-uses the buffer)."""
+    key = (shape_blocks, texture_blocks) + tuple((w.data_ptr(), w._version, str(w.device)) for w in weights)
+    hit = _PACK_CACHE.get("k")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    packed = pack_weights(dict(zip(names, weights)), shape_blocks, texture_blocks)
+    _PACK_CACHE["k"] = (key, packed)
+    return packed
+
+
 class DecoderPointsTrain(torch.autograd.Function):
     """Training-mode decoder (SURVEY 8a9 mode B): like DecoderPoints but the per-point decoder WEIGHTS are inputs too and
     receive gradients.  The layer-chain kernels additionally write every layer's input X_l (forward) and pre-activation
@@ -569,7 +597,7 @@ class DecoderPointsTrain(torch.autograd.Function):
         prec = resolve_precision(precision, shape_blocks, texture_blocks, xyz.shape[0] // max(latent.shape[0], 1))
         wgrad_precision = "bf16x3" if prec == BF16X3 else "fp32"
         names = per_point_tensor_names(shape_blocks, texture_blocks)
-        packed = pack_weights(dict(zip(names, weights)), shape_blocks, texture_blocks)
+        packed = _packed_for(names, weights, shape_blocks, texture_blocks)
         P, dev = xyz.shape[0], xyz.device
         n_slots = shape_blocks + texture_blocks + 4
         act = torch.empty(n_slots, P, 256, device=dev)
@@ -596,22 +624,21 @@ class DecoderPointsTrain(torch.autograd.Function):
                                           ctx.needs_input_grad[2], ctx.needs_input_grad[0], ctx.needs_input_grad[1], precision=prec,
                                           layer_grads=G)
         # ---- weight gradients: dW_l = G_l^T X_l, db_l = sum_p G_l on the split-K MFMA kernel (snr_weight_grad), one launch + one
-        # reduction per layer; X of layer 0 and the direction features are the positional encodings (recomputed: 63 + 27 columns)
-        def pe_padded(v, L, width):
-            arg = torch.cat([v * (2.0 ** i) for i in range(L)], -1)
-            return torch.cat([v, torch.sin(arg), torch.cos(arg), v.new_zeros(v.shape[0], width - 3 - 6 * L)], -1)
+        # reduction per layer; X of layer 0 and the direction features are the positional encodings, one launch of snr_pe_points (``pe``:
+        # columns 0..63 PE(xyz), 64..95 PE(dir); round 2 recomputed them with torch.sin / cos / cat: 0.3 ms a step)
+        pe = pe_points(xyz, viewdir)
         li_view, li_rgb0 = sb + 2, sb + tb + 3
         ws = torch.empty(_lib.lib().snr_weight_grad_ws_bytes(P, 256, 256), dtype=torch.uint8, device=dev)
         by_layer = {}
         for li in range(n_slots):              # MFMA layers in order; the two small heads follow
             n_out = 128 if li == li_rgb0 else 256
             if li == 0:
-                by_layer[li] = weight_grad(G[li], n_out, pe_padded(xyz, 10, 64), 64, ws=ws, precision=wprec)
+                by_layer[li] = weight_grad(G[li], n_out, pe[:, :64], 64, ws=ws, precision=wprec)
                 by_layer[li] = (by_layer[li][0][:, :63].contiguous(), by_layer[li][1])
             elif li == li_view:
                 dW = torch.empty(256, 256 + 28, device=dev)
                 _, db = weight_grad(G[li], 256, act[li - 1], 256, out=(dW[:, :256], torch.empty(256, device=dev)), ws=ws, precision=wprec)
-                weight_grad(G[li], 256, pe_padded(viewdir, 4, 28), 28, out=(dW[:, 256:], None), ws=ws, precision=wprec)
+                weight_grad(G[li], 256, pe[:, 64:], 28, out=(dW[:, 256:], None), ws=ws, precision=wprec)
                 by_layer[li] = (dW[:, :283].contiguous(), db)
             else:
                 by_layer[li] = weight_grad(G[li], n_out, act[li - 1], 256, ws=ws, precision=wprec)

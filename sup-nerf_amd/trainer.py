@@ -121,7 +121,7 @@ class GradBucket:
         if self.rows and rows is None:
             raise ValueError("GradBucket.allreduce_mean: row-sparse tables need the rows of this step (batch['code_idx'])")
         if self.rows:
-            self._touched = torch.unique(rows.to(self.flat.device).long())
+            self._touched = rows.to(self.flat.device).long()          # (one rank: duplicates are harmless for the zeroing, and torch.unique would sync)
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1):
             return
         world = dist.get_world_size(self.group)
@@ -132,7 +132,7 @@ class GradBucket:
         # every rank sends its unique touched rows, padded to the common length with index -1 (zero rows); one all-gather of the indices
         # and one of the [table 0 | table 1 | ...] gradient rows
         dev = self.flat.device
-        uniq = self._touched
+        uniq = torch.unique(self._touched)            # (a row touched twice holds the sum already: it must travel once)
         n_mine = torch.tensor([uniq.numel()], device=dev, dtype=torch.int64)
         sizes = [torch.zeros_like(n_mine) for _ in range(world)]
         dist.all_gather(sizes, n_mine, group=self.group)

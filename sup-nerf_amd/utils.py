@@ -139,7 +139,7 @@ def _shared_depths(near, far, n_samples, device, z_fixed=False, jitter=None):
     if jitter is None:
         jitter = _jitter_override()
         if jitter is None:
-            jitter = torch.rand(n_samples, pin_memory=torch.device(device).type == "cuda")      # same CPU generator, same numbers; async upload
+            jitter = torch.rand(n_samples)                   # same CPU generator, same numbers (uploaded from pageable memory, see _draw_jitter)
     return z + jitter.to(device, non_blocking=True) * (far - near) / (2 * n_samples)
 
 
@@ -208,10 +208,13 @@ def clear_caches():
 
 
 def _draw_jitter(n_samples, device):
-    """The ``torch.rand(S)`` draw of ``sample_from_rays`` (src/utils.py:162) from the same CPU generator, uploaded without a host sync."""
+    """The ``torch.rand(S)`` draw of ``sample_from_rays`` (src/utils.py:162) from the same CPU generator, uploaded without a host sync.
+    From PAGEABLE memory on purpose: the 256 bytes go through the runtime's staging buffer (~10 us, no stream sync).  A pinned
+    allocation per call (round 2) is not reusable until its copy has run, so a caller that queues calls faster than the GPU finishes
+    them -- any no_grad loop -- paid a fresh hipHostMalloc (~1 ms) per call until the allocator's cache had grown to the queue depth."""
     jitter = _jitter_override()
     if jitter is None:
-        jitter = torch.rand(n_samples, pin_memory=torch.device(device).type == "cuda")
+        jitter = torch.rand(n_samples)
     return jitter.to(device, non_blocking=True)
 
 

@@ -356,3 +356,17 @@ def test_render_family_a_golden(amd, dev, golden, packed, oracle_params, tag, pr
     assert maxdiff(rgb, g["rgb"]) < TOL_RGB
     assert float((depth.cpu() - g["depth"]).abs().mean()) < TOL_DEPTH_MEAN and maxdiff(depth, g["depth"]) < TOL_DEPTH_MAX
     assert maxdiff(acc, g["acc"]) < TOL_ACC
+
+
+@pytest.mark.parametrize("P", [1, 127, 128, 1000, 70000])
+def test_pe_points_layout(amd, dev, P):
+    """snr_pe_points: (P,96) = PE(xyz) | 0 | PE(viewdir) | 0 (src/model_supnerf.py:155-161), the X operand of encoding_xyz's and
+    encoding_viewdir's weight gradients in the training step; partial blocks included."""
+    g = torch.Generator().manual_seed(P)
+    xyz = (torch.rand(P, 3, generator=g) - 0.5) * 2
+    vd = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    out = amd.ops.pe_points(xyz.to(dev), vd.to(dev)).cpu()
+    want = torch.cat([O.positional_encoding(xyz, 10), torch.zeros(P, 1), O.positional_encoding(vd, 4), torch.zeros(P, 5)], dim=1)
+    assert out.shape == (P, 96)
+    assert float((out - want).abs().max()) < 5e-7            # (the kernels' sin / cos: 9e-8 of float64, the CPU's likewise)
+    assert torch.equal(out[:, :3], xyz) and torch.equal(out[:, 64:67], vd) and float(out[:, 63].abs().max()) == 0.0 and float(out[:, 91:].abs().max()) == 0.0

@@ -19,8 +19,16 @@ for prec in fp32 bf16x3; do
 done
 # 3. the one-object fused optimise loop (how many launches an iteration is, and what they cost)
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/loop -o loop -- python3 tools/prof_loop.py 30 > $out/loop.log 2>&1
-# 3b. the training step (BASELINE config 5's per-GPU shape): chains with dumps + the weight-gradient kernels
-rocprofv3 --kernel-trace --stats --output-format csv -d $raw/train -o train -- python3 tools/train_bench.py 8 > $out/train.log 2>&1
+# 2b. family B (NeRFRenderer.render_rays, SNR_Z_BOX): the same kernels with the box bounds / per-ray depths / Philox jitter in the prologue
+for prec in fp32 bf16x3; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $raw/box_fwd_$prec -o box_fwd -- python3 tools/prof_fwd.py $prec 20 fwd box > $out/box_fwd_${prec}.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $raw/box_fwd_bwd_$prec -o box_fwd_bwd -- python3 tools/prof_fwd.py $prec 20 bwd box > $out/box_fwd_bwd_${prec}.log 2>&1
+done
+# 3b. the training step (BASELINE config 5's per-GPU shape): chains with dumps + the weight-gradient kernels, both arithmetics
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/train -o train -- python3 tools/train_bench.py 8 bf16x3 > $out/train.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/train_fp32 -o train_fp32 -- python3 tools/train_bench.py 8 fp32 > $out/train_fp32.log 2>&1
+# 3c. the HBM-bound stand-alone kernels (encode with PE output, composite forward, scene composite)
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/hbm -o hbm -- python3 tools/prof_hbm.py > $out/hbm.log 2>&1
 # 4. counters of the dominant kernels, separate passes (no trace domains mixed in).  "fwd" = the headline forward (no ReLU bits saved),
 #    "bwd" = the optimiser's pair (forward that saves the bits + backward); the aggregation below takes the forward kernel's counters from
 #    the first and the backward kernel's from the second
