@@ -42,7 +42,8 @@ def _cache_put(cache, key, value):
 def _cam_table(K, px, py, like, key=None):
     """[(px - cx)/fx, (py - cy)/fy, 1] as ``like``'s dtype on ``like``'s device (the first half of get_rays, src/utils.py:122-131)."""
     if key is not None:
-        key = key + (tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2])), str(like.device), like.dtype)
+        Kc = K.detach().cpu() if torch.is_tensor(K) and K.is_cuda else K          # (one host copy, not four scalar reads of a device tensor)
+        key = key + (tuple(float(v) for v in (Kc[0, 0], Kc[1, 1], Kc[0, 2], Kc[1, 2])), str(like.device), like.dtype)
         hit = _CAM_CACHE.get(key)
         if hit is not None:
             return hit
@@ -218,15 +219,21 @@ def _draw_jitter(n_samples, device):
     return jitter.to(device, non_blocking=True)
 
 
-def _rays_and_depths(K, cam_pose, roi, uv_steps, obj_diag, n_samples, ids=None):
-    """Rays of the roi's pixel grid (optionally the subset ``ids``) and the shared depth vector: what render_rays{,_v2} / render_full_img
-    compute before the render (src/utils.py:445,462-470 + sample_from_rays :159-164).  Pose on the GPU: ONE launch (camera table cached,
-    rotation + normalisation + sphere bounds + two-sided linspace + jitter in ``snr_cam_rays_fwd``, backward one launch)."""
+def _rays_and_depths(K, cam_pose, roi, uv_steps, obj_diag, n_samples, ids=None, pixels=None):
+    """Rays of the roi's pixel grid (optionally the subset ``ids``), or of the listed ``pixels`` = (x_vec, y_vec) in image coordinates, and
+    the shared depth vector: what render_rays{,_v2,_specified} / render_full_img compute before the render (src/utils.py:445,462-470,
+    515-520 + sample_from_rays :159-164).  Pose on the GPU: ONE launch (camera table cached, rotation + normalisation + sphere bounds +
+    two-sided linspace + jitter in ``snr_cam_rays_fwd``, backward one launch)."""
     if _fusable_pose(cam_pose):
-        x0, y0, x1, y1 = [int(v) for v in roi]
-        nx, ny = (int(uv_steps[0]), int(uv_steps[1])) if uv_steps is not None else (x1 - x0, y1 - y0)
-        xs, ys = torch.linspace(x0, x1 - 1, nx), torch.linspace(y0, y1 - 1, ny)
-        cam = _cam_table(K, xs[None, :].expand(ny, nx), ys[:, None].expand(ny, nx), cam_pose, key=("grid", x0, y0, x1, y1, nx, ny)).reshape(-1, 3)
+        if pixels is not None:
+            x_vec, y_vec = np.asarray(pixels[0]), np.asarray(pixels[1])
+            cam = _cam_table(K, torch.from_numpy(x_vec), torch.from_numpy(y_vec), cam_pose,
+                             key=("pix", x_vec.shape, hash(x_vec.tobytes()), hash(y_vec.tobytes()))).reshape(-1, 3)
+        else:
+            x0, y0, x1, y1 = [int(v) for v in roi]
+            nx, ny = (int(uv_steps[0]), int(uv_steps[1])) if uv_steps is not None else (x1 - x0, y1 - y0)
+            xs, ys = torch.linspace(x0, x1 - 1, nx), torch.linspace(y0, y1 - 1, ny)
+            cam = _cam_table(K, xs[None, :].expand(ny, nx), ys[:, None].expand(ny, nx), cam_pose, key=("grid", x0, y0, x1, y1, nx, ny)).reshape(-1, 3)
         if ids is not None:
             cam = cam[torch.as_tensor(ids, device=cam.device)]
         if cam.shape[0] > 0:
@@ -234,7 +241,10 @@ def _rays_and_depths(K, cam_pose, roi, uv_steps, obj_diag, n_samples, ids=None):
             rays_o, viewdir, z = ops.CamRays.apply(cam_pose[:3, :].unsqueeze(0), cam.unsqueeze(0), _const(float(obj_diag) / 2, 1, dev),
                                                    _draw_jitter(n_samples, dev).reshape(1, n_samples), n_samples)
             return rays_o, viewdir, z[0]
-    rays_o, viewdir = get_rays(K, cam_pose, roi, uv_steps=uv_steps)
+    if pixels is not None:
+        rays_o, viewdir = get_rays_specified(K, cam_pose, pixels[0], pixels[1])
+    else:
+        rays_o, viewdir = get_rays(K, cam_pose, roi, uv_steps=uv_steps)
     if ids is not None:
         rays_o, viewdir = rays_o[ids], viewdir[ids]
     near, far = _sphere_bounds(cam_pose, obj_diag)
@@ -272,12 +282,14 @@ def _resize_to(img, mask_occ, im_sz, device):
     same CPU crop in every iteration."""
     key = (img.data_ptr(), img._version, tuple(img.shape), mask_occ.data_ptr(), mask_occ._version, tuple(mask_occ.shape), int(im_sz), str(device))
     hit = _TGT_CACHE.get(key)
-    if hit is not None and hit[0]() is img and hit[1]() is mask_occ:
+    # the cached targets are handed out as they are (a clone per call would be a launch per call): a caller that edits them in place --
+    # reference-style code does, e.g. ``occ_pixels[occ_pixels < 0] = 0`` -- bumps their version counter, and the entry is rebuilt
+    if hit is not None and hit[0]() is img and hit[1]() is mask_occ and hit[2]._version == hit[4] and hit[3]._version == hit[5]:
         return hit[2], hit[3]
     im, mk = _resize(img, mask_occ, im_sz)
     tgt, occ = im.reshape(-1, 3).to(device), mk.reshape(-1, 1).to(device)
     import weakref
-    _cache_put(_TGT_CACHE, key, (weakref.ref(img), weakref.ref(mask_occ), tgt, occ))
+    _cache_put(_TGT_CACHE, key, (weakref.ref(img), weakref.ref(mask_occ), tgt, occ, tgt._version, occ._version))
     return tgt, occ
 
 
@@ -352,11 +364,9 @@ def render_rays_v2(model, device, img, mask_occ, cam_pose, obj_diag, K, roi, n_s
 def render_rays_specified(model, device, img, mask_occ, cam_pose, obj_diag, K, roi, x_vec, y_vec, n_samples, shapecode, texturecode,
                           shapenet_obj_cood, sym_aug, kitti2nusc=False):
     """src/utils.py:504-551: rays at listed pixels of the crop (lidar pixels in the optimisers)."""
-    rays_o, viewdir = get_rays_specified(K, cam_pose, x_vec + int(roi[0]), y_vec + int(roi[1]))
+    rays_o, viewdir, z = _rays_and_depths(K, cam_pose, roi, None, obj_diag, n_samples, pixels=(x_vec + int(roi[0]), y_vec + int(roi[1])))
     rgb_tgt = img[y_vec, x_vec, :].to(device)
     occ_pixels = mask_occ[y_vec, x_vec, :].to(device)
-    near, far = _sphere_bounds(cam_pose, obj_diag)
-    z = _shared_depths(near, far, n_samples, rays_o.device)
     frame = _frame(_sym_coin(sym_aug), kitti2nusc, shapenet_obj_cood)
     rgb, depth, acc = _render_shared_z(model, device, rays_o, viewdir, z, obj_diag, frame, shapecode, texturecode)
     return rgb, depth, acc, rgb_tgt, occ_pixels

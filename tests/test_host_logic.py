@@ -72,6 +72,14 @@ def test_api_caches_follow_their_inputs(amd):
     d = U._resize_to(img.clone(), mask, 8, "cpu")                          # another tensor with the same numbers: its own entry
     assert d[0] is not c[0] and torch.equal(d[0], c[0])
     assert U._resize_to(img, mask, 4, "cpu")[0].shape == (16, 3)           # another size
+    # a caller that edits the RETURNED targets in place (reference-style ``occ_pixels[occ_pixels < 0] = 0``) must not poison later calls
+    e = U._resize_to(img, mask, 8, "cpu")
+    want_occ = e[1].clone()
+    e[1][e[1] < 0] = 0
+    f = U._resize_to(img, mask, 8, "cpu")
+    assert f[1] is not e[1] and torch.equal(f[1], want_occ)
+    U.clear_caches()
+    assert U._resize_to(img, mask, 8, "cpu")[0] is not f[0]
     K = torch.tensor([[1000., 0., 500.], [0., 1000., 300.], [0., 0., 1.]])
     pose = torch.cat([torch.eye(3), torch.tensor([[0.1], [0.2], [5.0]])], 1)
     o1, d1 = U.get_rays(K, pose, [100, 50, 164, 114], uv_steps=[8, 8])
