@@ -216,3 +216,20 @@ def test_waymo_loop_runs():
     m, sc, tc, pose = D.optimize_objects_batched(model, dev, objs, hp, torch.randn(2, 256, generator=g) * 0.3, torch.randn(2, 256, generator=g) * 0.3,
                                                  [0, 1], reg_iters=1)
     assert m.shape == (2, 6, 4) and bool(torch.isfinite(m).all()) and bool((m[:, -1, 0] > m[:, 0, 0]).all())
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` as the driver calls it (no launcher, no WORLD_SIZE): the script starts its two ranks itself and prints ONE
+    JSON line for the job.  On this one-GPU box the ranks rendezvous over gloo and share the card (SNR_BENCH_BACKEND=gloo: a rehearsal of
+    the N > 1 branch, the numbers mean nothing); on an 8-GPU node the same command runs one rank per GPU over RCCL."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SNR_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--headline-only"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["unit"] == "rays/s" and line["value"] > 0 and line["scaling"] == "weak"

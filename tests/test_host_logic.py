@@ -513,3 +513,38 @@ def test_kitti_host_geometry(amd, golden):
                 assert k != "optimize" or set(v) == set(hp[k])
             else:
                 assert hp[k] == v, (tag, k, hp[k], v)
+
+
+def test_bench_self_launch_parent_stays_off_the_gpu(monkeypatch, capsys):
+    """`python bench.py --gpus N` without WORLD_SIZE (how the driver calls it): the parent must start the ranks as CHILD processes with the
+    contract's torch.distributed.run command, relay exactly rank 0's JSON line, pass the exit code on -- and never initialise the GPU
+    itself (an exec / fork after HIP initialisation takes the box down)."""
+    import importlib.util
+    import subprocess as sp
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["kw"] = cmd, kw
+        return sp.CompletedProcess(cmd, 0, stdout='RCCL banner\n{"metric": "m", "value": 1.0, "n_gpus": 4}\n')
+    monkeypatch.setattr(sp, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    out = capsys.readouterr().out.strip().splitlines()
+    assert out == ['{"metric": "m", "value": 1.0, "n_gpus": 4}']                       # one line, the JSON, nothing else
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1].isdigit()
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert not torch.cuda.is_initialized()                                                # the parent never touched the GPU
+    # a failing child: its code comes back, nothing is invented on stdout
+    monkeypatch.setattr(sp, "run", lambda cmd, **kw: sp.CompletedProcess(cmd, 3, stdout=""))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 3 and capsys.readouterr().out == ""
