@@ -500,7 +500,7 @@ def main():
                                        "samples": N_SAMPLES, "steps": n_t, "dtype": DTYPE[p_t], "model_precision": m_t.precision}
         del m_t, codes, bucket, opt_t
     extra["training_step"]["note"] = ("trainer.train_step: forward + backward incl. every decoder weight gradient + one all-reduce of the flat gradient bucket + AdamW; "
-                                      "`fp32` = the reference's arithmetic (trainer default), `bf16x3` = split-bf16 chains and weight-gradient products")
+                                      "`fp32` = the reference's arithmetic, what `precision = 'auto'` trains in; `bf16x3` = split-bf16 chains and weight-gradient products, opt-in (2.2x faster; tests/test_driver_gpu.py::test_training_outcome_fp32_and_bf16x3_track_the_oracle has the evidence)")
     del batch
 
     log("HBM-bound kernels")

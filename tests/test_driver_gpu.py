@@ -78,15 +78,18 @@ def test_sharded_objects_single_process():
     assert list(D.shard_slice(3, 2, 1)) == [2]
 
 
-@pytest.mark.parametrize("precision", ["fp32", "auto"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 def test_training_step_matches_oracle(oracle_params, precision):
     """supnerf_amd.trainer.train_step on the HIP training path: losses and EVERY gradient of the first
     iteration against the oracle's autograd on the CPU, then three more iterations must keep lowering the loss.  Both arithmetics
-    (fp32: exact; auto: split-bf16 chains and weight-gradient products -- entries move by up to a percent where a ReLU flips)."""
+    (fp32: exact, the training default; bf16x3: split-bf16 chains and weight-gradient products, opt-in).  Mask-matched (tests/relu_bits.py): the oracle differentiates with
+    the ReLU bits the forward chain saved, so a flipped unit cannot move an entry by a percent and both arithmetics are held to 2e-4 of
+    each tensor's largest entry (round 2 accepted 5e-3 for split-bf16)."""
     import supnerf_amd
+    from relu_bits import relu_bits_of
     T = supnerf_amd.trainer
     dev = torch.device("cuda:0")
-    rel = 2e-4 if precision == "fp32" else 5e-3
+    rel = 2e-4
     m = supnerf_amd.CodeNeRF(shape_blocks=3, texture_blocks=1)
     m.load_state_dict(oracle_params, strict=True)
     m.precision = precision
@@ -99,32 +102,116 @@ def test_training_step_matches_oracle(oracle_params, precision):
                  viewdir=torch.nn.functional.normalize(torch.randn(B, n, 1, 3, generator=g), dim=-1).repeat(1, 1, S, 1),
                  z_vals=torch.sort(torch.rand(B, S, generator=g) * 4 + 9, dim=-1)[0], rgb_tgt=torch.rand(B, n, 3, generator=g),
                  occ_pixels=(torch.randint(0, 3, (B, n, 1), generator=g) - 1).float())
-    # oracle gradients (CPU autograd)
-    p_cpu = {k: v.detach().cpu().clone().requires_grad_() for k, v in m.named_parameters()}
-    w_sc = codes.shape_codes.weight.detach().cpu().clone().requires_grad_()
-    w_tc = codes.texture_codes.weight.detach().cpu().clone().requires_grad_()
-    ref = O.training_losses(p_cpu, batch["xyz"], batch["viewdir"], w_sc[batch["code_idx"]], w_tc[batch["code_idx"]], batch["z_vals"],
-                            batch["rgb_tgt"], batch["occ_pixels"], 0.1)
-    ref[0].backward()
+    cpu_batch = batch
     # product path
     batch = {k: v.to(dev) for k, v in batch.items()}
     params = list(m.parameters()) + list(codes.parameters())
     bucket = T.GradBucket(params)
     sc, tc = codes(batch["code_idx"])
-    losses_all, total = T.nerf_losses(m, batch["xyz"], batch["viewdir"], sc, tc, batch["z_vals"], batch["rgb_tgt"], batch["occ_pixels"], 0.1)
+    seen = {}
+
+    def capturing(*a):
+        out = m(*a)
+        seen["masks"] = relu_bits_of(out[0], 3, 1)          # (before backward frees what the operator saved)
+        return out
+    losses_all, total = T.nerf_losses(capturing, batch["xyz"], batch["viewdir"], sc, tc, batch["z_vals"], batch["rgb_tgt"], batch["occ_pixels"], 0.1)
     total.backward()
     bucket.check_views()
+    # oracle gradients (CPU autograd) on the same piecewise-linear function
+    p_cpu = {k: v.detach().cpu().clone().requires_grad_() for k, v in m.named_parameters()}
+    w_sc = codes.shape_codes.weight.detach().cpu().clone().requires_grad_()
+    w_tc = codes.texture_codes.weight.detach().cpu().clone().requires_grad_()
+    with O.given_relu_masks(seen["masks"]):
+        ref = O.training_losses(p_cpu, cpu_batch["xyz"], cpu_batch["viewdir"], w_sc[cpu_batch["code_idx"]], w_tc[cpu_batch["code_idx"]],
+                                cpu_batch["z_vals"], cpu_batch["rgb_tgt"], cpu_batch["occ_pixels"], 0.1)
+        ref[0].backward()
     assert abs(float(total) - float(ref[0])) < 1e-5 and abs(float(losses_all["psnr"]) - float(ref[4])) < 0.01
     assert abs(float(losses_all["loss_reg"]) - float(ref[3])) < 1e-5
+    worst = 0.0
     for (name, p) in list(m.named_parameters()) + [("shape_codes", codes.shape_codes.weight), ("texture_codes", codes.texture_codes.weight)]:
         want = {"shape_codes": w_sc, "texture_codes": w_tc}.get(name, p_cpu.get(name)).grad
         err = float((p.grad.cpu() - want).abs().max())
+        worst = max(worst, err / (float(want.abs().max()) + 1e-30))
         assert err <= rel * float(want.abs().max()) + 1e-7, (name, err, float(want.abs().max()))
+    print(f"[training step, {precision}] worst gradient entry, relative to its tensor's largest: {worst:.2e}")
     bucket.zero()
     hp = dict(lr_schedule=[dict(lr=1e-4, interval=100), dict(lr=1e-3, interval=100)])
     opt = T.make_optimizer(m, codes, hp)
     trace = [float(T.train_step(m, codes, opt, bucket, batch, 0.1)["loss_total"]) for _ in range(4)]
     assert all(b < a for a, b in zip(trace, trace[1:])), trace
+
+
+def test_training_outcome_fp32_and_bf16x3_track_the_oracle(oracle_params):
+    """Which arithmetic may config 5 train in?  (VERDICT r2 #4b)  60 steps of ``trainer.train_step`` over four fixed mini-batches (2 objects
+    x 32 rays x 64 samples, decoder + codes trained, the reference's AdamW) with the exact-fp32 kernels and with the split-bf16 kernels,
+    against the SAME 60 steps on the CPU oracle in float64 (the truth) and in float32 (the reference's arithmetic: its distance from the
+    truth is the floor).  Loss curve and final decoder weights, the latter relative to how far training moved each tensor."""
+    import supnerf_amd
+    T = supnerf_amd.trainer
+    dev = torch.device("cuda:0")
+    STEPS, B, n, S = 60, 2, 32, 64
+    g = torch.Generator().manual_seed(5)
+    batches = [dict(code_idx=torch.tensor([(2 * k) % 6, (2 * k + 3) % 6]), xyz=torch.rand(B, n, S, 3, generator=g) - 0.5,
+                    viewdir=torch.nn.functional.normalize(torch.randn(B, n, 1, 3, generator=g), dim=-1).repeat(1, 1, S, 1),
+                    z_vals=torch.sort(torch.rand(B, S, generator=g) * 4 + 9, dim=-1)[0], rgb_tgt=torch.rand(B, n, 3, generator=g),
+                    occ_pixels=(torch.randint(0, 3, (B, n, 1), generator=g) - 1).float()) for k in range(4)]
+    hp = dict(lr_schedule=[dict(lr=1e-4, interval=40000), dict(lr=1e-4, interval=40000)])       # the reference's rates (jsonfiles/*.json)
+
+    def oracle_run(dtype):
+        c = lambda t: t.to(dtype) if t.is_floating_point() else t
+        p = {k: c(v).clone().requires_grad_() for k, v in oracle_params.items()}
+        codes = T.CodeTables(6, 256, seed=4)
+        w_sc, w_tc = c(codes.shape_codes.weight.detach()).clone().requires_grad_(), c(codes.texture_codes.weight.detach()).clone().requires_grad_()
+        opt = torch.optim.AdamW([{"params": list(p.values()), "lr": 1e-4}, {"params": [w_sc], "lr": 1e-4}, {"params": [w_tc], "lr": 1e-4}])
+        curve = []
+        for it in range(STEPS):
+            b = {k: c(v) for k, v in batches[it % 4].items()}
+            opt.zero_grad()
+            total = O.training_losses(p, b["xyz"], b["viewdir"], w_sc[b["code_idx"]], w_tc[b["code_idx"]], b["z_vals"], b["rgb_tgt"], b["occ_pixels"], 0.1)[0]
+            total.backward()
+            opt.step()
+            curve.append(float(total))
+        return np.array(curve), {k: v.detach().double() for k, v in p.items()}
+
+    def gpu_run(precision):
+        m = supnerf_amd.CodeNeRF(3, 1); m.load_state_dict(oracle_params, strict=True); m.precision = precision
+        m = m.to(dev); m.train_decoder_weights = True
+        codes = T.CodeTables(6, 256, seed=4).to(dev)
+        bucket = T.GradBucket(list(m.parameters()) + list(codes.parameters()), row_sparse=list(codes.parameters()))
+        opt = T.make_optimizer(m, codes, hp)
+        dev_batches = [{k: v.to(dev) for k, v in b.items()} for b in batches]
+        curve = [float(T.train_step(m, codes, opt, bucket, dev_batches[it % 4], 0.1)["loss_total"]) for it in range(STEPS)]
+        return np.array(curve), {k: v.detach().double().cpu() for k, v in m.named_parameters()}
+
+    c64, w64 = oracle_run(torch.float64)
+    c32, w32 = oracle_run(torch.float32)
+    init = {k: v.double() for k, v in oracle_params.items()}
+
+    def weight_dev(w, entrywise=False):
+        """Worst tensor: distance from the float64 run's weights relative to how far that run moved the tensor (L2; entry-wise maxima are
+        printed only: Adam turns a gradient entry at rounding level into a full-size step of random sign, so single dead entries differ
+        by their whole movement between any two runs)."""
+        if entrywise:
+            return max(float((w[k] - w64[k]).abs().max()) / (float((w64[k] - init[k]).abs().max()) + 1e-12) for k in w64)
+        return max(float((w[k] - w64[k]).norm()) / (float((w64[k] - init[k]).norm()) + 1e-12) for k in w64)
+    floor_c, floor_w = float(np.abs(c32 - c64).max()), weight_dev(w32)
+    assert c64[-1] < c64[0] - 0.01                                      # the 60 steps do train
+    res = {}
+    for precision in ("fp32", "auto", "bf16x3"):
+        c, w = gpu_run(precision)
+        dc, dw = float(np.abs(c - c64).max()), weight_dev(w)
+        res[precision] = (c, w)
+        print(f"[training outcome, {precision}] loss {c[0]:.4f} -> {c[-1]:.4f}; vs the float64 oracle run: loss curve {dc:.2e} (fp32 oracle {floor_c:.2e}), "
+              f"final weights {dw:.2e} of each tensor's training movement in L2 (fp32 oracle {floor_w:.2e}); worst single entry "
+              f"{weight_dev(w, True):.2e} ({weight_dev(w32, True):.2e})")
+        if precision == "bf16x3":
+            # split-bf16 training is opt-in: measured 3.6e-5 / 9.3e-3 (27x / 8x the fp32 floor); it must stay inside 1e-4 / 2e-2
+            assert dc < 1e-4 and dw < 2e-2, (precision, dc, dw)
+        else:
+            # the default: as close to the truth as the reference's own fp32 arithmetic is, within a factor of three
+            assert dc < 3 * floor_c + 1e-5 and dw < 3 * floor_w + 1e-3, (precision, dc, floor_c, dw, floor_w)
+    # "auto" in training mode IS the exact-fp32 path
+    assert np.array_equal(res["auto"][0], res["fp32"][0]) and all(torch.equal(res["auto"][1][k], res["fp32"][1][k]) for k in res["fp32"][1])
 
 
 def test_batched_loop_equals_per_object_loop():
