@@ -175,17 +175,6 @@ __device__ __forceinline__ void split_store(float v, XOp& o, int j) {
 }
 
 template <int NT, int NA>
-__device__ __forceinline__ void acc_bias(f32x16 (&acc)[NA], const float* __restrict__ bias /*LDS*/, int h) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 32 * t + 8 * j + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t][4 * j + e] = b[e];
-        }
-}
-template <int NT, int NA>
 __device__ __forceinline__ void acc_zero(f32x16 (&acc)[NA]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -193,104 +182,13 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[NA]) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 }
 
-// What happens to a finished accumulator tile of the PREVIOUS layer on its way to becoming operand step s of the
-// current layer (s = 2*tile + half: registers 8*half .. 8*half+7 of the tile).
-struct FwdEpi {
-    int floor;            // ReLU as an integer max on the bit pattern: 0 for a ReLU layer, INT_MIN for none
-    const float* bias;    // LDS: bias of the layer being accumulated (its accumulators start from it)
-    const float* zl;      // LDS: latent term added after the activation (a block of zeros if none)
-    float* dump;          // DUMP (training): this lane's row of the activation dump, [point][256] + 4h, or null for a point past the end
-};
 // pin an operand step where it is produced: without this LLVM sinks the whole epilogue down to its use in the next
 // step (behind the barrier), which serialises it with that step's MFMAs instead of hiding it under this step's
 __device__ __forceinline__ void pin(XOp& o) { asm volatile("" : "+v"(o.hi), "+v"(o.lo)); }
 
-// one quarter of a tile's epilogue: registers 8*HALF + 4*JJ .. +3 -> elements 4*JJ .. +3 of operand step 2*T + HALF.
-// MASKS = false (no gradient will be asked for): the ReLU bits are not collected, which saves ~3 of ~10 VALU ops per value --
-// with one wave per SIMD the layer chain is bounded by instruction ISSUE (about six 4-cycle slots per 32-cycle MFMA).
-// bias and latent vectors of one quarter: fetched from LDS at the top of a step, consumed half a step or more later, so no
-// lgkmcnt wait sits between the MFMAs (an exposed LDS round trip there stalls the in-order wave AND the matrix pipe)
-// ZADD = false: the latent terms came folded into the biases (snr_render_args::latent_bias), nothing is added here
-struct EpiVec { f32x4 z; };
-template <int T, int HALF, int JJ, bool ZADD = true>
-__device__ __forceinline__ void fwd_quarter_load(EpiVec& v, const FwdEpi& c, int h) {
-    const int j = 2 * HALF + JJ;
-    if constexpr (ZADD) v.z = *reinterpret_cast<const f32x4*>(c.zl + 32 * T + 8 * j + 4 * h);
-}
-template <int T, int HALF, int JJ, bool MASKS, bool ZADD = true, bool DUMP = false>
-__device__ __forceinline__ void fwd_quarter(const f32x16& acc, XOp& out, const FwdEpi& c, const EpiVec& v, uint32_t (&mask)[4]) {
-#ifdef SNR_EXP_NOEPI
-    return;
-#endif
-    const int j = 2 * HALF + JJ;
-    f32x4 dv;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int r = 4 * j + e;
-        const float a = acc[r];           // bias already inside (acc_bias)
-        // ReLU bits (only stored for ReLU layers), one VALU op per value and no VCC: v_alignbit shifts the word left and
-        // takes in the sign bit of a; the 32 values of a word arrive in register order (tile 2w r0..15, tile 2w+1 r0..15), so
-        // store_mask recovers bit (T&1)*16 + r = "a > 0" as ~bitreverse(word).  (a == +0.0 counts as positive.)
-        if (MASKS) mask[T >> 1] = __builtin_amdgcn_alignbit(mask[T >> 1], __builtin_bit_cast(uint32_t, a), 31);
-        // ReLU as v_max_i32 on the bit pattern (no canonicalising second max, -0 -> +0), then the latent term, then the hi/lo split.
-        // Plain C++ on purpose: the same epilogue on v_pk_add_f32 through inline asm has a quarter fewer VALU ops and is 2-4 % SLOWER,
-        // the scheduler cannot place asm statements under the MFMAs (sched_group_barrier does not see them as VALU).
-        const float y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, a), c.floor));
-        const float xv = ZADD ? y + v.z[e] : y;
-        split_store(xv, out, r & 7);
-        if (DUMP) dv[e] = xv;
-    }
-    // training: the next layer's fp32 input (features 32T + 8j + 4h .. +3 of this lane's point) goes to HBM for the weight-gradient product
-    if (DUMP) { if (c.dump) *reinterpret_cast<f32x4*>(c.dump + 32 * T + 8 * j) = dv; }
-    if (JJ == 1) pin(out);
-    if (MASKS) asm volatile("" : "+v"(mask[T >> 1]));      // keep the bit capture here (LLVM otherwise recomputes it at the layer's end)
-}
-template <int T, int HALF, bool MASKS, bool ZADD = true, bool DUMP = false>
-__device__ __forceinline__ void fwd_half_tile(const f32x16& acc, XOp& out, const FwdEpi& c, int h, uint32_t (&mask)[4]) {
-    EpiVec v0, v1;
-    fwd_quarter_load<T, HALF, 0, ZADD>(v0, c, h);
-    fwd_quarter_load<T, HALF, 1, ZADD>(v1, c, h);
-    fwd_quarter<T, HALF, 0, MASKS, ZADD, DUMP>(acc, out, c, v0, mask);
-    fwd_quarter<T, HALF, 1, MASKS, ZADD, DUMP>(acc, out, c, v1, mask);
-}
-
-// density head on finished enc_shape accumulators (bias included): this lane's share of w_sigma . y
-__device__ __forceinline__ float sigma_partial(const f32x16 (&acc)[8], const float* __restrict__ wsig, int h) {
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-    // the weight vectors of tile t+1 are requested before tile t's arithmetic (order pinned): one LDS round trip in flight per tile
-    // instead of 32 waited for one after the other with the matrix pipe idle
-    f32x4 wc[4], wn[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wc[j] = *reinterpret_cast<const f32x4*>(wsig + 8 * j + 4 * h);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        if (t + 1 < 8) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wn[j] = *reinterpret_cast<const f32x4*>(wsig + 32 * (t + 1) + 8 * j + 4 * h);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            d0 = fmaf(wc[j][0], acc[t][4 * j + 0], d0); d1 = fmaf(wc[j][1], acc[t][4 * j + 1], d1);
-            d2 = fmaf(wc[j][2], acc[t][4 * j + 2], d2); d3 = fmaf(wc[j][3], acc[t][4 * j + 3], d3);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wc[j] = wn[j];
-    }
-    return (d0 + d1) + (d2 + d3);
-}
-
-// interleave request for one half-step region: after every MFMA one LDS read (while there are any) and a few VALU ops, so the
-// fragment fetches for the next half-step and the previous layer's epilogue are spread under the MFMAs instead of in blocks.
-// Measured (tools/ab_time.py, interleaved rounds): forward: 2-3 VALU per MFMA and no read request is best (-4 % against 4 VALU, -2 % against no request
-// at all; 3 since the one-instance layer moved the accumulator reads out of the epilogue); backward, ~34 ops per 12 MFMAs: 3 VALU and no read request (-1 % against 4).
-#ifndef SNR_IL_DS
-#define SNR_IL_DS 0
-#endif
-#ifndef SNR_IL_VALU
-#define SNR_IL_VALU 3
-#endif
+// interleave request for one half-step region of the backward layer body (32x32x16 shape): after every MFMA a few VALU ops, so the
+// previous layer's epilogue is spread under the MFMAs instead of in blocks.  Measured (tools/ab_time.py, interleaved rounds), ~34 ops
+// per 12 MFMAs: 3 VALU and no LDS-read request (-1 % against 4).  (The forward's request is SNR_INTERLEAVE16 below.)
 #ifndef SNR_ILB_DS
 #define SNR_ILB_DS 0
 #endif
@@ -303,80 +201,200 @@ __device__ __forceinline__ float sigma_partial(const f32x16 (&acc)[8], const flo
         if (DS) __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);                      \
         if (VALU) __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);                  \
     }
-#define SNR_INTERLEAVE(N_MFMA) SNR_INTERLEAVE_(N_MFMA, SNR_IL_DS, SNR_IL_VALU)
 #define SNR_INTERLEAVE_B(N_MFMA) SNR_INTERLEAVE_(N_MFMA, SNR_ILB_DS, SNR_ILB_VALU)
-// One layer with 16 operand steps taken from acc (+ 2 direction steps for enc_viewdir), NT output tiles back into acc: the sums
-// build up in a second, local accumulator set; the previous layer's set is dead once its last quarter has become operand step 15
-// (during step 14), so the MFMAs of step 15 deposit the finished tiles there (vdst != srcC).  One code instance therefore serves
-// every layer of the chain (no A->B / B->A pair, no odd/even tails): the bf16x3 kernels are half the size they were, which
-// matters with a 64 KiB instruction cache shared by two CUs.
-// Each step is two half-steps of NT/2 tiles.  The A fragments of a half-step are fetched from LDS while the previous
-// half-step's MFMAs run (two fragment buffers), the next chunk is acquired half a step before it is needed, and the
-// previous layer's epilogue for operand step S+1 is split over the two half-steps of step S.
-template <int NT, bool MASKS, bool ZADD, bool DUMP = false>
-__device__ __forceinline__ void layer_fwd(f32x16 (&accP)[8], XOp (&x)[16], const char* xdir_lds, Ring& ring, char* lds,
-                                          const FwdEpi& c, bool extra, uint32_t (&mask)[4], int tid, int lane) {
-    f32x16 accC[8];
-    const int h = lane >> 5;
-    const unsigned voff = lane * 16u + 4096u;         // DMA source offset of this lane inside the wave's slice (+ 4096, see ring_piece)
-    constexpr int NTH = NT / 2;
-    constexpr int SPC = (NT == 8) ? 2 : 4;            // steps per 32 KiB chunk
-    constexpr bool TAIL = (NT != 8);                  // rgb.0: the stream ends with this layer
-    constexpr int NCH = 16 / SPC;                     // chunks of this layer
-    constexpr int STEP_BYTES = NT * 2 * 1024;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) mask[i] = 0u;
-    acc_bias<NT, 8>(accC, c.bias, h);
-    fwd_half_tile<0, 0, MASKS, ZADD, DUMP>(accP[0], x[0], c, h, mask);
-    Frags<NTH> fa, fb;
-    const char* w = ring_acquire(ring, lds) + lane * 16;
-    load_frags<NTH, 0>(fa, w);
-    ring_pieces_in<0, SPC, 0, NCH, TAIL>(ring, voff);
-#define SNR_FSTEP(S)                                                                                                   \
-    {                                                                                                                  \
-        const char* ws = w + ((S) % SPC) * STEP_BYTES;                                                                 \
-        EpiVec v0, v1;                                                                                                 \
-        load_frags<NTH, NTH>(fb, ws);                                                                                  \
-        if constexpr ((S) + 1 < 16) {                                                                                  \
-            fwd_quarter_load<(((S) + 1) >> 1), (((S) + 1) & 1), 0, ZADD>(v0, c, h);                                          \
-            fwd_quarter_load<(((S) + 1) >> 1), (((S) + 1) & 1), 1, ZADD>(v1, c, h);                                          \
-        }                                                                                                              \
-        if constexpr ((S) == 15) mma_half_to<NTH, 0, 8>(accP, accC, x[S], fa); else mma_half<NTH, 0, 8>(accC, x[S], fa);       \
-        ring_pieces_in<(2 * (S) + 1) % (2 * SPC), SPC, (2 * (S) + 1) / (2 * SPC), NCH, TAIL>(ring, voff);              \
-        if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0, MASKS, ZADD, DUMP>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v0, mask); \
-        SNR_INTERLEAVE(3 * NTH)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + STEP_BYTES);                                   \
-        else if constexpr ((S) + 1 < 16) { w = ring_acquire<TAIL && ((S) + 1) / SPC == NCH - 1>(ring, lds) + lane * 16; load_frags<NTH, 0>(fa, w); } \
-        if constexpr ((S) == 15) mma_half_to<NTH, NTH, 8>(accP, accC, x[S], fb); else mma_half<NTH, NTH, 8>(accC, x[S], fb);   \
-        if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0)                                                \
-            ring_pieces_in<(2 * (S) + 2) % (2 * SPC), SPC, (2 * (S) + 2) / (2 * SPC), NCH, TAIL>(ring, voff);          \
-        if constexpr ((S) + 1 < 16) fwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1, MASKS, ZADD, DUMP>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, v1, mask); \
-        SNR_INTERLEAVE(3 * NTH)                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-    }
-    SNR_FSTEP(0) SNR_FSTEP(1) SNR_FSTEP(2) SNR_FSTEP(3) SNR_FSTEP(4) SNR_FSTEP(5) SNR_FSTEP(6) SNR_FSTEP(7)
-    SNR_FSTEP(8) SNR_FSTEP(9) SNR_FSTEP(10) SNR_FSTEP(11) SNR_FSTEP(12) SNR_FSTEP(13) SNR_FSTEP(14) SNR_FSTEP(15)
-#undef SNR_FSTEP
-    if (extra) {      // enc_viewdir: k = 256..287 are the direction features
-        w = ring_acquire(ring, lds) + lane * 16;
-        ring_pieces<0, 8>(ring, voff);
-        XOp d0, d1;
-        d0.hi = *reinterpret_cast<const bf16x8*>(xdir_lds);        d0.lo = *reinterpret_cast<const bf16x8*>(xdir_lds + 1024);
-        d1.hi = *reinterpret_cast<const bf16x8*>(xdir_lds + 2048); d1.lo = *reinterpret_cast<const bf16x8*>(xdir_lds + 3072);
-        step_mma<NT, 8>(accP, d0, w);
-        step_mma<NT, 8>(accP, d1, w + STEP_BYTES);
-    }
-}
 
-
-// ------------------------------------------------------------------------------------------ forward kernel
+// ------------------------------------------------------------------------------------------ forward kernel (v_mfma_f32_16x16x32_bf16)
+// Round 3: the forward chain runs on the 16x16x32 shape.  Same structure as before -- transposed GEMMs Y^T = W X^T, the accumulators of
+// layer l are the B operands of layer l+1 without data movement, weights through the LDS-DMA ring, the previous layer's epilogue spread
+// under the MFMAs -- on tiles of 16 features x 16 points: the wave's 32 points are two column blocks c that share every A fragment;
+// register r of lane (n = lane & 15, g = lane >> 4) of accumulator tile T of block c holds feature 16 T + 4 g + r of point 16 c + n, and
+// an operand step of 32 k takes the tiles 2S and 2S+1 (element j of the lane's 8: feature 32 S + 16 (j >> 2) + 4 g + (j & 3), the k order
+// of the forward weight image).  Why: in MFMA-dense loops on random data the chip holds a ~17 % higher clock on this shape (2.15-2.29 vs
+// 1.82-1.96 GHz in-kernel, tools/_diag/shape_bench.hip) at 11 % more cycles for the same layer body (twice the MFMA instructions, each
+// leaving 8 instead of 24 cycles of issue shadow): the isolated layer chain ran 7-8 % faster in wall time.
 #ifdef SNR_STAMPS
 #define SNR_STAMP(i) do { if (lane == 0 && tile32 * 32 < io.n_points) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     reinterpret_cast<unsigned long long*>(io.sigmas)[tile32 * 16 + (i)] = t_; } } while (0)
 #else
 #define SNR_STAMP(i) do {} while (0)
 #endif
+
+#ifndef SNR_IL16_MFMA
+#define SNR_IL16_MFMA 1
+#endif
+#ifndef SNR_IL16_VALU
+#define SNR_IL16_VALU 1
+#endif
+#define SNR_INTERLEAVE16(N_MFMA)                                                         \
+    _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA) / SNR_IL16_MFMA; ++g_) {            \
+        __builtin_amdgcn_sched_group_barrier(0x008, SNR_IL16_MFMA, 0);                   \
+        if (SNR_IL16_VALU) __builtin_amdgcn_sched_group_barrier(0x002, SNR_IL16_VALU, 0);\
+    }
+
+struct Frag16 { bf16x8 hi[4], lo[4]; };        // A fragments of four 16-row tiles (one group): 8 KiB of the chunk, contiguous
+__device__ __forceinline__ void load16(Frag16& f, const char* wq /* chunk + group offset + lane*16 */) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f.hi[t] = *reinterpret_cast<const bf16x8*>(wq + (2 * t) * 1024);
+        f.lo[t] = *reinterpret_cast<const bf16x8*>(wq + (2 * t + 1) * 1024);
+    }
+}
+// 24 MFMAs of one group: tiles T0 .. T0+3, both column blocks, three split products each.  TO_P: the layer's last step, the finished
+// sums go to the (dead) previous accumulator set.
+template <int T0, bool TO_P>
+__device__ __forceinline__ void mma16(f32x4 (&accC)[2][16], f32x4 (&accP)[2][16], const XOp (&x)[2], const Frag16& f) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.hi[t], x[c].hi, accC[c][T0 + t], 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.hi[t], x[c].lo, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.lo[t], x[c].hi, a, 0, 0, 0);
+            if (TO_P) accP[c][T0 + t] = a; else accC[c][T0 + t] = a;
+        }
+}
+// one whole k32-step of NT16 tiles straight from a chunk (no fragment pipelining): enc_xyz and enc_viewdir's direction step
+template <int NT16>
+__device__ __forceinline__ void step_mma16(f32x4 (&acc)[2][16], const XOp (&x)[2], const char* ws /* chunk + step offset + lane*16 */) {
+#pragma unroll
+    for (int t = 0; t < NT16; ++t) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + (2 * t) * 1024);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ws + (2 * t + 1) * 1024);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, x[c].hi, acc[c][t], 0, 0, 0);
+            acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, x[c].lo, acc[c][t], 0, 0, 0);
+            acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, x[c].hi, acc[c][t], 0, 0, 0);
+        }
+    }
+}
+
+// What happens to a finished 16x16 accumulator tile of the PREVIOUS layer on its way into an operand step of the current one.
+struct Epi16 {
+    int floor;            // ReLU as an integer max on the bit pattern: 0 for a ReLU layer, INT_MIN for none
+    const float* bias;    // LDS: bias of the layer being accumulated (its accumulators start from it)
+    const float* zl;      // LDS: latent term added after the activation (a block of zeros if none)
+    float* dump[2];       // DUMP (training): the lane's rows of the activation dump for its two points, [point][256] + 4 g, or null
+};
+// four values (features 16 T + 4 g .. +3 of point 16 c + n) -> elements 4*HALF .. +3 of the operand step; ReLU bits shifted into `mbits`
+// in arrival order (T ascending, e ascending; see store_masks16)
+template <int HALF, bool MASKS, bool ZADD, bool DUMP>
+__device__ __forceinline__ void epi16(const f32x4& acc, XOp& o, const Epi16& c, int T, int cblk, int g, uint32_t& mbits) {
+#ifdef SNR_EXP_NOEPI
+    return;
+#endif
+    f32x4 z;
+    if (ZADD) z = *reinterpret_cast<const f32x4*>(c.zl + 16 * T + 4 * g);
+    f32x4 dv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = acc[e];           // bias already inside
+        if (MASKS) mbits = __builtin_amdgcn_alignbit(mbits, __builtin_bit_cast(uint32_t, a), 31);
+        const float y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, a), c.floor));
+        const float xv = ZADD ? y + z[e] : y;
+        split_store(xv, o, 4 * HALF + e);
+        if (DUMP) dv[e] = xv;
+    }
+    if (DUMP) { if (c.dump[cblk]) *reinterpret_cast<f32x4*>(c.dump[cblk] + 16 * T) = dv; }
+    if (HALF == 1) pin(o);
+    if (MASKS) asm volatile("" : "+v"(mbits));
+}
+
+// One layer: NT16 output tiles (16: a 256-wide layer, one k32-step per 32 KiB chunk; 8: rgb.0, two steps per chunk, the stream's last
+// layer) from the 16 tiles of accP (8 operand steps), the sums building up in a local set and deposited in accP by the last step.
+// A chunk period is always four groups of four tiles (8 KiB of fragments each): the fragments of group q+1 are fetched while group q's
+// 24 MFMAs run, the next chunk is acquired in the period's last group, its successor's eight DMA pieces go out two per group, and the
+// previous layer's epilogue for operand step S+1 is spread over the groups of step S.
+// mw: the lane's ReLU bits of the layer being consumed, natural order: word 2 c + (T >> 3), see store_masks16.
+template <int NT16, bool MASKS, bool ZADD, bool DUMP>
+__device__ __forceinline__ void layer16(f32x4 (&accP)[2][16], Ring& ring, char* lds, const Epi16& c, uint32_t (&mw)[4], int lane) {
+    f32x4 accC[2][16];
+    const int g = lane >> 4;
+    const unsigned voff = lane * 16u + 4096u;
+    constexpr int GPS = NT16 / 4;                     // groups per step
+    constexpr int NG = 8 * GPS;                       // groups of the layer
+    constexpr bool TAIL = (NT16 != 16);               // rgb.0: the stream ends with this layer
+    constexpr int NCH = NG / 4;                       // chunks of this layer
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mw[i] = 0u;
+#pragma unroll
+    for (int t = 0; t < NT16; ++t) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(c.bias + 16 * t + 4 * g);
+        accC[0][t] = b; accC[1][t] = b;
+    }
+    XOp xc[2], xn[2];
+    epi16<0, MASKS, ZADD, DUMP>(accP[0][0], xc[0], c, 0, 0, g, mw[0]); epi16<1, MASKS, ZADD, DUMP>(accP[0][1], xc[0], c, 1, 0, g, mw[0]);
+    epi16<0, MASKS, ZADD, DUMP>(accP[1][0], xc[1], c, 0, 1, g, mw[2]); epi16<1, MASKS, ZADD, DUMP>(accP[1][1], xc[1], c, 1, 1, g, mw[2]);
+    Frag16 fa, fb;
+    const char* w = ring_acquire(ring, lds) + lane * 16;
+    load16(fa, w);
+    if constexpr (!TAIL || 2 < NCH) ring_pieces<0, 2>(ring, voff);
+    // group G: step S = G / GPS, tiles 4 (G % GPS); position Q = G % 4 in its chunk W = G / 4
+#define SNR_GROUP16(G, FCUR, FNXT)                                                                                         \
+    {                                                                                                                      \
+        constexpr int S_ = (G) / GPS, T0_ = 4 * ((G) % GPS), Q_ = (G) % 4, W_ = (G) / 4;                                   \
+        constexpr bool LASTS_ = S_ == 7;                                                                                   \
+        if constexpr (Q_ != 3) load16(FNXT, w + (Q_ + 1) * 8192);                                                          \
+        else if constexpr ((G) + 1 < NG) { w = ring_acquire<TAIL && W_ + 1 == NCH - 1>(ring, lds) + lane * 16; load16(FNXT, w); } \
+        mma16<T0_, LASTS_>(accC, accP, xc, FCUR);                                                                          \
+        if constexpr (Q_ != 3) { if constexpr (!TAIL || W_ + 2 < NCH) ring_pieces<2 * Q_ + 2, 2>(ring, voff); }            \
+        else if constexpr ((G) + 1 < NG) { if constexpr (!TAIL || W_ + 3 < NCH) ring_pieces<0, 2>(ring, voff); }           \
+        if constexpr (!LASTS_) {                                                                                           \
+            /* operand step S+1: four tile conversions (c0 h0, c0 h1, c1 h0, c1 h1) over the GPS groups of step S */      \
+            constexpr int E0_ = ((G) % GPS) * (4 / GPS);                                                                   \
+            _Pragma("unroll") for (int e_ = E0_; e_ < E0_ + 4 / GPS; ++e_) {                                               \
+                const int cb_ = e_ >> 1, hf_ = e_ & 1, T_ = 2 * (S_ + 1) + hf_;                                            \
+                if (hf_ == 0) epi16<0, MASKS, ZADD, DUMP>(accP[cb_][T_], xn[cb_], c, T_, cb_, g, mw[2 * cb_ + (T_ >> 3)]);  \
+                else epi16<1, MASKS, ZADD, DUMP>(accP[cb_][T_], xn[cb_], c, T_, cb_, g, mw[2 * cb_ + (T_ >> 3)]);           \
+            }                                                                                                              \
+        }                                                                                                                  \
+        SNR_INTERLEAVE16(24)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        if constexpr (!LASTS_ && ((G) % GPS) == GPS - 1) { xc[0] = xn[0]; xc[1] = xn[1]; }                                 \
+    }
+#define SNR_GROUP16_PAIR(G) SNR_GROUP16(G, fa, fb) SNR_GROUP16((G) + 1, fb, fa)
+    SNR_GROUP16_PAIR(0) SNR_GROUP16_PAIR(2) SNR_GROUP16_PAIR(4) SNR_GROUP16_PAIR(6)
+    SNR_GROUP16_PAIR(8) SNR_GROUP16_PAIR(10) SNR_GROUP16_PAIR(12) SNR_GROUP16_PAIR(14)
+    if constexpr (NG == 32) {
+        SNR_GROUP16_PAIR(16) SNR_GROUP16_PAIR(18) SNR_GROUP16_PAIR(20) SNR_GROUP16_PAIR(22)
+        SNR_GROUP16_PAIR(24) SNR_GROUP16_PAIR(26) SNR_GROUP16_PAIR(28) SNR_GROUP16_PAIR(30)
+    }
+#undef SNR_GROUP16_PAIR
+#undef SNR_GROUP16
+}
+
+// x | x[lane ^ 32] (the two lanes hold disjoint bits): gfx950 v_permlane32_swap, no LDS round trip
+__device__ __forceinline__ uint32_t or_halves(uint32_t v) {
+    uint32_t a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a | b;
+}
+// a 16-bit value's four nibbles spread to the even nibbles of a word
+__device__ __forceinline__ uint32_t spread_nibbles(uint32_t x) {
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    return (x | (x << 4)) & 0x0F0F0F0Fu;
+}
+// The lane's natural ReLU-bit words -> the documented layout (snr_layout.h: per 32-point tile and ReLU layer 64 lanes x uint4, lane
+// 32 h + p, bit (T32 & 1) * 16 + r of word T32 >> 1 = unit 32 T32 + 8 (r >> 2) + 4 h + (r & 3)) that the backward kernels and
+// tests/relu_bits.py read.  Natural: word mw[2 c + (T >> 3)] received the sign bits of tiles T = 8 q .. 8 q + 7 (four values each) by
+// alignbit, first arrival in bit 31: bit i of ~bitreverse(word) = "unit 16 T + 4 g + e is positive" with i = 4 (T & 7) + e.  Unit
+// 16 T + 4 g + e of point 16 c + n belongs to documented lane 32 (g & 1) + 16 c + n, word T >> 2, nibble 2 (T & 3) + (g >> 1): this lane
+// holds the even or the odd nibbles of every word, lane ^ 32 the others.
+template <int NWORDS /* natural words per column block: 2 (256 units) or 1 (128) */>
+__device__ __forceinline__ uint4 masks16_to_layout(const uint32_t (&mw)[4], int g) {
+    uint32_t out[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t nat = q < NWORDS ? ~__builtin_bitreverse32(mw[2 * c + q]) : 0u;
+            const unsigned sh = (g >> 1) * 4;
+            out[c][2 * q] = or_halves(spread_nibbles(nat & 0xFFFFu) << sh);
+            out[c][2 * q + 1] = or_halves(spread_nibbles(nat >> 16) << sh);
+        }
+    const bool c1 = (g >> 1) != 0;
+    return make_uint4(c1 ? out[1][0] : out[0][0], c1 ? out[1][1] : out[0][1], c1 ? out[1][2] : out[0][2], c1 ? out[1][3] : out[0][3]);
+}
 
 template <int MODE, bool MASKS, bool EBIAS, bool DUMP = false>      // EBIAS: io.latent_bias holds the latent terms folded into the next layers' biases
 __global__ void __launch_bounds__(256, 1)                           // DUMP (training): io.act receives every MFMA layer's fp32 input
@@ -440,10 +458,15 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     const unsigned voff = lane * 16u + 4096u;
     ring_start(ring, reinterpret_cast<const char*>(io.packed + L.bf_fwd), total_chunks, lds, voff);
 
-    XOp x[16];
+    // Positional encodings: lane (p, h) computes half of point p's sine / cosine pairs into the point's scratch row (rows are private
+    // to the wave: LDS operations of one wave execute in order); the operand steps then gather, for lane (n, gq), the features
+    // 32 s + 16 (j >> 2) + 4 gq + (j & 3) of the points 16 c + n.
+    const int n16 = lane & 15, gq = lane >> 4;
+    XOp x0[2][2];                                     // enc_xyz: [k32-step][column block]
     char* xdir = lds + OFF_XDIR + wave * 4096 + lane * 16;
     {
-        float* sc = reinterpret_cast<float*>(lds + OFF_PE) + (wave * 32 + p) * PE_ROWF;      // rows are private to a wave
+        float* scw = reinterpret_cast<float*>(lds + OFF_PE) + (wave * 32) * PE_ROWF;
+        float* sc = scw + p * PE_ROWF;
 #pragma unroll 1
         for (int i = 0; i < 15; ++i) {
             const int q = 15 * h + i;
@@ -452,17 +475,21 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
             sc[3 + q] = sn; sc[3 + 3 * XYZ_FREQ + q] = cs;
         }
         if (h == 0) { sc[0] = px; sc[1] = py; sc[2] = pz; sc[63] = 0.f; }
-        {   // all 32 scratch reads first, then the conversions (order pinned: the compiler otherwise waits for every read on its own)
-            float pv[32];
+        {   // all scratch reads first, then the conversions (order pinned: the compiler otherwise waits for every read on its own)
+            float pv[2][2][8];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pv[8 * s + j] = sc[16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pv[s][c][j] = scw[(16 * c + n16) * PE_ROWF + 32 * s + 16 * (j >> 2) + 4 * gq + (j & 3)];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) split_store(pv[8 * s + j], x[s], j);
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) split_store(pv[s][c][j], x0[s][c], j);
         }
 #pragma unroll 1
         for (int i = 0; i < 6; ++i) {
@@ -476,55 +503,58 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
 #pragma unroll
             for (int f = D_DIR; f < 32; ++f) sc[f] = 0.f;
         }
-        float dvv[16];
+        float dvv[2][8];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dvv[8 * s + j] = sc[16 * s + 8 * (j >> 2) + 4 * h + (j & 3)];
+            for (int j = 0; j < 8; ++j) dvv[c][j] = scw[(16 * c + n16) * PE_ROWF + 16 * (j >> 2) + 4 * gq + (j & 3)];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int c = 0; c < 2; ++c) {      // the direction step of enc_viewdir, parked in LDS until that layer: [column block][plane][lane] x 16 B
             XOp d;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) split_store(dvv[8 * s + j], d, j);
-            *reinterpret_cast<bf16x8*>(xdir + s * 2048) = d.hi;
-            *reinterpret_cast<bf16x8*>(xdir + s * 2048 + 1024) = d.lo;
+            for (int j = 0; j < 8; ++j) split_store(dvv[c][j], d, j);
+            *reinterpret_cast<bf16x8*>(xdir + c * 2048) = d.hi;
+            *reinterpret_cast<bf16x8*>(xdir + c * 2048 + 1024) = d.lo;
         }
     }
 
-    f32x16 accA[8];
-    uint32_t mask[4];
-    float sig_dot = 0.f;
+    f32x4 accA[2][16];
+    uint32_t mw[4];
+    float sig_dot[2] = {0.f, 0.f};
     SNR_STAMP(2);
 
-    // ---- enc_xyz: 4 operand steps straight from the encoding -> accA
+    // ---- enc_xyz: two k32-steps (one chunk each) straight from the encoding -> accA
     {
         const char* w = ring_acquire(ring, lds) + lane * 16;      // (its barrier also retires the scratch rows)
-        ring_pieces<0, 4>(ring, voff);
-        acc_bias<8, 8>(accA, vec + VEC_BIAS, h);
-        step_mma<8, 8>(accA, x[0], w);
-        ring_pieces<4, 4>(ring, voff);
-        step_mma<8, 8>(accA, x[1], w + 16 * 1024);
+        ring_pieces<0, 8>(ring, voff);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(vec + VEC_BIAS + 16 * t + 4 * gq);
+            accA[0][t] = b; accA[1][t] = b;
+        }
+        step_mma16<16>(accA, x0[0], w);
         w = ring_acquire(ring, lds) + lane * 16;
-        ring_pieces<0, 4>(ring, voff);
-        step_mma<8, 8>(accA, x[2], w);
-        ring_pieces<4, 4>(ring, voff);
-        step_mma<8, 8>(accA, x[3], w + 16 * 1024);
+        ring_pieces<0, 8>(ring, voff);
+        step_mma16<16>(accA, x0[1], w);
     }
 
     SNR_STAMP(3);
     // ---- 256-wide layers: layer li consumes the accumulators of layer li-1 (epilogue fused into its steps)
     auto epi_of = [&](int l) {     // epilogue configuration of MFMA layer l's output
-        FwdEpi c;
+        Epi16 c;
         c.floor = (l != li_encshape) ? 0 : (int)0x80000000;
         const int la = latent_after(l, sb, tb);
         c.bias = (EBIAS && la >= 0) ? latw + la * 256 : vec + VEC_BIAS + (l + 1) * 256;
         c.zl = (!EBIAS && la >= 0) ? latw + la * 256 : vec + VEC_ZERO;
-        c.dump = nullptr;
+        c.dump[0] = c.dump[1] = nullptr;
         if (DUMP) {      // slot l = the output of layer l after activation and latent add = the input of layer l + 1
             int t = threadIdx.x; asm volatile("" : "+v"(t));
-            const long long gpd = tile128 * 128 + wave * 32 + (t & 31);
-            if (gpd < io.n_points) c.dump = io.act + ((long long)l * io.n_points + gpd) * 256 + 4 * ((t & 63) >> 5);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const long long gpd = tile128 * 128 + wave * 32 + 16 * cb + (t & 15);
+                if (gpd < io.n_points) c.dump[cb] = io.act + ((long long)l * io.n_points + gpd) * 256 + 4 * ((t & 63) >> 4);
+            }
         }
         return c;
     };
@@ -533,83 +563,109 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     // `lane` would have to stay in VGPRs across the whole layer chain, and the allocator spills them
     auto fresh_lane = [&]() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t & 63; };
     auto store_mask = [&](int l) {   // ReLU bits of layer l (complete once the next layer has consumed all its tiles)
-        if (MASKS && tile_live && l != li_encshape)
-            io.masks[(tile32 * n_relu + relu_slot(l, sb)) * 64 + lane] =
-                make_uint4(~__builtin_bitreverse32(mask[0]), ~__builtin_bitreverse32(mask[1]), ~__builtin_bitreverse32(mask[2]), ~__builtin_bitreverse32(mask[3]));
+        if (MASKS && l != li_encshape) {
+            const int ln = fresh_lane(), g4 = ln >> 4;
+            const uint4 m = masks16_to_layout<2>(mw, g4);
+            if (tile_live) io.masks[(tile32 * n_relu + relu_slot(l, sb)) * 64 + 32 * (g4 & 1) + 16 * (g4 >> 1) + (ln & 15)] = m;
+        }
+    };
+    auto extra_dir_step = [&]() {      // enc_viewdir: k = 256 .. 287 are the direction features (their operand steps wait in LDS)
+        const int ln = fresh_lane();
+        const char* w = ring_acquire(ring, lds) + ln * 16;
+        ring_pieces<0, 8>(ring, ln * 16u + 4096u);
+        const char* xd = lds + OFF_XDIR + wave * 4096 + ln * 16;
+        XOp d[2];
+        d[0].hi = *reinterpret_cast<const bf16x8*>(xd);        d[0].lo = *reinterpret_cast<const bf16x8*>(xd + 1024);
+        d[1].hi = *reinterpret_cast<const bf16x8*>(xd + 2048); d[1].lo = *reinterpret_cast<const bf16x8*>(xd + 3072);
+        step_mma16<16>(accA, d, w);
     };
 #pragma unroll 1
     for (int li = 1; li <= li_last; ++li) {
-        layer_fwd<8, MASKS, !EBIAS, DUMP>(accA, x, xdir, ring, lds, epi_of(li - 1), li == li_view, mask, tid, lane);
+        layer16<16, MASKS, !EBIAS, DUMP>(accA, ring, lds, epi_of(li - 1), mw, lane);
+        if (li == li_view) extra_dir_step();
         store_mask(li - 1);
-        if (li == li_encshape) sig_dot = sigma_partial(accA, vec + VEC_SIGW, fresh_lane() >> 5);
+        if (li == li_encshape) {      // density head: this lane's share of w_sigma . y on the finished enc_shape tiles (bias included)
+            const int g4 = fresh_lane() >> 4;
+            const float* wsig = vec + VEC_SIGW;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wsig + 16 * t + 4 * g4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sig_dot[0] = fmaf(wv[e], accA[0][t][e], sig_dot[0]); sig_dot[1] = fmaf(wv[e], accA[1][t][e], sig_dot[1]); }
+            }
+        }
         SNR_STAMP(3 + li);
     }
-    // ---- rgb.0: 256 -> 128 (4 tiles) from the last 256-wide layer's accumulators
-    layer_fwd<4, MASKS, !EBIAS, DUMP>(accA, x, xdir, ring, lds, epi_of(li_last), false, mask, tid, lane);
+    // ---- rgb.0: 256 -> 128 (8 tiles) from the last 256-wide layer's accumulators
+    layer16<8, MASKS, !EBIAS, DUMP>(accA, ring, lds, epi_of(li_last), mw, lane);
     store_mask(li_last);
     SNR_STAMP(12);
 
-    const int lane_t = fresh_lane(), p_t = lane_t & 31, h_t = lane_t >> 5;
-    // density head (enc_shape's output dotted with w_sigma inside the epilogues)
-    const float pre = sum_halves(sig_dot) + vec[VEC_MISC + 0];
-    const float o_sigma = pre > 20.f ? pre : log1pf(expf(pre));
+    const int lane_t = fresh_lane(), n_t = lane_t & 15, g_t = lane_t >> 4;
+    // density head: the four lanes (n, 0..3) of a point hold its four shares
+    float o_sigma[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const float pre = sum_halves(sum_row_pairs(sig_dot[cb])) + vec[VEC_MISC + 0];
+        o_sigma[cb] = pre > 20.f ? pre : log1pf(expf(pre));
+    }
 
     // ---- colour head: ReLU(rgb.0) . W2 on the VALU
-    float pr = 0.f, pg = 0.f, pb = 0.f;
+    float pr[2] = {0.f, 0.f}, pg[2] = {0.f, 0.f}, pb[2] = {0.f, 0.f};
     {
-        uint32_t mk[2] = {0u, 0u};
+        uint32_t mk[4] = {0u, 0u, 0u, 0u};          // natural words 2 c (tiles 0..7); same arrival order as the layers' bits
         const float* w2 = vec + VEC_RGBW;
-        float* hdump = nullptr;           // training: ReLU(rgb.0), the input of rgb.2, slot li_last + 1 (128 columns)
+        float* hdump[2] = {nullptr, nullptr};       // training: ReLU(rgb.0), the input of rgb.2, slot li_last + 1 (128 columns)
         if (DUMP) {
-            const long long gpd = tile128 * 128 + wave * 32 + p_t;
-            if (gpd < io.n_points) hdump = io.act + ((long long)(li_last + 1) * io.n_points + gpd) * 256 + 4 * h_t;
-        }
-        // (the 12 weight vectors of tile t+1 requested before tile t's arithmetic, order pinned: see sigma_partial)
-        f32x4 wc[12], wn[12];
-        auto request = [&](f32x4 (&w)[12], int t) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n0 = 32 * t + 8 * j + 4 * h_t;
-                w[3 * j] = *reinterpret_cast<const f32x4*>(w2 + n0);
-                w[3 * j + 1] = *reinterpret_cast<const f32x4*>(w2 + 128 + n0);
-                w[3 * j + 2] = *reinterpret_cast<const f32x4*>(w2 + 256 + n0);
+            for (int cb = 0; cb < 2; ++cb) {
+                const long long gpd = tile128 * 128 + wave * 32 + 16 * cb + n_t;
+                if (gpd < io.n_points) hdump[cb] = io.act + ((long long)(li_last + 1) * io.n_points + gpd) * 256 + 4 * g_t;
             }
-        };
-        request(wc, 0);
+        }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (t + 1 < 4) request(wn, t + 1);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 8; ++t) {
+            const f32x4 wr = *reinterpret_cast<const f32x4*>(w2 + 16 * t + 4 * g_t);
+            const f32x4 wg = *reinterpret_cast<const f32x4*>(w2 + 128 + 16 * t + 4 * g_t);
+            const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + 16 * t + 4 * g_t);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int cb = 0; cb < 2; ++cb) {
                 f32x4 dv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = accA[t][4 * j + e];
-                    if (MASKS && v > 0.f) mk[t >> 1] |= 1u << ((t & 1) * 16 + 4 * j + e);
+                    float v = accA[cb][t][e];
+                    if (MASKS) mk[2 * cb] = __builtin_amdgcn_alignbit(mk[2 * cb], __builtin_bit_cast(uint32_t, v), 31);
                     v = fmaxf(v, 0.f);
                     dv[e] = v;
-                    pr = fmaf(wc[3 * j][e], v, pr); pg = fmaf(wc[3 * j + 1][e], v, pg); pb = fmaf(wc[3 * j + 2][e], v, pb);
+                    pr[cb] = fmaf(wr[e], v, pr[cb]); pg[cb] = fmaf(wg[e], v, pg[cb]); pb[cb] = fmaf(wb[e], v, pb[cb]);
                 }
-                if (DUMP) { if (hdump) *reinterpret_cast<f32x4*>(hdump + 32 * t + 8 * j) = dv; }
+                if (DUMP) { if (hdump[cb]) *reinterpret_cast<f32x4*>(hdump[cb] + 16 * t) = dv; }
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 12; ++i) wc[i] = wn[i];
         }
-        if (MASKS && tile_live) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane_t] = make_uint4(mk[0], mk[1], 0u, 0u);
+        if (MASKS) {
+            const uint4 m = masks16_to_layout<1>(mk, g_t);
+            if (tile_live) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + 32 * (g_t & 1) + 16 * (g_t >> 1) + n_t] = m;
+        }
     }
-    const float cr = sum_halves(pr) + vec[VEC_MISC + 4];
-    const float cg = sum_halves(pg) + vec[VEC_MISC + 5];
-    const float cb = sum_halves(pb) + vec[VEC_MISC + 6];
+    float cr[2], cg[2], cb_[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        cr[cb] = sum_halves(sum_row_pairs(pr[cb])) + vec[VEC_MISC + 4];
+        cg[cb] = sum_halves(sum_row_pairs(pg[cb])) + vec[VEC_MISC + 5];
+        cb_[cb] = sum_halves(sum_row_pairs(pb[cb])) + vec[VEC_MISC + 6];
+    }
+    // every lane holds both column blocks' results for its n: lanes 0..31 speak for the wave's 32 points (point = lane)
+    const bool c1 = (lane_t >> 4) & 1;
+    const float my_sigma = c1 ? o_sigma[1] : o_sigma[0], my_r = c1 ? cr[1] : cr[0], my_g = c1 ? cg[1] : cg[0], my_b = c1 ? cb_[1] : cb_[0];
+    const int p_t = lane_t & 31;
 
     SNR_STAMP(13);
 #ifndef SNR_STAMPS
     {   // (the point index again, from the fresh lane id)
         const long long gp_e = tile128 * 128 + wave * 32 + p_t;
         if (gp_e < io.n_points && lane_t < 32) {
-            if (io.sigmas) io.sigmas[gp_e] = o_sigma;
-            if (io.rgbs) { io.rgbs[gp_e * 3] = cr; io.rgbs[gp_e * 3 + 1] = cg; io.rgbs[gp_e * 3 + 2] = cb; }
+            if (io.sigmas) io.sigmas[gp_e] = my_sigma;
+            if (io.rgbs) { io.rgbs[gp_e * 3] = my_r; io.rgbs[gp_e * 3 + 1] = my_g; io.rgbs[gp_e * 3 + 2] = my_b; }
         }
     }
 #endif
@@ -617,7 +673,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         float* comp = reinterpret_cast<float*>(lds + OFF_COMP);
         if (lane_t < 32) {
             float* c = comp + (wave * 32 + p_t) * COMP_STRIDE;
-            c[0] = o_sigma; c[1] = cr; c[2] = cg; c[3] = cb;      // c[4] = composite depth, parked there at the start
+            c[0] = my_sigma; c[1] = my_r; c[2] = my_g; c[3] = my_b;      // c[4] = composite depth, parked there at the start
         }
         __syncthreads();
         const int S = g.S;
@@ -1036,11 +1092,14 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
 }
 
 // ------------------------------------------------------------------------------------------ packing
-// One thread per (k16-step, tile, lane, j): writes the hi and the lo element of the layer image
+// One thread per (k-step, tile, lane, j): writes the hi and the lo element of the layer image
 //   [s][tile][plane hi/lo][lane][8].
-//   forward  (transpose == 0): value = W[row][k]           row = output feature, k = input feature
-//   backward (transpose == 1): value = W[k][row]           row = input feature,  k = output feature
-__global__ void pack_bf16_kernel(const float* __restrict__ Wt, int n_out, int k_in, int transpose, int n_tiles, int KS, int tile0,
+//   backward (transpose == 1, v_mfma_f32_32x32x16_bf16): k16-steps, 32-row tiles; value = W[k][row], row = input feature, k = output
+//     feature 16 s + 8 (j >> 2) + 4 (lane >> 5) + (j & 3) -- the order in which a 32x32 accumulator tile re-enters the MFMA as B operand;
+//   forward (transpose == 0, v_mfma_f32_16x16x32_bf16): k32-steps, 16-row tiles; value = W[row][k], row = 16 tile + (lane & 15) = output
+//     feature, k = input feature 32 s + 16 (j >> 2) + 4 (lane >> 4) + (j & 3) -- the order in which the 16x16 accumulator tiles 2s, 2s+1
+//     re-enter; k_off shifts k (enc_viewdir's direction step: features 256 .. 282 as one step of their own).
+__global__ void pack_bf16_kernel(const float* __restrict__ Wt, int n_out, int k_in, int transpose, int n_tiles, int KS, int tile0, int k_off,
                                  __bf16* __restrict__ dst) {
     const long long total = (long long)n_tiles * KS * 64 * 8;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -1048,11 +1107,16 @@ __global__ void pack_bf16_kernel(const float* __restrict__ Wt, int n_out, int k_
         const int lane = (int)((i >> 3) & 63);
         const int tile = (int)((i >> 9) % n_tiles);
         const int s = (int)((i >> 9) / n_tiles);
-        const int row = 32 * (tile0 + tile) + (lane & 31), hh = lane >> 5;
-        const int k = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
         float v = 0.f;
-        if (!transpose) { if (row < n_out && k < k_in) v = Wt[(long long)row * k_in + k]; }
-        else            { if (row < k_in && k < n_out) v = Wt[(long long)k * k_in + row]; }
+        if (!transpose) {
+            const int row = 16 * (tile0 + tile) + (lane & 15);
+            const int k = k_off + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+            if (row < n_out && k < k_in) v = Wt[(long long)row * k_in + k];
+        } else {
+            const int row = 32 * (tile0 + tile) + (lane & 31), hh = lane >> 5;
+            const int k = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+            if (row < k_in && k < n_out) v = Wt[(long long)k * k_in + row];
+        }
         const __bf16 hi = (__bf16)v;
         const __bf16 lo = (__bf16)(v - (float)hi);
         const long long base = (((long long)s * n_tiles + tile) * 2) * 512;      // bf16 elements; plane stride 512
@@ -1074,22 +1138,27 @@ int snr_bf16_supported_(int sb, int tb, long long points_per_obj) {
 int snr_bf16_pack_(const float* const* W /* per-point weight tensors in MFMA-layer order */, int sb, int tb, float* packed, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
     const Layout L = make_layout(sb, tb);
-    auto launch = [&](const float* w, int n_out, int k_in, int transpose, int n_tiles, int KS, __bf16* dst, int tile0 = 0) {
+    auto launch = [&](const float* w, int n_out, int k_in, int transpose, int n_tiles, int KS, __bf16* dst, int tile0 = 0, int k_off = 0) {
         const long long total = (long long)n_tiles * KS * 512;
         int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-        bf::pack_bf16_kernel<<<grid, 256, 0, st>>>(w, n_out, k_in, transpose, n_tiles, KS, tile0, dst);
+        bf::pack_bf16_kernel<<<grid, 256, 0, st>>>(w, n_out, k_in, transpose, n_tiles, KS, tile0, k_off, dst);
     };
     const int n_layers = sb + tb + 4;
-    // forward stream
+    // forward stream (16x16x32 image): k32-steps of 16-row tiles; enc_viewdir = 8 steps over the 256 hidden units + one step over the
+    // direction features
     char* f = reinterpret_cast<char*>(packed + L.bf_fwd);
     for (int li = 0; li < n_layers; ++li) {
         const bool is_xyz = li == 0, is_view = li == sb + 2, is_rgb0 = li == n_layers - 1;
         const int n_out = is_rgb0 ? 128 : 256;
         const int k_in = is_xyz ? D_XYZ : (is_view ? 256 + D_DIR : 256);
-        const int KS = is_xyz ? 4 : (is_view ? 18 : 16);
-        const int n_tiles = n_out / 32;
-        launch(W[li], n_out, k_in, 0, n_tiles, KS, reinterpret_cast<__bf16*>(f));
+        const int KS = is_xyz ? 2 : 8;
+        const int n_tiles = n_out / 16;
+        launch(W[li], n_out, is_view ? 256 + D_DIR : k_in, 0, n_tiles, KS, reinterpret_cast<__bf16*>(f));
         f += (long long)n_tiles * 2 * KS * 1024;
+        if (is_view) {                                             // the direction features: one more k32-step, a chunk of its own
+            launch(W[li], n_out, k_in, 0, n_tiles, 1, reinterpret_cast<__bf16*>(f), 0, 256);
+            f += (long long)n_tiles * 2 * 1024;
+        }
     }
     if (f - reinterpret_cast<char*>(packed + L.bf_fwd) != L.bf_fwd_bytes) return SNR_E_SHAPE;
     // backward stream: rgb.0^T, texture^T (reverse), enc_viewdir^T, enc_shape^T, shape^T (reverse), enc_xyz^T

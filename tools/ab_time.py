@@ -42,14 +42,23 @@ def timed(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 libs = {}
+import copy
+pp_names = ops.per_point_tensor_names(3, 1)
+pp = [dict(model.named_parameters())[n].detach().contiguous() for n in pp_names]
+a_shipped, keep = a, []
 def setup(name):
     lib = good if name == "shipped" else C.CDLL(os.path.join(ROOT, "tools", "_diag", f"libvariant_{name}.so"), mode=os.RTLD_NOW | os.RTLD_DEEPBIND)
-    for fn in ("snr_render_fwd", "snr_render_bwd", "snr_render_bwd_ws_bytes"):
+    for fn in ("snr_render_fwd", "snr_render_bwd", "snr_render_bwd_ws_bytes", "snr_pack_weights", "snr_packed_bytes"):
         getattr(lib, fn).restype, getattr(lib, fn).argtypes = _lib._SIGS[fn]
-    wsb = lib.snr_render_bwd_ws_bytes(C.byref(a)); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    f0 = lambda: lib.snr_render_fwd(C.byref(a), rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), None, None, None, st())
-    f1 = lambda: lib.snr_render_fwd(C.byref(a), rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), sig.data_ptr(), rgbs.data_ptr(), masks.data_ptr(), st())
-    b = lambda: lib.snr_render_bwd(C.byref(a), sig.data_ptr(), rgbs.data_ptr(), masks.data_ptr(), d_rgb.data_ptr(), d_depth.data_ptr(), d_acc.data_ptr(),
+    # every variant packs the weights itself (the stream layouts may differ between variants)
+    pk_v = torch.empty(lib.snr_packed_bytes(3, 1) // 4, device=dev)
+    arr = (C.c_void_p * len(pp))(*[t.data_ptr() for t in pp])
+    assert lib.snr_pack_weights(arr, len(pp), 3, 1, pk_v.data_ptr(), st()) == 0
+    a_v = type(a_shipped)(); C.memmove(C.byref(a_v), C.byref(a_shipped), C.sizeof(a_shipped)); a_v.packed = pk_v.data_ptr(); keep.append(pk_v)
+    wsb = lib.snr_render_bwd_ws_bytes(C.byref(a_v)); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    f0 = lambda: lib.snr_render_fwd(C.byref(a_v), rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), None, None, None, st())
+    f1 = lambda: lib.snr_render_fwd(C.byref(a_v), rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), sig.data_ptr(), rgbs.data_ptr(), masks.data_ptr(), st())
+    b = lambda: lib.snr_render_bwd(C.byref(a_v), sig.data_ptr(), rgbs.data_ptr(), masks.data_ptr(), d_rgb.data_ptr(), d_depth.data_ptr(), d_acc.data_ptr(),
                                    (None if os.environ.get('SNR_AB_NOLAT') else d_lat.data_ptr()), d_o.data_ptr(), d_d.data_ptr(), None, ws.data_ptr(), wsb, st())
     assert f1() == 0 and b() == 0
     good.snr_render_fwd(C.byref(a32), rgb32.data_ptr(), depth32.data_ptr(), acc32.data_ptr(), None, None, None, st())
