@@ -16,7 +16,7 @@
 
 namespace snr {
 
-constexpr int WG_DEPTH = 8;            // k-steps of operands in flight per wave (8 x 1024 MFMA cycles cover an HBM round trip under load)
+constexpr int WG_DEPTH = 8;            // k-steps per operand set: one set in flight per wave while the other is consumed (4, 12 and 16 measured the same)
 
 // Operand addressing shared by both arithmetics: a wave-uniform base (SGPRs, advanced per k-step) + a loop-invariant 32-bit lane offset,
 // so a load is one instruction with no address arithmetic.  Loads are unconditional and unmasked in the main loop: lanes whose rows /
@@ -48,7 +48,8 @@ wgrad_mfma_kernel(const float* __restrict__ G, long long ldg, int n_out, const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    constexpr int TRIP = 2 * WG_DEPTH;                                 // points per trip of the main loop
+    constexpr int SET = 2 * WG_DEPTH;                                  // points per operand set
+    constexpr int TRIP = 2 * SET;                                      // points per trip of the main loop: two sets, each consumed in place
     const long long full_end = p_begin + (p_end - p_begin) / TRIP * TRIP;
     auto load = [&](long long p, f32x4& a, f32x4& b) {                 // k-step at points p, p + 1 (this lane: p + h); p is wave-uniform
         const long long pc = p + 2 <= p_end ? p : p_begin;             // past the slice: any valid k-step, the values are dropped
@@ -62,18 +63,30 @@ wgrad_mfma_kernel(const float* __restrict__ G, long long ldg, int n_out, const f
 #pragma unroll
             for (int f = 0; f < 4; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[f], acc[e][f], 0, 0, 0);
     };
-    f32x4 a[WG_DEPTH], b[WG_DEPTH];
+    // Two operand sets of WG_DEPTH k-steps each: while one set is consumed IN PLACE the other one lands (WG_DEPTH x 1024 MFMA cycles cover
+    // an HBM round trip), and a set's registers are requested again right after the MFMAs that read them.  (A single set refilled slot by
+    // slot behind a register copy made LLVM rotate the whole set through v_mov at the end of every trip, behind an s_waitcnt vmcnt(0):
+    // every trip then waited for the loads it had just issued; this form: 0.570 -> 0.544 ms per 256 x 256 layer at 524 288 points.  The rest
+    // of the distance to the 0.44 ms of matrix time is the clock: the counters put the matrix pipe at 0.85 busy at ~2.08 GHz.)
+    f32x4 a0[WG_DEPTH], b0[WG_DEPTH], a1[WG_DEPTH], b1[WG_DEPTH];
     if (p_begin < full_end) {
 #pragma unroll
-        for (int d = 0; d < WG_DEPTH; ++d) load(p_begin + 2 * d, a[d], b[d]);
+        for (int d = 0; d < WG_DEPTH; ++d) load(p_begin + 2 * d, a0[d], b0[d]);
     }
     for (long long p = p_begin; p < full_end; p += TRIP) {
 #pragma unroll
         for (int d = 0; d < WG_DEPTH; ++d) {
-            const f32x4 av = a[d], bv = b[d];
-            load(p + TRIP + 2 * d < full_end ? p + TRIP + 2 * d : p_begin, a[d], b[d]);
+            load(p + SET + 2 * d, a1[d], b1[d]);
             __builtin_amdgcn_sched_barrier(0);
-            mma(av, bv);
+            mma(a0[d], b0[d]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const long long pn = p + TRIP < full_end ? p + TRIP : p_begin;          // past the last trip: a valid set, dropped
+#pragma unroll
+        for (int d = 0; d < WG_DEPTH; ++d) {
+            load(pn + 2 * d, a0[d], b0[d]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1[d], b1[d]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -307,7 +320,7 @@ using namespace snr;
 
 static void wgrad_plan(int64_t n_points, int n_out, long long* pps, int* n_slices) {
     // one slice per compute unit and pass where the points allow it; a slice is a whole number of k-step groups
-    const long long unit = 32;      // whole k-step groups of both arithmetics (fp32: 2 x WG_DEPTH points, split-bf16: 2 x 16)
+    const long long unit = 32;      // whole main-loop trips of both arithmetics (fp32: 2 sets x WG_DEPTH k-steps x 2 points, split-bf16: 2 x 16)
     long long per = (n_points + (n_out >= 32 ? 255 : 1023)) / (n_out >= 32 ? 256 : 1024);      // narrow heads: memory-bound, 4 blocks per CU
     const long long min_per = 512;
     if (per < min_per) per = min_per;
