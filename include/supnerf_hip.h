@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SNR_ABI_VERSION 6
+#define SNR_ABI_VERSION 7
 
 enum {
     SNR_OK = 0,
@@ -278,6 +278,12 @@ int snr_metric_row(const float* loss_out, const float* depth_pred, float* depth0
  * pointers / element counts / learning rates; step = 1 for the first update. */
 int snr_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
                    const float* lr, int n_groups, int64_t step, float beta1, float beta2, float eps, float weight_decay, void* stream);
+/* The same update for any number of tensors in ONE launch: the training step's optimiser (src/trainer_unified_nuscenes.py:414-422, AdamW over
+ * every decoder tensor and the two code tables).  table: DEVICE memory, n_tensors entries of six 64-bit words
+ * {param*, grad*, exp_avg*, exp_avg_sq*, numel, group} (fp32 contiguous tensors; group < n_groups selects the learning rate lr[group],
+ * a HOST array); max_numel = the largest numel in the table; step = 1 for the first update. */
+int snr_adamw_table_step(const void* table, int n_tensors, int64_t max_numel, const float* lr, int n_groups, int64_t step, float beta1, float beta2,
+                         float eps, float weight_decay, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Weight gradient of one decoder layer (training mode): the weight half of loss_total.mean().backward()

@@ -286,18 +286,38 @@ struct AdamGroups {
     float step_size[4];    // lr / (1 - beta1^step)
     int count;
 };
+// one element of torch.optim.AdamW's update (amsgrad off; torch/optim/adam.py's arithmetic, scalars prepared on the host in double)
+__device__ __forceinline__ void adamw_one(float& p, float& m, float& v, float g, float decay, float step_size, float beta1, float beta2, float eps,
+                                          float bias2_sqrt) {
+    p *= decay;
+    m = m + (g - m) * (1.f - beta1);                  // lerp
+    v = v * beta2 + (1.f - beta2) * g * g;
+    const float denom = sqrtf(v) / bias2_sqrt + eps;
+    p -= step_size * (m / denom);
+}
 __global__ void __launch_bounds__(256) adamw_kernel(AdamGroups a, float beta1, float beta2, float eps, float bias2_sqrt) {
     const int gi = blockIdx.y;
     if (gi >= a.count) return;
-    const float step_size = a.step_size[gi];
+    const float step_size = a.step_size[gi], decay = a.decay[gi];
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < a.n[gi]; i += (long long)gridDim.x * 256) {
-        const float g = a.g[gi][i];
-        float p = a.p[gi][i] * a.decay[gi];
-        const float m = a.m[gi][i] + (g - a.m[gi][i]) * (1.f - beta1);                  // lerp
-        const float v = a.v[gi][i] * beta2 + (1.f - beta2) * g * g;
-        const float denom = sqrtf(v) / bias2_sqrt + eps;
-        p -= step_size * (m / denom);
+        float p = a.p[gi][i], m = a.m[gi][i], v = a.v[gi][i];
+        adamw_one(p, m, v, a.g[gi][i], decay, step_size, beta1, beta2, eps, bias2_sqrt);
         a.p[gi][i] = p; a.m[gi][i] = m; a.v[gi][i] = v;
+    }
+}
+// The same update for ANY number of tensors in one launch (the training step: 28 decoder tensors + latent layers + the two code tables):
+// a table in device memory names every tensor once (the addresses of parameters, gradient views and moments do not change between
+// steps), blockIdx.y picks the tensor, its parameter group picks the rate.
+struct AdamEntry { float* p; const float* g; float* m; float* v; long long n; long long group; };
+struct AdamScalars { float decay[4], step_size[4]; };
+__global__ void __launch_bounds__(256) adamw_table_kernel(const AdamEntry* __restrict__ table, AdamScalars sc, float beta1, float beta2, float eps,
+                                                          float bias2_sqrt) {
+    const AdamEntry e = table[blockIdx.y];
+    const float step_size = sc.step_size[e.group], decay = sc.decay[e.group];
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < e.n; i += (long long)gridDim.x * 256) {
+        float p = e.p[i], m = e.m[i], v = e.v[i];
+        adamw_one(p, m, v, e.g[i], decay, step_size, beta1, beta2, eps, bias2_sqrt);
+        e.p[i] = p; e.m[i] = m; e.v[i] = v;
     }
 }
 
@@ -385,6 +405,26 @@ int snr_adamw_step(float* const* params, const float* const* grads, float* const
     if (nmax == 0) return SNR_OK;
     long long gx = (nmax + 255) / 256; if (gx > 1024) gx = 1024;
     adamw_kernel<<<dim3((unsigned)gx, (unsigned)n_groups), 256, 0, (hipStream_t)stream>>>(a, beta1, beta2, eps, (float)sqrt(b2));
+    return snr_check_launch_();
+}
+
+int snr_adamw_table_step(const void* table, int n_tensors, int64_t max_numel, const float* lr, int n_groups, int64_t step, float beta1, float beta2,
+                         float eps, float weight_decay, void* stream) {
+    if (n_tensors == 0) return SNR_OK;
+    if (!table || !lr || n_tensors < 0 || n_tensors > 65535 || max_numel < 0 || n_groups < 1 || n_groups > 4 || step < 1) return SNR_E_ARG;
+    if (((uintptr_t)table & 7) != 0) return SNR_E_ARG;
+    static_assert(sizeof(AdamEntry) == 48, "table entry = 6 x 8 bytes");
+    const double b1 = 1.0 - pow((double)beta1, (double)step), b2 = 1.0 - pow((double)beta2, (double)step);
+    AdamScalars sc;
+    for (int i = 0; i < 4; ++i) {
+        const bool on = i < n_groups;
+        sc.decay[i] = on ? (float)(1.0 - (double)lr[i] * (double)weight_decay) : 1.f;
+        sc.step_size[i] = on ? (float)((double)lr[i] / b1) : 0.f;
+    }
+    if (max_numel == 0) return SNR_OK;
+    long long gx = (max_numel + 1023) / 1024; if (gx > 256) gx = 256; if (gx < 1) gx = 1;
+    adamw_table_kernel<<<dim3((unsigned)gx, (unsigned)n_tensors), 256, 0, (hipStream_t)stream>>>((const AdamEntry*)table, sc, beta1, beta2, eps,
+                                                                                                   (float)sqrt(b2));
     return snr_check_launch_();
 }
 

@@ -412,6 +412,69 @@ class DeviceAdamW:
                                             self.betas[0], self.betas[1], self.eps, self.weight_decay, _stream(dev)), "snr_adamw_step")
 
 
+class TableAdamW:
+    """torch.optim.AdamW's update (amsgrad off, same defaults) for ANY number of tensors as ONE launch per step: the training step's
+    optimiser (src/trainer_unified_nuscenes.py:414-422; torch's foreach form is ~18 launches over the 36 tensors, its ``fused=True`` form
+    does not reproduce the update on this ROCm build).  ``groups``: [(list of parameters, lr), ...] (up to 4).  Gradients are read from
+    the ``.grad`` tensors the parameters hold WHEN THE OPTIMISER IS BUILT (the trainer's bucket views: fixed addresses), which are
+    checked again at every step.  After the launch the parameters' version counters are bumped, so caches keyed on them (the packed
+    weight stream) see the change."""
+
+    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if not 1 <= len(groups) <= 4:
+            raise SnrError("TableAdamW: 1 to 4 parameter groups")
+        self.lr = [float(lr) for _, lr in groups]
+        self.params, self.group_of = [], []
+        for gi, (ps, _) in enumerate(groups):
+            for p in ps:
+                if p.requires_grad:
+                    self.params.append(p); self.group_of.append(gi)
+        if not self.params:
+            raise SnrError("TableAdamW: no trainable parameter")
+        dev = self.params[0].device
+        for p in self.params:
+            if not p.is_cuda or p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
+                raise SnrError("TableAdamW: fp32 contiguous parameters on one GPU")
+            if p.grad is None or p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or p.grad.shape != p.shape or p.grad.device != dev:
+                raise SnrError("TableAdamW: every parameter needs its dense fp32 .grad buffer before the optimiser is built (GradBucket)")
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self.steps = 0
+        self._key = None
+        self._table = None
+        self._build_table()
+
+    def _build_table(self):
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in self.params)
+        if key == self._key:
+            return
+        rows = [[p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), g]
+                for p, m, v, g in zip(self.params, self.exp_avg, self.exp_avg_sq, self.group_of)]
+        self._table = torch.tensor(rows, dtype=torch.int64).to(self.params[0].device)
+        self._max_numel = max(p.numel() for p in self.params)
+        self._key = key
+
+    def zero_grad(self, set_to_none=False):
+        if set_to_none:
+            raise SnrError("TableAdamW reads the gradients from fixed buffers: clear them in place (GradBucket.zero)")
+        for p in self.params:
+            p.grad.zero_()
+
+    def step(self):
+        for p in self.params:
+            if p.grad is None:
+                raise SnrError("TableAdamW.step: a parameter lost its .grad buffer (zero_grad(set_to_none=True)?)")
+        self._build_table()          # (a moved parameter or a replaced gradient buffer: new table)
+        self.steps += 1
+        lr = (C.c_float * len(self.lr))(*self.lr)
+        dev = self.params[0].device
+        with torch.cuda.device(dev):
+            check(_lib.lib().snr_adamw_table_step(_p(self._table), len(self.params), int(self._max_numel), lr, len(self.lr), self.steps,
+                                                  self.betas[0], self.betas[1], self.eps, self.weight_decay, _stream(dev)), "snr_adamw_table_step")
+        torch.autograd.graph.increment_version(self.params)
+
+
 # ------------------------------------------------------------------------------------ decoder on points
 def decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=False, precision="fp32", activations=None):
     """xyz, viewdir (P,3); latent (B,NLAT,256) -> sigmas (P,), rgbs (P,3)[, relu masks]."""

@@ -165,11 +165,19 @@ def learning_rates(hpams: dict, niter: int):
 
 
 def make_optimizer(model: nn.Module, codes: CodeTables, hpams: dict, niter: int = 0):
-    """AdamW over model / shape codes / texture codes (src/trainer_unified_nuscenes.py:414-422)."""
+    """AdamW over model / shape codes / texture codes (src/trainer_unified_nuscenes.py:414-422).  Parameters on the GPU that already
+    hold their gradient buffers (a ``GradBucket`` was built first): the same update as ONE launch per step (``ops.TableAdamW``; torch's
+    foreach AdamW is ~18 launches = 0.4 ms of a 6.6 ms step; its ``fused=True`` form was tried and does not reproduce the foreach update
+    on this ROCm build -- parameters 3.5e-4 apart after three steps at lr 1e-4).  Anything else (CPU tensors, no bucket yet):
+    ``torch.optim.AdamW``."""
     lr1, lr2 = learning_rates(hpams, niter)
-    return torch.optim.AdamW([{"params": model.parameters(), "lr": lr1},
-                              {"params": codes.shape_codes.parameters(), "lr": lr2},
-                              {"params": codes.texture_codes.parameters(), "lr": lr2}])
+    groups = [(list(model.parameters()), lr1), (list(codes.shape_codes.parameters()), lr2), (list(codes.texture_codes.parameters()), lr2)]
+    trainable = [p for ps, _ in groups for p in ps if p.requires_grad]
+    if trainable and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad is not None and p.grad.is_contiguous()
+                         and p.grad.shape == p.shape for p in trainable):
+        from . import ops
+        return ops.TableAdamW(groups)
+    return torch.optim.AdamW([{"params": ps, "lr": lr} for ps, lr in groups])
 
 
 def train_step(model, codes: CodeTables, opt, bucket: GradBucket, batch: Dict[str, torch.Tensor], loss_occ_coef: float,

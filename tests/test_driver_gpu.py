@@ -320,3 +320,30 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["unit"] == "rays/s" and line["value"] > 0 and line["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_optimise_loop_is_bit_reproducible(prec):
+    """Two runs of the fused loop from the same seeds (torch's global CPU generator feeds the jitter, like the reference's torch.rand(S))
+    give the same bits in every metric of every iteration, the final codes and the pose: no launch of the iteration -- forward, backward,
+    the latent-gradient reductions, loss tail, AdamW -- depends on scheduling order (no atomics, fixed reduction trees)."""
+    import supnerf_amd as A
+    D = A.driver
+    dev = torch.device("cuda:0")
+    model = A.CodeNeRF(3, 1); model.load_state_dict(O.init_decoder_params()); model = model.to(dev)
+    model.precision = prec
+    hp = D.load_hpams()
+    hp["render_im_sz"] = 32
+    hp["optimize"]["num_opts"] = 12
+    objs = D.make_objects([31, 32], 32)
+    g = torch.Generator().manual_seed(7)
+    sc0, tc0 = torch.randn(2, 256, generator=g) * 0.3, torch.randn(2, 256, generator=g) * 0.3
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(77)
+        one = D.optimize_object(model, dev, objs[0], hp, sc0[:1], tc0[:1], seed=3)
+        both = D.optimize_objects_batched(model, dev, objs, hp, sc0, tc0, seeds=[3, 4])
+        torch.cuda.synchronize()
+        runs.append([t.cpu() for t in one] + [t.cpu() for t in both])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b), float((a - b).abs().max())

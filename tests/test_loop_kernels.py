@@ -181,6 +181,37 @@ def test_device_adamw_matches_torch(amd, dev):
         assert md(b, a) < 2e-6, md(b, a)
 
 
+def test_table_adamw_matches_torch_and_bumps_versions(amd, dev):
+    """The training step's optimiser (src/trainer_unified_nuscenes.py:414-422): ONE launch for any number of tensors in up to four groups,
+    gradients read from the fixed buffers the parameters held when it was built (bucket views at odd offsets of one flat buffer), the
+    parameters' version counters bumped so that caches keyed on them notice.  Against torch.optim.AdamW on the CPU, 25 steps."""
+    g = torch.Generator().manual_seed(12)
+    shapes = [(256, 63), (256,), (256, 256), (1, 256), (1,), (256, 283), (3, 128), (3,), (6, 256), (6, 256), (70001,)]
+    group = [0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 0]
+    lrs = [1e-2, 2e-2, 5e-3]
+    p_ref = [torch.randn(*s, generator=g).requires_grad_() for s in shapes]
+    p_dev = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in p_ref]
+    flat = torch.zeros(sum(p.numel() for p in p_dev), device=dev)
+    off = 0
+    for p in p_dev:                                   # gradient buffers = views into one flat buffer (GradBucket's layout)
+        p.grad = flat[off:off + p.numel()].view_as(p); off += p.numel()
+    ref = torch.optim.AdamW([{"params": [p for p, k in zip(p_ref, group) if k == gi], "lr": lr} for gi, lr in enumerate(lrs)], foreach=False)
+    mine = amd.ops.TableAdamW([([p for p, k in zip(p_dev, group) if k == gi], lr) for gi, lr in enumerate(lrs)])
+    v0 = [p._version for p in p_dev]
+    for step in range(25):
+        for a, b in zip(p_ref, p_dev):
+            gr = torch.randn(*a.shape, generator=g) * (0.1 + step % 3)
+            a.grad = gr.clone(); b.grad.copy_(gr.to(dev))
+        ref.step(); mine.step()
+    for a, b in zip(p_ref, p_dev):
+        assert md(b, a) < 2e-6, (tuple(a.shape), md(b, a))
+    assert all(p._version > v for p, v in zip(p_dev, v0))
+    with pytest.raises(amd.SnrError):
+        mine.zero_grad(set_to_none=True)
+    mine.zero_grad()
+    assert float(flat.abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------ weight gradients (src/trainer_unified_nuscenes.py:334: the dW half of backward)
 @pytest.mark.parametrize("P,n_out,ldg,n_in,ldx", [(4096, 256, 256, 256, 256), (70001, 128, 256, 256, 256), (1537, 256, 256, 64, 64), (999, 256, 256, 28, 28),
                                                   (20000, 3, 3, 128, 256), (20000, 1, 1, 256, 256), (2, 256, 256, 256, 256), (524288, 256, 256, 256, 256)])
