@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SNR_ABI_VERSION 7
+#define SNR_ABI_VERSION 8
 
 enum {
     SNR_OK = 0,
@@ -218,6 +218,18 @@ int snr_composite_bwd(const float* sigmas, const float* rgbs, const float* z_val
  * ---------------------------------------------------------------------------------- */
 int snr_encode_fwd(const snr_render_args* a, float* xyz, float* viewdir, float* z_out,
                    float* pe_xyz, float* pe_dir, uint8_t* hit, void* stream);
+/* The per-object latent layers of a frozen decoder in one launch (src/model_supnerf.py:253,261; model_codenerf.py:50,58):
+ *   z[b][j] = ReLU(code_j[b] W_j^T + b_j), j < shape_blocks reads the shape code, the rest the texture code  -> z (B, n_lat, 256)
+ *   latent_bias[b][j] = b_next_j + z[b][j] W_next_j^T   [nullable]: what snr_render_args::latent_bias takes
+ * with the weights STACKED and TRANSPOSED once by the host: w_lat (512, n_lat*256) -- rows 0..255 multiply the shape code, rows 256..511
+ * the texture code, column block j = layer j, zero where a layer does not read that code -- b_lat (n_lat*256), w_nxt (n_lat*256, n_lat*256)
+ * block diagonal (block j = shape_layer_{j+1} / texture_layer_{..}.0.weight^T), b_nxt (n_lat*256).  shapecode, texturecode (B,256).
+ * snr_latent_bwd: d_z (B, n_lat, 256) -> d_shapecode, d_texturecode (B,256) [each nullable] through the ReLU (z > 0) and W_j; a code no
+ * layer reads gets zeros.  (Weight gradients of the latent layers: not here -- training mode keeps them on torch.) */
+int snr_latent_fwd(const float* shapecode, const float* texturecode, const float* w_lat, const float* b_lat, const float* w_nxt, const float* b_nxt,
+                   int64_t n_objects, int shape_blocks, int texture_blocks, float* z, float* latent_bias, void* stream);
+int snr_latent_bwd(const float* d_z, const float* z, const float* w_lat, int64_t n_objects, int shape_blocks, int texture_blocks,
+                   float* d_shapecode, float* d_texturecode, void* stream);
 /* Positional encodings of explicit points (PE, src/model_supnerf.py:155-161) in the layout the training step's weight-gradient products
  * read: xyz, viewdir (P,3) -> out (P,96), 16-byte aligned: columns 0..62 = PE(xyz, 10 frequencies), 63 = 0, 64..90 = PE(viewdir, 4
  * frequencies), 91..95 = 0 -- the input of encoding_xyz and the direction features of encoding_viewdir (X of their dW = G^T X). */

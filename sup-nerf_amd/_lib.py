@@ -72,6 +72,8 @@ _SIGS = {
     "snr_metric_row": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int64, C.c_int, _P, _P, _P]),
     "snr_adamw_step": (C.c_int, [C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_float),
                                  C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "snr_latent_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P]),
+    "snr_latent_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P]),
     "snr_adamw_table_step": (C.c_int, [_P, C.c_int, C.c_int64, C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
 }
 

@@ -321,6 +321,59 @@ __global__ void __launch_bounds__(256) adamw_table_kernel(const AdamEntry* __res
     }
 }
 
+// ---- the per-object latent layers (src/model_supnerf.py:253,261: z_j = ReLU(Lin_j(code)), the code = the shape code for the shape blocks, the
+// texture code for the texture blocks) and the bias each z_j folds into (snr_render_args::latent_bias: b_next_j + W_next_j z_j), one launch.
+// w_lat (512, n_lat*256): row block 0 multiplies the shape code, row block 1 the texture code, column block j = layer j (transposed
+// nn.Linear weights, zero where a layer does not read that code); w_nxt (n_lat*256, n_lat*256) block diagonal, transposed likewise.
+// One workgroup per (object, latent layer), thread t = output unit t: every weight row is read with consecutive lanes on consecutive floats.
+__global__ void __launch_bounds__(256) latent_fwd_kernel(const float* __restrict__ sc, const float* __restrict__ tc, const float* __restrict__ w_lat,
+                                                         const float* __restrict__ b_lat, const float* __restrict__ w_nxt, const float* __restrict__ b_nxt,
+                                                         int sb, int n_lat, float* __restrict__ z, float* __restrict__ lb) {
+    __shared__ float code[256], zs[256];
+    const int b = blockIdx.x, j = blockIdx.y, t = threadIdx.x;
+    const long long ld = (long long)n_lat * 256;
+    code[t] = (j < sb ? sc : tc)[(long long)b * 256 + t];
+    __syncthreads();
+    const float* w = w_lat + (long long)(j < sb ? 0 : 256) * ld + j * 256 + t;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 256; k += 4) {
+        a0 = fmaf(code[k], w[(long long)k * ld], a0);           a1 = fmaf(code[k + 1], w[(long long)(k + 1) * ld], a1);
+        a2 = fmaf(code[k + 2], w[(long long)(k + 2) * ld], a2); a3 = fmaf(code[k + 3], w[(long long)(k + 3) * ld], a3);
+    }
+    const float zv = fmaxf(((a0 + a1) + (a2 + a3)) + b_lat[j * 256 + t], 0.f);
+    z[((long long)b * n_lat + j) * 256 + t] = zv;
+    if (!lb) return;
+    zs[t] = zv;
+    __syncthreads();
+    const float* wn = w_nxt + (long long)(j * 256) * ld + j * 256 + t;
+    a0 = a1 = a2 = a3 = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 256; k += 4) {
+        a0 = fmaf(zs[k], wn[(long long)k * ld], a0);           a1 = fmaf(zs[k + 1], wn[(long long)(k + 1) * ld], a1);
+        a2 = fmaf(zs[k + 2], wn[(long long)(k + 2) * ld], a2); a3 = fmaf(zs[k + 3], wn[(long long)(k + 3) * ld], a3);
+    }
+    lb[((long long)b * n_lat + j) * 256 + t] = ((a0 + a1) + (a2 + a3)) + b_nxt[j * 256 + t];
+}
+// backward to the codes: d code[k] = sum over the layers that read this code and their units t of (d z_j[t] where z_j[t] > 0) * w_lat[k][j*256 + t].
+// One wave per code element (grid: objects x 2 codes x 64 workgroups of 4 waves), its lanes along the row of w_lat; fixed summation order.
+__global__ void __launch_bounds__(256) latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ w_lat,
+                                                         int sb, int n_lat, float* __restrict__ d_sc, float* __restrict__ d_tc) {
+    const int b = blockIdx.x, which = blockIdx.y, lane = threadIdx.x & 63;
+    const int k = blockIdx.z * 4 + (threadIdx.x >> 6);
+    const int j0 = which ? sb : 0, j1 = which ? n_lat : sb;
+    float* out = which ? d_tc : d_sc;
+    if (!out) return;
+    const long long ld = (long long)n_lat * 256;
+    const float* w = w_lat + (long long)(which * 256 + k) * ld;
+    const float* g = dz + (long long)b * ld;
+    const float* zz = z + (long long)b * ld;
+    float acc = 0.f;
+    for (int c = j0 * 256 + lane; c < j1 * 256; c += 64) acc = fmaf(zz[c] > 0.f ? g[c] : 0.f, w[c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) out[(long long)b * 256 + k] = acc;
+}
+
 }  // namespace snr
 
 using namespace snr;
@@ -425,6 +478,27 @@ int snr_adamw_table_step(const void* table, int n_tensors, int64_t max_numel, co
     long long gx = (max_numel + 1023) / 1024; if (gx > 256) gx = 256; if (gx < 1) gx = 1;
     adamw_table_kernel<<<dim3((unsigned)gx, (unsigned)n_tensors), 256, 0, (hipStream_t)stream>>>((const AdamEntry*)table, sc, beta1, beta2, eps,
                                                                                                    (float)sqrt(b2));
+    return snr_check_launch_();
+}
+
+int snr_latent_fwd(const float* shapecode, const float* texturecode, const float* w_lat, const float* b_lat, const float* w_nxt, const float* b_nxt,
+                   int64_t n_objects, int shape_blocks, int texture_blocks, float* z, float* latent_bias, void* stream) {
+    const int n_lat = shape_blocks + texture_blocks;
+    if (n_objects == 0 || n_lat == 0) return SNR_OK;
+    if (n_objects < 0 || n_objects > 0x7fffffff || shape_blocks < 0 || texture_blocks < 0 || n_lat > 65535) return SNR_E_ARG;
+    if (!w_lat || !b_lat || !z || (shape_blocks && !shapecode) || (texture_blocks && !texturecode) || (latent_bias && (!w_nxt || !b_nxt))) return SNR_E_ARG;
+    latent_fwd_kernel<<<dim3((unsigned)n_objects, (unsigned)n_lat), 256, 0, (hipStream_t)stream>>>(shapecode, texturecode, w_lat, b_lat, w_nxt, b_nxt,
+                                                                                                shape_blocks, n_lat, z, latent_bias);
+    return snr_check_launch_();
+}
+
+int snr_latent_bwd(const float* d_z, const float* z, const float* w_lat, int64_t n_objects, int shape_blocks, int texture_blocks,
+                   float* d_shapecode, float* d_texturecode, void* stream) {
+    const int n_lat = shape_blocks + texture_blocks;
+    if (n_objects == 0 || n_lat == 0) return SNR_OK;        /* (no latent layer: the codes receive no gradient; the caller zero-fills) */
+    if (n_objects < 0 || n_objects > 0x7fffffff || shape_blocks < 0 || texture_blocks < 0) return SNR_E_ARG;
+    if (!d_z || !z || !w_lat) return SNR_E_ARG;
+    latent_bwd_kernel<<<dim3((unsigned)n_objects, 2, 64), 256, 0, (hipStream_t)stream>>>(d_z, z, w_lat, shape_blocks, n_lat, d_shapecode, d_texturecode);
     return snr_check_launch_();
 }
 

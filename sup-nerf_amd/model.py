@@ -118,7 +118,12 @@ class _DecoderBase(nn.Module):
             lat_layers, _ = self._latent_params()
             if not self.train_decoder_weights or not torch.is_grad_enabled() or \
                     not any(q.requires_grad for l in lat_layers for q in (l.weight, l.bias)):
-                w_lat, b_lat, _, _ = self._stacked()
+                w_lat, b_lat, w_nxt, b_nxt = self._stacked()
+                if shape_latent.shape == texture_latent.shape and shape_latent.dim() == 2 and shape_latent.shape[1] == 256 and texture_latent.is_cuda:
+                    # one launch for all latent layers AND the biases they fold into (latent_biases hands the second output on)
+                    z, lb = ops.LatentLayers.apply(shape_latent, texture_latent, w_lat, b_lat, w_nxt, b_nxt, self.shape_blocks, self.texture_blocks)
+                    z._snr_latent_bias = lb
+                    return z
                 codes = torch.cat([shape_latent, texture_latent], dim=-1)
                 return torch.relu(torch.addmm(b_lat, codes, w_lat)).view(shape_latent.shape[0], n_lat, 256)
         outs = [getattr(self, f"shape_latent_layer_{j + 1}")(shape_latent) for j in range(self.shape_blocks)]
@@ -134,6 +139,9 @@ class _DecoderBase(nn.Module):
         gradient of the latent terms themselves.  None when there are no blocks."""
         if self.shape_blocks + self.texture_blocks == 0:
             return None
+        lb = getattr(lat, "_snr_latent_bias", None)          # (computed with the latent terms themselves: ops.LatentLayers)
+        if lb is not None and lb.shape == lat.shape:
+            return lb
         with torch.no_grad():
             if lat.is_cuda:
                 _, _, w_nxt, b_nxt = self._stacked()

@@ -412,6 +412,46 @@ class DeviceAdamW:
                                             self.betas[0], self.betas[1], self.eps, self.weight_decay, _stream(dev)), "snr_adamw_step")
 
 
+class LatentLayers(torch.autograd.Function):
+    """The per-object latent layers of a FROZEN decoder (src/model_supnerf.py:253,261) and the biases their outputs fold into, one launch;
+    backward to the two codes one launch.  shapecode, texturecode (B,256); w_lat, b_lat, w_nxt, b_nxt: ``model._stacked()``.
+    -> z (B, n_lat, 256), latent_bias (B, n_lat, 256) [no gradient: the render backward returns the gradient of z itself]."""
+
+    @staticmethod
+    def forward(ctx, shapecode, texturecode, w_lat, b_lat, w_nxt, b_nxt, shape_blocks, texture_blocks):
+        shapecode, texturecode = _f32c(shapecode), _f32c(texturecode)
+        _need_gpu(shapecode, texturecode, w_lat, b_lat, w_nxt, b_nxt)
+        n_lat, B, dev = shape_blocks + texture_blocks, shapecode.shape[0], shapecode.device
+        if shapecode.shape != (B, 256) or texturecode.shape != (B, 256) or w_lat.shape != (512, n_lat * 256) or w_nxt.shape != (n_lat * 256, n_lat * 256) \
+                or b_lat.numel() != n_lat * 256 or b_nxt.numel() != n_lat * 256:
+            raise SnrError("latent_layers: expected codes (B,256), w_lat (512, n_lat*256), w_nxt (n_lat*256, n_lat*256), biases (n_lat*256)")
+        z, lb = torch.empty(B, n_lat, 256, device=dev), torch.empty(B, n_lat, 256, device=dev)
+        with torch.cuda.device(dev):
+            check(_lib.lib().snr_latent_fwd(_p(shapecode), _p(texturecode), _p(w_lat), _p(b_lat), _p(w_nxt), _p(b_nxt), B, int(shape_blocks),
+                                            int(texture_blocks), _p(z), _p(lb), _stream(dev)), "snr_latent_fwd")
+        ctx.save_for_backward(z, w_lat)
+        ctx.blocks = (int(shape_blocks), int(texture_blocks))
+        ctx.mark_non_differentiable(lb)
+        ctx.set_materialize_grads(False)
+        return z, lb
+
+    @staticmethod
+    def backward(ctx, d_z, _d_lb):
+        z, w_lat = ctx.saved_tensors
+        if d_z is None:
+            return (None,) * 8
+        if any(ctx.needs_input_grad[2:6]):
+            raise SnrError("latent_layers: the stacked weights are constants here (training mode runs the per-layer torch form)")
+        sb, tb = ctx.blocks
+        B, dev = z.shape[0], z.device
+        d_z = _f32c(d_z)
+        d_sc = torch.empty(B, 256, device=dev) if ctx.needs_input_grad[0] else None
+        d_tc = torch.empty(B, 256, device=dev) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(dev):
+            check(_lib.lib().snr_latent_bwd(_p(d_z), _p(z), _p(w_lat), B, sb, tb, _p(d_sc), _p(d_tc), _stream(dev)), "snr_latent_bwd")
+        return d_sc, d_tc, None, None, None, None, None, None
+
+
 class TableAdamW:
     """torch.optim.AdamW's update (amsgrad off, same defaults) for ANY number of tensors as ONE launch per step: the training step's
     optimiser (src/trainer_unified_nuscenes.py:414-422; torch's foreach form is ~18 launches over the 36 tensors, its ``fused=True`` form

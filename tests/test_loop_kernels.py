@@ -161,6 +161,34 @@ def test_metric_row(amd, dev, opt_cam_pose):
     assert md(row[:, 1], want_d) < 2e-5 and float(row[2, 1]) == 0.0
 
 
+# ------------------------------------------------------------------ per-object latent layers (src/model_supnerf.py:253,261)
+@pytest.mark.parametrize("sb,tb,B", [(3, 1, 1), (3, 1, 5), (2, 1, 64), (1, 0, 3), (0, 2, 2), (5, 5, 2)])
+def test_latent_layers_one_launch_matches_torch(amd, dev, sb, tb, B):
+    """z_j = ReLU(Lin_j(code)) for every block and the biases they fold into, one launch, against the per-layer nn.Linear form in float64;
+    the gradient to both codes against torch's autograd of that form (a code no layer reads gets zeros)."""
+    torch.manual_seed(sb * 10 + tb)
+    m = amd.CodeNeRF(sb, tb).to(dev)
+    g = torch.Generator().manual_seed(B)
+    sc0, tc0 = torch.randn(B, 256, generator=g) * 0.3, torch.randn(B, 256, generator=g) * 0.3
+    up = torch.randn(B, sb + tb, 256, generator=g)
+    sc, tc = sc0.to(dev).requires_grad_(), tc0.to(dev).requires_grad_()
+    z = m.latent_terms(sc, tc)
+    lb = m.latent_biases(z)
+    assert getattr(z, "_snr_latent_bias", None) is lb                     # (the one-launch path ran)
+    (z * up.to(dev)).sum().backward()
+    m64 = amd.CodeNeRF(sb, tb).double(); m64.load_state_dict({k: v.double().cpu() for k, v in m.state_dict().items()})
+    s64, t64 = sc0.double().requires_grad_(), tc0.double().requires_grad_()
+    lat = [getattr(m64, f"shape_latent_layer_{j + 1}")(s64) for j in range(sb)] + [getattr(m64, f"texture_latent_layer_{j + 1}")(t64) for j in range(tb)]
+    nxt = [getattr(m64, f"shape_layer_{j + 1}")[0] for j in range(sb)] + [getattr(m64, f"texture_layer_{j + 1}")[0] for j in range(tb)]
+    z64 = torch.stack(lat, 1)
+    lb64 = torch.stack([lin(z64[:, j]) for j, lin in enumerate(nxt)], 1)
+    (z64 * up.double()).sum().backward()
+    assert md(z, z64) < 2e-6 and md(lb, lb64) < 5e-6, (md(z, z64), md(lb, lb64))
+    for got, want in ((sc.grad, s64.grad), (tc.grad, t64.grad)):
+        want = torch.zeros(B, 256, dtype=torch.float64) if want is None else want
+        assert md(got, want) < 1e-5 * max(1.0, float(want.abs().max())), md(got, want)
+
+
 # ------------------------------------------------------------------ AdamW (src/optimizer_nuscenes.py:1762-1769: torch.optim.AdamW defaults)
 def test_device_adamw_matches_torch(amd, dev):
     g = torch.Generator().manual_seed(11)
