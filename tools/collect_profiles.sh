@@ -27,6 +27,13 @@ done
 # 3b. the training step (BASELINE config 5's per-GPU shape): chains with dumps + the weight-gradient kernels, both arithmetics
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/train -o train -- python3 tools/train_bench.py 8 bf16x3 > $out/train.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/train_fp32 -o train_fp32 -- python3 tools/train_bench.py 8 fp32 > $out/train_fp32.log 2>&1
+# 3b'. BASELINE config 3's iteration: 64 objects x 4096 rays x 64 samples per launch (what the 1 -> 8 GPU curve shards)
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/c3 -o c3 -- python3 tools/prof_c3.py 64 8 > $out/c3.log 2>&1
+# 3b". the weight-gradient products alone (256 x 256 layer, 524 288 points): per-kernel time, then matrix-pipe and clock counters
+for prec in fp32 bf16x3; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $raw/wgrad_$prec -o wgrad_$prec -- python3 tools/prof_wgrad.py $prec 8 > $out/wgrad_${prec}.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $raw/wgradpmc_$prec -o pmc -- python3 tools/prof_wgrad.py $prec 8 > $out/wgrad_pmc_${prec}.log 2>&1
+done
 # 3c. the HBM-bound stand-alone kernels (encode with PE output, composite forward, scene composite)
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/hbm -o hbm -- python3 tools/prof_hbm.py > $out/hbm.log 2>&1
 # 4. counters of the dominant kernels, separate passes (no trace domains mixed in).  "fwd" = the headline forward (no ReLU bits saved),
@@ -63,5 +70,23 @@ for prec, fwd_name, bwd_name in (("fp32", "decoder_fwd_kernel", "decoder_bwd_ker
                    "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (FETCH_SIZE x2 on gfx950, MI355X_MICROARCH.md)"},
                   open(os.path.join(out, f"{which}_pmc_{prec}.json"), "w"), indent=1)
         print(prec, which, json.dumps(res))
+# the weight-gradient products: counters per dispatch + duration -> matrix-pipe busy fraction and effective clock
+for prec, kname in (("fp32", "wgrad_mfma_kernel"), ("bf16x3", "wgrad_bf16x3_kernel")):
+    agg, dur = {}, []
+    for f in glob.glob(os.path.join(raw, f"wgradpmc_{prec}", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if kname in row.get("Kernel_Name", ""):
+                agg.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    for f in glob.glob(os.path.join(raw, f"wgradpmc_{prec}", "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if kname in row.get("Kernel_Name", ""):
+                dur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+    if agg and dur:
+        m = {c: sum(v) / len(v) for c, v in agg.items()}
+        us = sum(dur) / len(dur)
+        json.dump({"kernel": kname + ", 256 x 256 layer, 524 288 points", "mean_us_under_counters": us, "counters_per_dispatch": m,
+                   "mfma_busy_frac": m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4 * m["SQ_WAVE_CYCLES"]) if m.get("SQ_WAVE_CYCLES") else None,
+                   "effective_clock_ghz": m.get("GRBM_GUI_ACTIVE", 0) / 8 / us / 1e3 if m.get("GRBM_GUI_ACTIVE") else None},
+                  open(os.path.join(out, f"wgrad_pmc_{prec}.json"), "w"), indent=1)
 PY
 ls -la $out
