@@ -488,7 +488,8 @@ def main():
     batch = {k: v.to(dev) for k, v in batch.items()}
     hp_t = dict(lr_schedule=[dict(lr=1e-4, interval=40000), dict(lr=1e-4, interval=40000)])
     extra["training_step"] = {}
-    for p_t in ("fp32", "bf16x3"):
+    DTYPE_T = dict(DTYPE, auto="f32 layer chains (exact) + bf16x3 weight-gradient products (fp32 accumulate)")
+    for p_t in ("auto", "fp32", "bf16x3"):
         m_t = A.CodeNeRF(3, 1); m_t.load_state_dict(w["params"]); m_t = m_t.to(dev); m_t.train_decoder_weights = True
         m_t.precision = p_t
         codes = T.CodeTables(64, 256, seed=1).to(dev)
@@ -497,10 +498,12 @@ def main():
         n_t = 10
         t_t = clock.wall(lambda: T.train_step(m_t, codes, opt_t, bucket, batch, 0.1), n_t, 3)
         extra["training_step"][p_t] = {"ms_per_step": t_t / n_t * 1e3, "rays_per_s": world * Bt * nt * n_t / t_t, "objects_per_gpu": Bt, "rays_per_object": nt,
-                                       "samples": N_SAMPLES, "steps": n_t, "dtype": DTYPE[p_t], "model_precision": m_t.precision}
+                                       "samples": N_SAMPLES, "steps": n_t, "dtype": DTYPE_T[p_t], "model_precision": m_t.precision}
         del m_t, codes, bucket, opt_t
-    extra["training_step"]["note"] = ("trainer.train_step: forward + backward incl. every decoder weight gradient + one all-reduce of the flat gradient bucket + AdamW; "
-                                      "`fp32` = the reference's arithmetic, what `precision = 'auto'` trains in; `bf16x3` = split-bf16 chains and weight-gradient products, opt-in (2.2x faster; tests/test_driver_gpu.py::test_training_outcome_fp32_and_bf16x3_track_the_oracle has the evidence)")
+    extra["training_step"]["note"] = ("trainer.train_step: forward + backward incl. every decoder weight gradient + one all-reduce of the flat gradient bucket + AdamW (one launch); "
+                                      "`auto` = the library default in training mode: exact-fp32 layer chains + split-bf16 weight-gradient products -- a 60-step run ends where the "
+                                      "reference's own fp32 arithmetic ends (the chains decide that, not the products); `fp32` = exact fp32 throughout, the reference's arithmetic product for "
+                                      "product; `bf16x3` = split-bf16 throughout, opt-in (tests/test_driver_gpu.py::test_training_outcome_fp32_and_bf16x3_track_the_oracle has the evidence for all three)")
     del batch
 
     log("HBM-bound kernels")

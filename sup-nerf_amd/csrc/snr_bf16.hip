@@ -778,7 +778,7 @@ __device__ __forceinline__ void bwd_quarter(const f32x16& acc, XOp& out, const B
     for (int e = 0; e < 4; ++e) {
         const int r = 4 * j + e;
         float v = acc[r];
-        v = ((c.m[T >> 1] >> ((T & 1) * 16 + r)) & 1u) ? v : 0.f;
+        v = ((c.m[T >> 1] >> ((T & 1) * 16 + r)) & 1u) ? v : 0.f;      // (v_bfe_i32 + v_and instead of test + select: measured, 0.5979 -> 0.5970 ms, nothing)
         split_store(v, out, r & 7);
         if (DUMP) dv[e] = v;
     }

@@ -682,8 +682,9 @@ class DecoderPointsTrain(torch.autograd.Function):
     """Training-mode decoder (SURVEY 8a9 mode B): like DecoderPoints but the per-point decoder WEIGHTS are inputs too and
     receive gradients.  The layer-chain kernels additionally write every layer's input X_l (forward) and pre-activation
     gradient G_l (backward) to HBM, and the weight gradients dW_l = G_l^T X_l, db_l = sum_p G_l come from the split-K MFMA kernels
-    behind ``weight_grad`` (no library BLAS).  ``precision``: "fp32" = exact fp32 MFMA throughout; "bf16x3" / "auto" = split-bf16
-    products in all three (the chains and the weight-gradient product; bias sums and the two narrow heads stay fp32).  ``weights`` = the
+    behind ``weight_grad`` (no library BLAS).  ``precision``: "fp32" = exact fp32 MFMA throughout; "bf16x3" = split-bf16
+    products in all three (the chains and the weight-gradient product; bias sums and the two narrow heads stay fp32); a pair
+    (chains, products), e.g. ("fp32", "bf16x3"): exact fp32 layer chains, split-bf16 weight-gradient products.  ``weights`` = the
     per-point tensors in per_point_tensor_names order."""
 
     @staticmethod
@@ -697,8 +698,13 @@ class DecoderPointsTrain(torch.autograd.Function):
         if n_pad:
             xyz, viewdir = _pad_rows(xyz, B, P0 // B, n_pad), _pad_rows(viewdir, B, P0 // B, n_pad)
         # one arithmetic for the whole step: the forward / backward layer chains and the weight-gradient products
-        prec = resolve_precision(precision, shape_blocks, texture_blocks, xyz.shape[0] // max(latent.shape[0], 1))
-        wgrad_precision = "bf16x3" if prec == BF16X3 else "fp32"
+        # ``precision``: one name for the whole step, or (layer chains, weight-gradient products) -- ("fp32", "bf16x3") is what "auto"
+        # trains in (model.forward): the chains decide where a training run ends up, the products do not
+        chain_precision, wgrad_override = precision if isinstance(precision, tuple) else (precision, None)
+        prec = resolve_precision(chain_precision, shape_blocks, texture_blocks, xyz.shape[0] // max(latent.shape[0], 1))
+        wgrad_precision = wgrad_override or ("bf16x3" if prec == BF16X3 else "fp32")
+        if wgrad_precision not in ("fp32", "bf16x3"):
+            raise SnrError(f"weight-gradient products run in 'fp32' or 'bf16x3', not {wgrad_precision!r}")
         names = per_point_tensor_names(shape_blocks, texture_blocks)
         packed = _packed_for(names, weights, shape_blocks, texture_blocks)
         P, dev = xyz.shape[0], xyz.device

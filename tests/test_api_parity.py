@@ -395,7 +395,7 @@ def test_training_shapes_volume_rendering_batch(amd, dev, model, golden):
 def test_training_step_weight_gradients(amd, dev, oracle_params, golden, precision):
     """Training mode (src/trainer_unified_nuscenes.py:120-129,334): loss.backward() also reaches every decoder weight.
     Checked against the reference's own gradients: every bias and small tensor in full, every weight's first row,
-    and sum / abs-sum of every tensor.  "fp32": exact fp32 MFMA in the chains and the weight-gradient product (what "auto" trains in);
+    and sum / abs-sum of every tensor.  "fp32": exact fp32 MFMA in the chains and the weight-gradient product;
     "bf16x3": split-bf16 in all three (against the REFERENCE's numbers the comparison cannot be mask-matched; 2048 points here: a hidden unit whose pre-activation sits within round-off of zero flips its ReLU between the two arithmetics and
     moves single entries by up to a percent; the aggregated sums stay at 1e-4)."""
     g = golden("train_step")

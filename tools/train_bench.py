@@ -6,7 +6,7 @@ import supnerf_amd as A
 from supnerf_amd import trainer as T, synthetic as SY
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-PREC = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
+PREC = sys.argv[2] if len(sys.argv) > 2 else "auto"      # auto | fp32 | bf16x3
 n, S = 1024, 64
 dev = torch.device("cuda:0")
 m = A.CodeNeRF(3, 1); m.load_state_dict(SY.init_decoder_params()); m = m.to(dev); m.train_decoder_weights = True; m.precision = PREC
