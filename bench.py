@@ -488,7 +488,7 @@ def main():
     batch = {k: v.to(dev) for k, v in batch.items()}
     hp_t = dict(lr_schedule=[dict(lr=1e-4, interval=40000), dict(lr=1e-4, interval=40000)])
     extra["training_step"] = {}
-    DTYPE_T = dict(DTYPE, auto="f32 layer chains (exact) + bf16x3 weight-gradient products (fp32 accumulate)")
+    DTYPE_T = dict(DTYPE, auto="f32 forward chain (exact) + bf16x3 backward chain and weight-gradient products (fp32 accumulate)")
     for p_t in ("auto", "fp32", "bf16x3"):
         m_t = A.CodeNeRF(3, 1); m_t.load_state_dict(w["params"]); m_t = m_t.to(dev); m_t.train_decoder_weights = True
         m_t.precision = p_t
@@ -501,8 +501,8 @@ def main():
                                        "samples": N_SAMPLES, "steps": n_t, "dtype": DTYPE_T[p_t], "model_precision": m_t.precision}
         del m_t, codes, bucket, opt_t
     extra["training_step"]["note"] = ("trainer.train_step: forward + backward incl. every decoder weight gradient + one all-reduce of the flat gradient bucket + AdamW (one launch); "
-                                      "`auto` = the library default in training mode: exact-fp32 layer chains + split-bf16 weight-gradient products -- a 60-step run ends where the "
-                                      "reference's own fp32 arithmetic ends (the chains decide that, not the products); `fp32` = exact fp32 throughout, the reference's arithmetic product for "
+                                      "`auto` = the library default in training mode: exact-fp32 forward chain + split-bf16 backward chain and weight-gradient products -- a 60-step run ends where the "
+                                      "reference's own fp32 arithmetic ends (the forward chain decides that, not what runs behind it); `fp32` = exact fp32 throughout, the reference's arithmetic product for "
                                       "product; `bf16x3` = split-bf16 throughout, opt-in (tests/test_driver_gpu.py::test_training_outcome_fp32_and_bf16x3_track_the_oracle has the evidence for all three)")
     del batch
 

@@ -684,7 +684,8 @@ class DecoderPointsTrain(torch.autograd.Function):
     gradient G_l (backward) to HBM, and the weight gradients dW_l = G_l^T X_l, db_l = sum_p G_l come from the split-K MFMA kernels
     behind ``weight_grad`` (no library BLAS).  ``precision``: "fp32" = exact fp32 MFMA throughout; "bf16x3" = split-bf16
     products in all three (the chains and the weight-gradient product; bias sums and the two narrow heads stay fp32); a pair
-    (chains, products), e.g. ("fp32", "bf16x3"): exact fp32 layer chains, split-bf16 weight-gradient products.  ``weights`` = the
+    (chains, products) or a triple (forward chain, backward chain, products), e.g. ("fp32", "bf16x3", "bf16x3"): exact fp32 forward,
+    split-bf16 backward chain (on the ReLU bits the forward saved) and weight-gradient products.  ``weights`` = the
     per-point tensors in per_point_tensor_names order."""
 
     @staticmethod
@@ -698,10 +699,17 @@ class DecoderPointsTrain(torch.autograd.Function):
         if n_pad:
             xyz, viewdir = _pad_rows(xyz, B, P0 // B, n_pad), _pad_rows(viewdir, B, P0 // B, n_pad)
         # one arithmetic for the whole step: the forward / backward layer chains and the weight-gradient products
-        # ``precision``: one name for the whole step, or (layer chains, weight-gradient products) -- ("fp32", "bf16x3") is what "auto"
-        # trains in (model.forward): the chains decide where a training run ends up, the products do not
-        chain_precision, wgrad_override = precision if isinstance(precision, tuple) else (precision, None)
-        prec = resolve_precision(chain_precision, shape_blocks, texture_blocks, xyz.shape[0] // max(latent.shape[0], 1))
+        # ``precision``: one name for the whole step, or (layer chains, weight-gradient products), or (forward chain, backward chain,
+        # products) -- ("fp32", "auto", "bf16x3") is what "auto" trains in (model.forward): the forward chain decides where a training
+        # run ends up, what runs behind it does not
+        bwd_chain = None
+        if isinstance(precision, tuple) and len(precision) == 3:
+            chain_precision, bwd_chain, wgrad_override = precision
+        else:
+            chain_precision, wgrad_override = precision if isinstance(precision, tuple) else (precision, None)
+        per_obj = xyz.shape[0] // max(latent.shape[0], 1)
+        prec = resolve_precision(chain_precision, shape_blocks, texture_blocks, per_obj)
+        prec_bwd = prec if bwd_chain is None else resolve_precision(bwd_chain, shape_blocks, texture_blocks, per_obj)
         wgrad_precision = wgrad_override or ("bf16x3" if prec == BF16X3 else "fp32")
         if wgrad_precision not in ("fp32", "bf16x3"):
             raise SnrError(f"weight-gradient products run in 'fp32' or 'bf16x3', not {wgrad_precision!r}")
@@ -713,7 +721,7 @@ class DecoderPointsTrain(torch.autograd.Function):
         sig, rgb, masks = decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=True, precision=prec,
                                       activations=act)
         ctx.save_for_backward(xyz, viewdir, latent, packed, masks, sig, act, *weights)
-        ctx.cfg = (shape_blocks, texture_blocks, wgrad_precision, prec)
+        ctx.cfg = (shape_blocks, texture_blocks, wgrad_precision, prec_bwd)
         if n_pad:
             return _unpad_rows(sig, B, P0 // B, n_pad), _unpad_rows(rgb, B, P0 // B, n_pad)
         return sig, rgb

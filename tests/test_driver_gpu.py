@@ -143,8 +143,8 @@ def test_training_step_matches_oracle(oracle_params, precision):
 
 def test_training_outcome_fp32_and_bf16x3_track_the_oracle(oracle_params):
     """Which arithmetic may config 5 train in?  (VERDICT r2 #4b)  60 steps of ``trainer.train_step`` over four fixed mini-batches (2 objects
-    x 32 rays x 64 samples, decoder + codes trained, the reference's AdamW) with the exact-fp32 kernels, with exact-fp32 chains + split-bf16
-    weight-gradient products ("auto") and with the split-bf16 kernels,
+    x 32 rays x 64 samples, decoder + codes trained, the reference's AdamW) with the exact-fp32 kernels, with the exact-fp32 forward chain +
+    split-bf16 backward chain and weight-gradient products ("auto") and with the split-bf16 kernels,
     against the SAME 60 steps on the CPU oracle in float64 (the truth) and in float32 (the reference's arithmetic: its distance from the
     truth is the floor).  Loss curve and final decoder weights, the latter relative to how far training moved each tensor."""
     import supnerf_amd
@@ -211,8 +211,8 @@ def test_training_outcome_fp32_and_bf16x3_track_the_oracle(oracle_params):
         else:
             # the default: as close to the truth as the reference's own fp32 arithmetic is, within a factor of three
             assert dc < 3 * floor_c + 1e-5 and dw < 3 * floor_w + 1e-3, (precision, dc, floor_c, dw, floor_w)
-    # "auto" in training mode = the exact-fp32 CHAINS with split-bf16 weight-gradient PRODUCTS: held to the fp32 floor above like "fp32";
-    # its forward is the exact one (the first loss, before any weight moved, is the same number)
+    # "auto" in training mode = the exact-fp32 FORWARD chain with the split-bf16 backward chain and weight-gradient products: held to the
+    # fp32 floor above like "fp32"; its forward is the exact one (the first loss, before any weight moved, is the same number)
     assert res["auto"][0][0] == res["fp32"][0][0] and not np.array_equal(res["auto"][0], res["fp32"][0])
 
 
