@@ -27,6 +27,7 @@ done
 # 3b. the training step (BASELINE config 5's per-GPU shape): chains with dumps + the weight-gradient kernels, both arithmetics
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/train -o train -- python3 tools/train_bench.py 8 bf16x3 > $out/train.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/train_fp32 -o train_fp32 -- python3 tools/train_bench.py 8 fp32 > $out/train_fp32.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/train_auto -o train_auto -- python3 tools/train_bench.py 8 auto > $out/train_auto.log 2>&1
 # 3b'. BASELINE config 3's iteration: 64 objects x 4096 rays x 64 samples per launch (what the 1 -> 8 GPU curve shards)
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/c3 -o c3 -- python3 tools/prof_c3.py 64 8 > $out/c3.log 2>&1
 # 3b". the weight-gradient products alone (256 x 256 layer, 524 288 points): per-kernel time, then matrix-pipe and clock counters
