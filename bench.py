@@ -447,15 +447,15 @@ def main():
             fn(); torch.cuda.synchronize()
             t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
             return time.perf_counter() - t0
-        for p in ("fp32", "auto"):
+        for p, name in (("fp32", "fp32"), (("fp32", "bf16x3"), "fp32_forward_bf16x3_backward"), ("auto", "auto")):
             model.precision = p
             t_f = timed(lambda: D.optimize_object(model, dev, objs[0], hp, sc_l, tc_l, seed=0))
-            loop[f"fused_eager_{p}"] = {"ms_per_iteration": t_f / n_it1 * 1e3, "object_iterations_per_s": n_it1 / t_f}
+            loop[f"fused_eager_{name}"] = {"ms_per_iteration": t_f / n_it1 * 1e3, "object_iterations_per_s": n_it1 / t_f}
         t_a = timed(lambda: D.optimize_object_api(model, dev, objs[0], hp, sc_l, tc_l, seed=0))
         loop.update({"api_structured_auto": {"ms_per_iteration": t_a / n_it1 * 1e3, "object_iterations_per_s": n_it1 / t_a},
                      "iterations": n_it1, "rays_per_object": N_RAYS,
                      "note": "iteration = forward + backward (codes, pose) + 64-pixel depth render + metric row + AdamW at 4096 x 64; fused_eager = driver.optimize_object "
-                             "(~24 launches per iteration, no graph); api_structured = the same loop on the public functions, call for call like the reference; "
+                             "(~20 launches per iteration, no graph; fp32_forward_bf16x3_backward: precision = ('fp32', 'bf16x3'), the reference's forward values bit for bit with the gradient on the split-bf16 kernel); api_structured = the same loop on the public functions, call for call like the reference; "
                              "set-up included everywhere"})
     extra["optimise_loop"] = loop
 

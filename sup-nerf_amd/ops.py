@@ -18,9 +18,16 @@ IDENTITY_FRAME = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
 PRECISIONS = {"fp32": FP32, "bf16x3": BF16X3}
 
 
-def resolve_precision(precision, shape_blocks, texture_blocks, points_per_obj) -> int:
+def resolve_precision(precision, shape_blocks, texture_blocks, points_per_obj, backward=False) -> int:
     """'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16, ~2^-17 operand error, several times faster) or 'auto'
-    (bf16x3 where the kernel supports the configuration, else fp32).  Asking for 'bf16x3' where it is unsupported raises."""
+    (bf16x3 where the kernel supports the configuration, else fp32).  Asking for 'bf16x3' where it is unsupported raises.
+    A pair (forward, backward) names the two launches apart, e.g. ("fp32", "bf16x3"): the reference's forward values bit for bit in
+    its own arithmetic, the gradient on the split-bf16 kernel (it applies the ReLU pattern the forward saved; 2^-17 per product) --
+    ``backward`` picks the member.  (A training triple (forward chain, backward chain, products) resolves like its first two.)"""
+    if isinstance(precision, tuple):
+        if len(precision) not in (2, 3):
+            raise SnrError(f"a precision tuple is (forward, backward) or (forward chain, backward chain, products), got {precision!r}")
+        precision = precision[1 if backward else 0]
     if isinstance(precision, int) and not isinstance(precision, bool):
         return precision
     if precision is None or precision == "auto":
@@ -606,7 +613,7 @@ class DecoderPoints(torch.autograd.Function):
         sig, rgb, masks = decoder_fwd(xyz, viewdir, latent, packed, shape_blocks, texture_blocks, save_masks=need, precision=prec)
         if need:
             ctx.save_for_backward(xyz, viewdir, latent, packed, masks, sig)
-            ctx.cfg = (shape_blocks, texture_blocks, prec)
+            ctx.cfg = (shape_blocks, texture_blocks, resolve_precision(precision, shape_blocks, texture_blocks, xyz.shape[0] // B, backward=True))
         if n_pad:
             return _unpad_rows(sig, B, P // B, n_pad), _unpad_rows(rgb, B, P // B, n_pad)
         return sig, rgb
@@ -684,8 +691,9 @@ class DecoderPointsTrain(torch.autograd.Function):
     gradient G_l (backward) to HBM, and the weight gradients dW_l = G_l^T X_l, db_l = sum_p G_l come from the split-K MFMA kernels
     behind ``weight_grad`` (no library BLAS).  ``precision``: "fp32" = exact fp32 MFMA throughout; "bf16x3" = split-bf16
     products in all three (the chains and the weight-gradient product; bias sums and the two narrow heads stay fp32); a pair
-    (chains, products) or a triple (forward chain, backward chain, products), e.g. ("fp32", "bf16x3", "bf16x3"): exact fp32 forward,
-    split-bf16 backward chain (on the ReLU bits the forward saved) and weight-gradient products.  ``weights`` = the
+    (forward chain, backward chain) -- the products follow the backward chain -- or a triple (forward chain, backward chain, products),
+    e.g. ("fp32", "bf16x3", "bf16x3"): exact fp32 forward, split-bf16 backward chain (on the ReLU bits the forward saved) and
+    weight-gradient products.  ``weights`` = the
     per-point tensors in per_point_tensor_names order."""
 
     @staticmethod
@@ -699,18 +707,14 @@ class DecoderPointsTrain(torch.autograd.Function):
         if n_pad:
             xyz, viewdir = _pad_rows(xyz, B, P0 // B, n_pad), _pad_rows(viewdir, B, P0 // B, n_pad)
         # one arithmetic for the whole step: the forward / backward layer chains and the weight-gradient products
-        # ``precision``: one name for the whole step, or (layer chains, weight-gradient products), or (forward chain, backward chain,
-        # products) -- ("fp32", "auto", "bf16x3") is what "auto" trains in (model.forward): the forward chain decides where a training
-        # run ends up, what runs behind it does not
-        bwd_chain = None
-        if isinstance(precision, tuple) and len(precision) == 3:
-            chain_precision, bwd_chain, wgrad_override = precision
-        else:
-            chain_precision, wgrad_override = precision if isinstance(precision, tuple) else (precision, None)
+        # ``precision``: one name for the whole step, (forward chain, backward chain) -- the products follow the backward chain -- or (forward
+        # chain, backward chain, products); ("fp32", "auto", "bf16x3") is what "auto" trains in (model.forward): the forward chain decides
+        # where a training run ends up, what runs behind it does not
+        wgrad_override = precision[2] if isinstance(precision, tuple) and len(precision) == 3 else None
         per_obj = xyz.shape[0] // max(latent.shape[0], 1)
-        prec = resolve_precision(chain_precision, shape_blocks, texture_blocks, per_obj)
-        prec_bwd = prec if bwd_chain is None else resolve_precision(bwd_chain, shape_blocks, texture_blocks, per_obj)
-        wgrad_precision = wgrad_override or ("bf16x3" if prec == BF16X3 else "fp32")
+        prec = resolve_precision(precision, shape_blocks, texture_blocks, per_obj)
+        prec_bwd = resolve_precision(precision, shape_blocks, texture_blocks, per_obj, backward=True)
+        wgrad_precision = wgrad_override or ("bf16x3" if prec_bwd == BF16X3 else "fp32")       # (a pair: the products follow the backward chain)
         if wgrad_precision not in ("fp32", "bf16x3"):
             raise SnrError(f"weight-gradient products run in 'fp32' or 'bf16x3', not {wgrad_precision!r}")
         names = per_point_tensor_names(shape_blocks, texture_blocks)
@@ -982,7 +986,7 @@ def render_bwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg: Re
     bh = _f32c(cfg.box_half)
     a = _render_args(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg.frame, cfg.xyz_mul, cfg.z_mode, cfg.flags,
                      cfg.rays_per_obj, cfg.n_samples, cfg.shape_blocks, cfg.texture_blocks,
-                     resolve_precision(cfg.precision, cfg.shape_blocks, cfg.texture_blocks, cfg.rays_per_obj * cfg.n_samples),
+                     resolve_precision(cfg.precision, cfg.shape_blocks, cfg.texture_blocks, cfg.rays_per_obj * cfg.n_samples, backward=True),
                      box_half=bh, rng=cfg.rng)
     ws_bytes = _lib.lib().snr_render_bwd_ws_bytes(C.byref(a))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

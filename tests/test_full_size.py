@@ -120,6 +120,34 @@ def test_config2_full_size_against_oracle(amd, dev, oracle_params, c2_oracle, pr
     assert e_true < floor + GRAD_REL[precision], (e_true, floor)
 
 
+def test_config2_exact_forward_with_split_bf16_backward(amd, dev, oracle_params, c2_oracle):
+    """``precision = ("fp32", "bf16x3")``: the forward is the exact-fp32 launch (bit for bit what ``"fp32"`` renders), the backward the
+    split-bf16 launch on the ReLU bits that forward saved -- gradients held to the same bounds as the split-bf16 pair's."""
+    r = c2_oracle
+    ob = r["ob"]
+    outs = {}
+    for precision in ("fp32", ("fp32", "bf16x3")):
+        model = make_model(amd, dev, oracle_params, precision)
+        sc, tc = r["sc0"].to(dev).requires_grad_(), r["tc0"].to(dev).requires_grad_()
+        pose = ob["cam_pose"].to(dev).requires_grad_()
+        amd.utils.JITTER_OVERRIDE = r["jit"]
+        try:
+            out = amd.utils.render_rays_v2(model, dev, r["img"], r["mask"], pose, ob["obj_diag"], ob["K"], ob["roi"], S, sc, tc, 1, 0, im_sz=IM)
+        finally:
+            amd.utils.JITTER_OVERRIDE = None
+        O.optimise_losses(out[0], out[2], out[3], out[4], 0.1)[0].backward()
+        outs[precision if isinstance(precision, str) else "mixed"] = ([t.detach() for t in out[:3]], sc.grad, tc.grad, pose.grad)
+    for a, b in zip(outs["fp32"][0], outs["mixed"][0]):
+        assert torch.equal(a, b)                                    # the same forward launch
+    e = dict(sc=rel(outs["mixed"][1], r["g_sc"]), tc=rel(outs["mixed"][2], r["g_tc"]))
+    floor, e_true = rel(r["g_pose"], r["g_pose64"]), rel(outs["mixed"][3], r["g_pose64"])
+    print(f"[config 2, fp32 forward + bf16x3 backward] grad rel err codes {e['sc']:.2e}/{e['tc']:.2e}, pose vs float64 {e_true:.2e} (fp32 oracle {floor:.2e}); "
+          f"against the fp32 pair's gradients: codes {rel(outs['mixed'][1], outs['fp32'][1]):.2e}/{rel(outs['mixed'][2], outs['fp32'][2]):.2e}")
+    assert not torch.equal(outs["mixed"][1], outs["fp32"][1])       # (the split-bf16 backward really ran)
+    assert max(e["sc"], e["tc"]) < GRAD_REL["auto"], e
+    assert e_true < floor + GRAD_REL["auto"], (e_true, floor)
+
+
 # ------------------------------------------------------------------ config 3
 C3_OBJECTS, C3_SAMPLED = 64, (0, 29, 63)
 
