@@ -195,9 +195,12 @@ __device__ __forceinline__ void pin(XOp& o) { asm volatile("" : "+v"(o.hi), "+v"
 #ifndef SNR_ILB_VALU
 #define SNR_ILB_VALU 3
 #endif
+#ifndef SNR_ILB_MFMA
+#define SNR_ILB_MFMA 1
+#endif
 #define SNR_INTERLEAVE_(N_MFMA, DS, VALU)                                                \
-    _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA); ++g_) {                            \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
+    _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA) / SNR_ILB_MFMA; ++g_) {             \
+        __builtin_amdgcn_sched_group_barrier(0x008, SNR_ILB_MFMA, 0);                    \
         if (DS) __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);                      \
         if (VALU) __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);                  \
     }
@@ -219,11 +222,14 @@ __device__ __forceinline__ void pin(XOp& o) { asm volatile("" : "+v"(o.hi), "+v"
 #define SNR_STAMP(i) do {} while (0)
 #endif
 
+// interleave request of the forward's groups: 3 MFMAs, then 3 VALU ops (tools/ab_time.py, two boxes, interleaved rounds: 1:1 0.4940 /
+// 0.5289 ms forward / forward with ReLU bits, 3:3 0.4840 / 0.5162, 1:0 0.4937 / 0.5232, 2:2, 3:2, 3:4, 4:3, 4:4, 6:6, 8:8, 12:12 all slower
+// than 3:3 -- the solver's freedom inside a request matters as much as the ratio)
 #ifndef SNR_IL16_MFMA
-#define SNR_IL16_MFMA 1
+#define SNR_IL16_MFMA 3
 #endif
 #ifndef SNR_IL16_VALU
-#define SNR_IL16_VALU 1
+#define SNR_IL16_VALU 3
 #endif
 #define SNR_INTERLEAVE16(N_MFMA)                                                         \
     _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA) / SNR_IL16_MFMA; ++g_) {            \
