@@ -231,9 +231,13 @@ __device__ __forceinline__ void pin(XOp& o) { asm volatile("" : "+v"(o.hi), "+v"
 #ifndef SNR_IL16_VALU
 #define SNR_IL16_VALU 3
 #endif
+#ifndef SNR_IL16_DS
+#define SNR_IL16_DS 0          // (an LDS-read request in the groups: 1 or 2 per 3 or 6 MFMAs measured 1.4 - 5 % slower)
+#endif
 #define SNR_INTERLEAVE16(N_MFMA)                                                         \
     _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA) / SNR_IL16_MFMA; ++g_) {            \
         __builtin_amdgcn_sched_group_barrier(0x008, SNR_IL16_MFMA, 0);                   \
+        if (SNR_IL16_DS) __builtin_amdgcn_sched_group_barrier(0x100, SNR_IL16_DS, 0);    \
         if (SNR_IL16_VALU) __builtin_amdgcn_sched_group_barrier(0x002, SNR_IL16_VALU, 0);\
     }
 
