@@ -254,27 +254,38 @@ __global__ void __launch_bounds__(1024) wgrad_reduce_kernel(const float* __restr
 }
 
 // narrow outputs (the density head: 1 row, the colour head: 3 rows): one thread per input column, points strided over the slices;
-// X is streamed once with coalesced loads, the <= 4 gradient values of a point are broadcast loads
-__global__ void __launch_bounds__(256) wgrad_small_kernel(const float* __restrict__ G, long long ldg, int n_out, const float* __restrict__ X, long long ldx,
+// X is streamed once with coalesced loads, the <= 4 gradient values of a point are wave-uniform (scalar) loads.  Whole groups of eight
+// points run without a single condition (NO = n_out is a template parameter, a column past n_in reads column 0 and its sums are never
+// looked at): the conditional form spent the loop on ~80 scalar branches per group (282 us for the two heads at 524 288 points,
+// 215 us now).
+template <int NO>
+__global__ void __launch_bounds__(256) wgrad_small_kernel(const float* __restrict__ G, long long ldg, const float* __restrict__ X, long long ldx,
                                                           int n_in, long long n_points, long long points_per_slice, float* __restrict__ part_w,
                                                           float* __restrict__ part_b) {
     const int j = threadIdx.x;
+    const int jc = j < n_in ? j : 0;
     const long long p_begin = blockIdx.x * points_per_slice;
     const long long p_end = p_begin + points_per_slice < n_points ? p_begin + points_per_slice : n_points;
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long long p = p_begin; p < p_end; p += 8) {           // eight points' loads in flight
-        float x[8], g[8][4];
+    long long p = p_begin;
+    constexpr int WD = 8;                                      // (4, 16, 32 measured the same once the conditions were gone)
+    for (; p + WD <= p_end; p += WD) {                         // WD points' loads in flight
+        float x[WD], g[WD][NO];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool on = p + u < p_end;
-            x[u] = (on && j < n_in) ? X[(p + u) * ldx + j] : 0.f;
+        for (int u = 0; u < WD; ++u) x[u] = X[(p + u) * ldx + jc];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) g[u][i] = (on && i < n_out) ? G[(p + u) * ldg + i] : 0.f;
-        }
+        for (int u = 0; u < WD; ++u)
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+            for (int i = 0; i < NO; ++i) g[u][i] = G[(p + u) * ldg + i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { acc[i] += g[u][i] * x[u]; bs[i] += g[u][i]; }
+        for (int u = 0; u < WD; ++u)
+#pragma unroll
+            for (int i = 0; i < NO; ++i) { acc[i] += g[u][i] * x[u]; bs[i] += g[u][i]; }
+    }
+    for (; p < p_end; ++p) {                                   // ragged tail (< WD points)
+        const float xv = X[p * ldx + jc];
+#pragma unroll
+        for (int i = 0; i < NO; ++i) { const float gv = G[p * ldg + i]; acc[i] += gv * xv; bs[i] += gv; }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) part_w[((long long)blockIdx.x * 4 + i) * 256 + j] = acc[i];
@@ -360,7 +371,10 @@ int snr_weight_grad(const float* G, int64_t ldg, int n_out, const float* X, int6
         if (n_out > 4) return SNR_E_UNSUPPORTED;        /* 5..31 output rows: no such layer in the decoder */
         float* part_w = ws; float* part_b = ws + (long long)ns * 4 * 256;
         if (n_points == 0) ns = 0;
-        if (ns) wgrad_small_kernel<<<ns, 256, 0, st>>>(G, ldg, n_out, X, ldx, n_in, n_points, pps, part_w, part_b);
+        if (ns && n_out == 1) wgrad_small_kernel<1><<<ns, 256, 0, st>>>(G, ldg, X, ldx, n_in, n_points, pps, part_w, part_b);
+        else if (ns && n_out == 2) wgrad_small_kernel<2><<<ns, 256, 0, st>>>(G, ldg, X, ldx, n_in, n_points, pps, part_w, part_b);
+        else if (ns && n_out == 3) wgrad_small_kernel<3><<<ns, 256, 0, st>>>(G, ldg, X, ldx, n_in, n_points, pps, part_w, part_b);
+        else if (ns) wgrad_small_kernel<4><<<ns, 256, 0, st>>>(G, ldg, X, ldx, n_in, n_points, pps, part_w, part_b);
         wgrad_small_reduce_kernel<<<n_out, 1024, 0, st>>>(part_w, part_b, ns, n_out, n_in, dW, ld_dw, db);
     }
     return snr_check_launch_();
