@@ -463,14 +463,14 @@ def main():
     # ---- BASELINE config 3 through the driver: 64 objects sharded over the ranks, one all_gather at the end; the library's default
     # arithmetic, then the reference's
     n_it3 = 8
-    for p3, key in (("auto", "c3_sharded"), ("fp32", "c3_sharded_fp32")):
+    for p3, key in (("auto", "c3_sharded"), ("fp32", "c3_sharded_fp32"), (("fp32", "bf16x3"), "c3_sharded_fp32_forward_bf16x3_backward")):
         model.precision = p3
         dt3, rows3, n_mine = c3_leg(model, dev, rank, world, dist, clock, n_it3 if p3 == "auto" else 4)
         it3 = n_it3 if p3 == "auto" else 4
         extra[key] = {"objects": C3_OBJECTS, "objects_this_rank": n_mine, "iterations": it3, "seconds": dt3,
                       "ms_per_iteration": dt3 / it3 * 1e3, "object_iterations_per_s": C3_OBJECTS * it3 / dt3,
                       "rays_per_s_fwd_bwd_plus_depth_render": C3_OBJECTS * it3 * N_RAYS / dt3,
-                      "precision": "auto (bf16x3)" if p3 == "auto" else "fp32", "metric_rows_finite": bool(torch.isfinite(rows3).all()),
+                      "precision": "auto (bf16x3)" if p3 == "auto" else ("fp32" if p3 == "fp32" else "fp32 forward (the reference's values) + bf16x3 backward"), "metric_rows_finite": bool(torch.isfinite(rows3).all()),
                       "note": "strong scaling of BASELINE configs[2]: the 64 objects are fixed, each rank optimises its contiguous slice in one launch per "
                               "iteration; includes the per-object host set-up and the final all_gather of the metric rows (RCCL)"}
     model.precision = "auto"
