@@ -334,35 +334,39 @@ __global__ void __launch_bounds__(256) adamw_table_kernel(const AdamEntry* __res
 // texture code for the texture blocks) and the bias each z_j folds into (snr_render_args::latent_bias: b_next_j + W_next_j z_j), one launch.
 // w_lat (512, n_lat*256): row block 0 multiplies the shape code, row block 1 the texture code, column block j = layer j (transposed
 // nn.Linear weights, zero where a layer does not read that code); w_nxt (n_lat*256, n_lat*256) block diagonal, transposed likewise.
-// One workgroup per (object, latent layer), thread t = output unit t: every weight row is read with consecutive lanes on consecutive floats.
-__global__ void __launch_bounds__(256) latent_fwd_kernel(const float* __restrict__ sc, const float* __restrict__ tc, const float* __restrict__ w_lat,
-                                                         const float* __restrict__ b_lat, const float* __restrict__ w_nxt, const float* __restrict__ b_nxt,
-                                                         int sb, int n_lat, float* __restrict__ z, float* __restrict__ lb) {
-    __shared__ float code[256], zs[256];
-    const int b = blockIdx.x, j = blockIdx.y, t = threadIdx.x;
+// One workgroup per (object, latent layer), a thread per output unit and quarter of its sum: every weight row is read with consecutive lanes on
+// consecutive floats.
+__global__ void __launch_bounds__(1024) latent_fwd_kernel(const float* __restrict__ sc, const float* __restrict__ tc, const float* __restrict__ w_lat,
+                                                          const float* __restrict__ b_lat, const float* __restrict__ w_nxt, const float* __restrict__ b_nxt,
+                                                          int sb, int n_lat, float* __restrict__ z, float* __restrict__ lb) {
+    // 1024 threads: output unit t = tid & 255, the 256 terms of its sum in four quarters kq = tid >> 8 that meet in LDS (the kernel is a
+    // chain of load latencies: four times the threads, a quarter of the trips)
+    __shared__ float code[256], zs[256], quarter[4][256];
+    const int b = blockIdx.x, j = blockIdx.y, t = threadIdx.x & 255, kq = threadIdx.x >> 8;
     const long long ld = (long long)n_lat * 256;
-    code[t] = (j < sb ? sc : tc)[(long long)b * 256 + t];
+    if (kq == 0) code[t] = (j < sb ? sc : tc)[(long long)b * 256 + t];
     __syncthreads();
-    const float* w = w_lat + (long long)(j < sb ? 0 : 256) * ld + j * 256 + t;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < 256; k += 4) {
-        a0 = fmaf(code[k], w[(long long)k * ld], a0);           a1 = fmaf(code[k + 1], w[(long long)(k + 1) * ld], a1);
-        a2 = fmaf(code[k + 2], w[(long long)(k + 2) * ld], a2); a3 = fmaf(code[k + 3], w[(long long)(k + 3) * ld], a3);
+    auto dot64 = [&](const float* v, const float* w) {       // sum over k = 64 kq .. 64 kq + 63 of v[k] * w[k * ld]
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+        for (int k = 64 * kq; k < 64 * kq + 64; k += 4) {
+            a0 = fmaf(v[k], w[(long long)k * ld], a0);           a1 = fmaf(v[k + 1], w[(long long)(k + 1) * ld], a1);
+            a2 = fmaf(v[k + 2], w[(long long)(k + 2) * ld], a2); a3 = fmaf(v[k + 3], w[(long long)(k + 3) * ld], a3);
+        }
+        return (a0 + a1) + (a2 + a3);
+    };
+    quarter[kq][t] = dot64(code, w_lat + (long long)(j < sb ? 0 : 256) * ld + j * 256 + t);
+    __syncthreads();
+    if (kq == 0) {
+        const float zv = fmaxf(((quarter[0][t] + quarter[1][t]) + (quarter[2][t] + quarter[3][t])) + b_lat[j * 256 + t], 0.f);
+        z[((long long)b * n_lat + j) * 256 + t] = zv;
+        zs[t] = zv;
     }
-    const float zv = fmaxf(((a0 + a1) + (a2 + a3)) + b_lat[j * 256 + t], 0.f);
-    z[((long long)b * n_lat + j) * 256 + t] = zv;
     if (!lb) return;
-    zs[t] = zv;
     __syncthreads();
-    const float* wn = w_nxt + (long long)(j * 256) * ld + j * 256 + t;
-    a0 = a1 = a2 = a3 = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < 256; k += 4) {
-        a0 = fmaf(zs[k], wn[(long long)k * ld], a0);           a1 = fmaf(zs[k + 1], wn[(long long)(k + 1) * ld], a1);
-        a2 = fmaf(zs[k + 2], wn[(long long)(k + 2) * ld], a2); a3 = fmaf(zs[k + 3], wn[(long long)(k + 3) * ld], a3);
-    }
-    lb[((long long)b * n_lat + j) * 256 + t] = ((a0 + a1) + (a2 + a3)) + b_nxt[j * 256 + t];
+    quarter[kq][t] = dot64(zs, w_nxt + (long long)(j * 256) * ld + j * 256 + t);
+    __syncthreads();
+    if (kq == 0) lb[((long long)b * n_lat + j) * 256 + t] = ((quarter[0][t] + quarter[1][t]) + (quarter[2][t] + quarter[3][t])) + b_nxt[j * 256 + t];
 }
 // backward to the codes: d code[k] = sum over the layers that read this code and their units t of (d z_j[t] where z_j[t] > 0) * w_lat[k][j*256 + t].
 // One wave per code element (grid: objects x 2 codes x 64 workgroups of 4 waves), its lanes along the row of w_lat; fixed summation order.
@@ -496,7 +500,7 @@ int snr_latent_fwd(const float* shapecode, const float* texturecode, const float
     if (n_objects == 0 || n_lat == 0) return SNR_OK;
     if (n_objects < 0 || n_objects > 0x7fffffff || shape_blocks < 0 || texture_blocks < 0 || n_lat > 65535) return SNR_E_ARG;
     if (!w_lat || !b_lat || !z || (shape_blocks && !shapecode) || (texture_blocks && !texturecode) || (latent_bias && (!w_nxt || !b_nxt))) return SNR_E_ARG;
-    latent_fwd_kernel<<<dim3((unsigned)n_objects, (unsigned)n_lat), 256, 0, (hipStream_t)stream>>>(shapecode, texturecode, w_lat, b_lat, w_nxt, b_nxt,
+    latent_fwd_kernel<<<dim3((unsigned)n_objects, (unsigned)n_lat), 1024, 0, (hipStream_t)stream>>>(shapecode, texturecode, w_lat, b_lat, w_nxt, b_nxt,
                                                                                                 shape_blocks, n_lat, z, latent_bias);
     return snr_check_launch_();
 }
