@@ -28,9 +28,10 @@ def amd():
     return supnerf_amd
 
 
-@pytest.fixture(scope="module", params=["fp32", "auto"])
+@pytest.fixture(scope="module", params=["fp32", "auto", ("fp32", "auto")], ids=["fp32", "auto", "fp32fwd_bf16x3bwd"])
 def model(amd, dev, oracle_params, request):
-    """Every API test runs twice: exact fp32 MFMA kernels, and 'auto' (= split-bf16 wherever the shape allows it)."""
+    """Every API test runs three times: exact fp32 MFMA kernels, 'auto' (= split-bf16 wherever the shape allows it), and the pair
+    (exact-fp32 forward, split-bf16 backward on the ReLU bits that forward saved -- where the shape allows it)."""
     m = amd.CodeNeRF(shape_blocks=3, texture_blocks=1)
     m.load_state_dict(oracle_params, strict=True)
     m.precision = request.param
