@@ -31,6 +31,7 @@ namespace snr {
 // lane's point p = lane & 31 (both half-waves hold the same point).  Outputs sigma, r, g, b valid in
 // every lane.  All four waves of the workgroup must call it together (block-wide barriers inside).
 // -------------------------------------------------------------------------------------------
+template <bool STAGED>      // STAGED (the points decoder, which is what trains): activation dumps through LDS, whole cache lines per store
 __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const Layout& L, float* lds, long long gp /*clamped point id*/, bool live,
                                                      long long tile32, float x, float y, float z, float dx, float dy, float dz,
                                                      float& o_sigma, float& o_r, float& o_g, float& o_b) {
@@ -41,6 +42,8 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     const int n_relu = n_relu_layers(sb, tb);
     // a workgroup covers 4 wave tiles; the last one of a launch may own tiles past the end (buffers are sized for ceil(P/32) tiles)
     const bool tile_live = tile32 * 32 < io.n_points;
+    const int dump_rows = STAGED ? (int)((io.n_points - tile32 * 32) < 32 ? (io.n_points - tile32 * 32) : 32) : 0;       // rows of this wave's tile that exist
+    float* const dump_scr = lds + LDS_SCRATCH + wave * PE_WAVE;      // the wave's positional-encoding scratch, idle after the prologue
     const float* bias = lds + LDS_BIAS;            // staged in the prologue
     const float* heads = bias + L.n_mfma_layers * 256;   // sigma_w (256) | sigma_b | rgb2_w (384) | rgb2_b, as in the packed stream
     const float* lat = io.latent + (gp / io.points_per_obj) * (long long)L.n_lat * 256;
@@ -118,7 +121,8 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         if (lat_in_lds && la >= 0) epilogue<8, 8>(acc, in, true, lds + LDS_LAT + la * 256, h, mask);
         else epilogue<8, 8>(acc, in, true, la >= 0 ? lat + la * 256 : nullptr, h, mask);
         if (io.masks && tile_live) io.masks[(tile32 * n_relu + 0) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
-        if (io.act && live) dump_operand<8>(in, io.act + ((long long)0 * io.n_points + gp) * 256, h);
+        if constexpr (STAGED) { if (io.act && tile_live) dump_operand_staged<8>(in, io.act + ((long long)0 * io.n_points + tile32 * 32) * 256, dump_rows, dump_scr, lane); }
+        else if (io.act && live) dump_operand<8>(in, io.act + ((long long)0 * io.n_points + gp) * 256, h);
     }
 
     SNR32_STAMP(1);      // enc_xyz + its epilogue
@@ -145,7 +149,8 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         else epilogue<8, 8>(acc, in, relu, la >= 0 ? lat + la * 256 : nullptr, h, mask);
         if (relu && io.masks && tile_live)
             io.masks[(tile32 * n_relu + relu_slot(li, sb)) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
-        if (io.act && live) dump_operand<8>(in, io.act + ((long long)li * io.n_points + gp) * 256, h);
+        if constexpr (STAGED) { if (io.act && tile_live) dump_operand_staged<8>(in, io.act + ((long long)li * io.n_points + tile32 * 32) * 256, dump_rows, dump_scr, lane); }
+        else if (io.act && live) dump_operand<8>(in, io.act + ((long long)li * io.n_points + gp) * 256, h);
         if (li <= 6) SNR32_STAMP(1 + li);      // layer li + its epilogue (+ bias init of the next)
         if (li == li_encshape) {
             // density head: softplus(w_sigma . y + b)   (src/model_supnerf.py:257)
@@ -178,7 +183,8 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     SNR32_STAMP(9);      // rgb.0's chunks
     epilogue<4, 8>(acc, in, true, nullptr, h, mask);
     if (io.masks && tile_live) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mask[0], mask[1], 0u, 0u);
-    if (io.act && live) dump_operand<4>(in, io.act + ((long long)(li_last + 1) * io.n_points + gp) * 256, h);
+    if constexpr (STAGED) { if (io.act && tile_live) dump_operand_staged<4>(in, io.act + ((long long)(li_last + 1) * io.n_points + tile32 * 32) * 256, dump_rows, dump_scr, lane); }
+    else if (io.act && live) dump_operand<4>(in, io.act + ((long long)(li_last + 1) * io.n_points + gp) * 256, h);
     {
         const float* w2 = heads + (L.rgb2_w - L.sigma_w);
         float pr = 0.f, pg = 0.f, pb = 0.f;
@@ -231,7 +237,7 @@ decoder_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const 
     unsigned long long st_c0 = 0, st_r0 = 0;
     if (tid == 0) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c0), "=s"(st_r0) :: "memory");
 #endif
-    decoder_forward_tile(io, L, lds, gp, live, tile128 * 4 + wave, x, y, z, dx, dy, dz, sg, cr, cg, cb);
+    decoder_forward_tile<MODE == 0>(io, L, lds, gp, live, tile128 * 4 + wave, x, y, z, dx, dy, dz, sg, cr, cg, cb);
 #ifdef SNR_STAMPS
     if (tid == 0 && io.sigmas) {
         unsigned long long c1, r1;

@@ -121,6 +121,10 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     // wave tiles past the end of the launch (last workgroup): read tile 0's ReLU bits (results are discarded), store nothing
     const bool tile_live = tile32 * 32 < io.n_points;
     const long long tile32m = tile_live ? tile32 : 0;
+    // training dumps of the points decoder go through the wave's positional-encoding scratch (idle until the encoding gradient at the
+    // kernel's end): whole cache lines per store, see dump_operand_staged
+    const int dump_rows = (int)((io.n_points - tile32m * 32) < 32 ? (io.n_points - tile32m * 32) : 32);
+    float* const dump_scr = lds + LDS_SCRATCH + wave * PE_WAVE;
 
     // ---- start the transposed weight stream
     Pipe pipe;
@@ -218,7 +222,8 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
                 }
             }
     }
-    if (io.gdump && live) dump_operand<4>(in, io.gdump + ((long long)(li_last + 1) * io.n_points + gp) * 256, h);
+    if constexpr (MODE == 0) { if (io.gdump && tile_live) dump_operand_staged<4>(in, io.gdump + ((long long)(li_last + 1) * io.n_points + tile32 * 32) * 256, dump_rows, dump_scr, lane); }
+    else if (io.gdump && live) dump_operand<4>(in, io.gdump + ((long long)(li_last + 1) * io.n_points + gp) * 256, h);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -242,7 +247,8 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
         // the ReLU bits the NEXT boundary applies (layer li-1's, enc_xyz's after the loop) are requested now, a whole layer ahead:
         // a load at the boundary itself would expose a memory round trip with the matrix pipe idle
         mk_next = io.masks[(tile32m * n_relu + (li - 1 >= 1 ? relu_slot(li - 1, sb) : 0)   /* (enc_shape: a valid slot, not applied) */) * 64 + lane];
-        if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)li * io.n_points + gp) * 256, h);
+        if constexpr (MODE == 0) { if (io.gdump && tile_live) dump_operand_staged<8>(in, io.gdump + ((long long)li * io.n_points + tile32 * 32) * 256, dump_rows, dump_scr, lane); }
+    else if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)li * io.n_points + gp) * 256, h);
         const int rows_after = rows_of(li - 1);
         if (is_view) {      // two instances of the layer body, each with compile-time chunk heights and tile count: a run-time "ninth tile?" /
                             // "how many DMA pieces?" inside every chunk costs scalar branches that nothing overlaps (one wave per SIMD)
@@ -277,7 +283,8 @@ decoder_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const floa
     SNR32_BSTAMP(11);
     // ---- enc_xyz^T : 256 -> 64 positional-encoding features
     masked_to_operand<8>(acc, in, true, mk_next, nullptr, 0.f, h);
-    if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)0 * io.n_points + gp) * 256, h);
+    if constexpr (MODE == 0) { if (io.gdump && tile_live) dump_operand_staged<8>(in, io.gdump + ((long long)0 * io.n_points + tile32 * 32) * 256, dump_rows, dump_scr, lane); }
+    else if (io.gdump && live) dump_operand<8>(in, io.gdump + ((long long)0 * io.n_points + gp) * 256, h);
     step<2, 9, true>(acc, in[0], pipe, lds, 64, tid);
     step<2, 9>(acc, in[1], pipe, lds, 64, tid);
     step<2, 9>(acc, in[2], pipe, lds, 64, tid);

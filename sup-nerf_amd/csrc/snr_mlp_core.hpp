@@ -190,6 +190,30 @@ __device__ __forceinline__ void dump_operand(const float (&in)[9][16], float* __
         }
 }
 
+// The same dump through the wave's (idle) positional-encoding scratch in LDS: a tile (32 points x 32 features) is written as the lanes hold
+// it and read back so that eight consecutive lanes cover one point's 128 bytes -- every store instruction then writes 8 whole cache
+// lines instead of 32 quarter lines.  Called by every lane of the wave (rows past the end are skipped per lane); `rows` = the dump rows of
+// the wave's 32 points (row r = point tile_first + r), `n_rows` = how many of them exist.  LDS operations of one wave execute in order.
+constexpr int DUMP_ROW = 36;      // 32 floats + 4 of padding: conflict-free 16-byte writes (row = lane & 31) and reads (row = lane >> 3)
+template <int NT>
+__device__ __forceinline__ void dump_operand_staged(const float (&in)[9][16], float* __restrict__ rows, int n_rows, float* scr, int lane) {
+    const int p = lane & 31, h = lane >> 5, rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = {in[t][4 * j], in[t][4 * j + 1], in[t][4 * j + 2], in[t][4 * j + 3]};
+            *reinterpret_cast<f32x4*>(scr + p * DUMP_ROW + 8 * j + 4 * h) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + rr;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(scr + r * DUMP_ROW + 4 * cc);
+            if (r < n_rows) *reinterpret_cast<f32x4*>(rows + (long long)r * 256 + 32 * t + 4 * cc) = v;
+        }
+    }
+}
+
 struct BwdIO {
     const float* packed;
     const float* latent;
