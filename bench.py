@@ -50,7 +50,7 @@ FLOP_PER_RAY = 57.56e6          # forward, S = 64; optim
 PEAK_TFLOPS = {"fp32": 157.3,    # MI355X_MICROARCH.md "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f32
                "bf16x3": 2500.0}  # dense BF16 MFMA peak; the split-bf16 path issues 3 MFMAs per algorithmic product
 ISSUE_FACTOR = {"fp32": 1.0, "bf16x3": 3.0}
-DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)"}
+DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 = split 16-bit pieces (fp32 operands as hi + lo: fp16 pieces in the forward chain, bf16 pieces in the backward chain and the weight-gradient products; 3 MFMAs per product, fp32 accumulate)"}
 FWD_KERNEL = {"fp32": "decoder_fwd_kernel<1>", "bf16x3": "bf16_fwd_kernel<1,false,true>"}
 BWD_KERNEL = {"fp32": "decoder_bwd_kernel<1>", "bf16x3": "bf16_bwd_kernel<1>"}
 N_RAYS, N_SAMPLES, IM_SZ = 4096, 64, 64
@@ -488,10 +488,10 @@ def main():
     batch = {k: v.to(dev) for k, v in batch.items()}
     hp_t = dict(lr_schedule=[dict(lr=1e-4, interval=40000), dict(lr=1e-4, interval=40000)])
     extra["training_step"] = {}
-    DTYPE_T = dict(DTYPE, auto="f32 forward chain (exact) + bf16x3 backward chain and weight-gradient products (fp32 accumulate)")
-    for p_t in ("auto", "fp32", "bf16x3"):
+    DTYPE_T = dict(DTYPE, auto=DTYPE["bf16x3"] + " -- what 'auto' trains in", fp32_fwd="f32 forward chain (exact) + split backward chain and weight-gradient products")
+    for p_t in ("auto", "fp32", "fp32_fwd"):
         m_t = A.CodeNeRF(3, 1); m_t.load_state_dict(w["params"]); m_t = m_t.to(dev); m_t.train_decoder_weights = True
-        m_t.precision = p_t
+        m_t.precision = ("fp32", "bf16x3", "bf16x3") if p_t == "fp32_fwd" else p_t
         codes = T.CodeTables(64, 256, seed=1).to(dev)
         bucket = T.GradBucket(list(m_t.parameters()) + list(codes.parameters()), row_sparse=list(codes.parameters()))
         opt_t = T.make_optimizer(m_t, codes, hp_t)
@@ -501,9 +501,10 @@ def main():
                                        "samples": N_SAMPLES, "steps": n_t, "dtype": DTYPE_T[p_t], "model_precision": m_t.precision}
         del m_t, codes, bucket, opt_t
     extra["training_step"]["note"] = ("trainer.train_step: forward + backward incl. every decoder weight gradient + one all-reduce of the flat gradient bucket + AdamW (one launch); "
-                                      "`auto` = the library default in training mode: exact-fp32 forward chain + split-bf16 backward chain and weight-gradient products -- a 60-step run ends where the "
-                                      "reference's own fp32 arithmetic ends (the forward chain decides that, not what runs behind it); `fp32` = exact fp32 throughout, the reference's arithmetic product for "
-                                      "product; `bf16x3` = split-bf16 throughout, opt-in (tests/test_driver_gpu.py::test_training_outcome_fp32_and_bf16x3_track_the_oracle has the evidence for all three)")
+                                      "`auto` = the library default in training mode = the split kernels throughout (fp16 pieces in the forward chain: a 60-step run ends where the "
+                                      "reference's own fp32 arithmetic ends -- the forward chain's arithmetic decides that, and two fp16 pieces carry 22 bits); `fp32` = exact fp32 throughout, the "
+                                      "reference's arithmetic product for product; `fp32_fwd` = the exact-fp32 forward chain with the split backward chain and products "
+                                      "(tests/test_driver_gpu.py::test_training_outcome_fp32_and_bf16x3_track_the_oracle has the evidence)")
     del batch
 
     log("HBM-bound kernels")

@@ -215,6 +215,31 @@ __device__ __forceinline__ void pin(XOp& o) { asm volatile("" : "+v"(o.hi), "+v"
 // of the forward weight image).  Why: in MFMA-dense loops on random data the chip holds a ~17 % higher clock on this shape (2.15-2.29 vs
 // 1.82-1.96 GHz in-kernel, tools/_diag/shape_bench.hip) at 11 % more cycles for the same layer body (twice the MFMA instructions, each
 // leaving 8 instead of 24 cycles of issue shadow): the isolated layer chain ran 7-8 % faster in wall time.
+// Element type of the FORWARD chain's split operands (activations, forward weight stream): IEEE half.  Two fp16 pieces keep 22 bits of an
+// fp32 operand where two bf16 pieces keep 16 (tools/_diag/split_accuracy.py: operand error of a product 3e-7 against 4.5e-6 relative,
+// the level of fp32 accumulation itself), at the same three MFMAs per product and +1.4 % of kernel time (0.4929 against 0.4862 ms):
+// rendered colours 6e-8 from the exact-fp32 kernel's instead of 2.2e-7 -- and a 60-step training run ends where the reference's own fp32
+// arithmetic ends (loss curve 2.1e-6 / weights 1.21e-3 of their movement from the float64 run; bf16 pieces: 3.9e-5 / 1.1e-2, because a
+// pre-activation that lands on the other side of zero flips a ReLU).  Activations are clamped to the fp16 range (+-65504) in the same
+// v_med3 that applies the ReLU; what lies below 6e-8 in magnitude is lost (absolute, harmless beside biases of order 0.1).  The backward
+// chain and the weight-gradient products carry GRADIENTS, whose magnitudes need bf16's exponent range: they stay on bf16 pieces.
+// -DSNR_FWD_BF16 builds the bf16 forward of rounds 1-2 (A/B timing).
+#ifndef SNR_FWD_BF16
+#define SNR_FWD_F16 1
+typedef _Float16 fwd_t;
+#define SNR_MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
+#else
+typedef __bf16 fwd_t;
+#define SNR_MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
+#endif
+typedef fwd_t fwdx8 __attribute__((ext_vector_type(8)));
+struct FOp { fwdx8 hi, lo; };
+__device__ __forceinline__ void split_store_f(float v, FOp& o, int j) {
+    const fwd_t hi = (fwd_t)v;
+    o.hi[j] = hi;
+    o.lo[j] = (fwd_t)(v - (float)hi);
+}
+__device__ __forceinline__ void pin(FOp& o) { asm volatile("" : "+v"(o.hi), "+v"(o.lo)); }
 #ifdef SNR_STAMPS
 #define SNR_STAMP(i) do { if (lane == 0 && tile32 * 32 < io.n_points) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     reinterpret_cast<unsigned long long*>(io.sigmas)[tile32 * 16 + (i)] = t_; } } while (0)
@@ -241,40 +266,40 @@ __device__ __forceinline__ void pin(XOp& o) { asm volatile("" : "+v"(o.hi), "+v"
         if (SNR_IL16_VALU) __builtin_amdgcn_sched_group_barrier(0x002, SNR_IL16_VALU, 0);\
     }
 
-struct Frag16 { bf16x8 hi[4], lo[4]; };        // A fragments of four 16-row tiles (one group): 8 KiB of the chunk, contiguous
+struct Frag16 { fwdx8 hi[4], lo[4]; };        // A fragments of four 16-row tiles (one group): 8 KiB of the chunk, contiguous
 __device__ __forceinline__ void load16(Frag16& f, const char* wq /* chunk + group offset + lane*16 */) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        f.hi[t] = *reinterpret_cast<const bf16x8*>(wq + (2 * t) * 1024);
-        f.lo[t] = *reinterpret_cast<const bf16x8*>(wq + (2 * t + 1) * 1024);
+        f.hi[t] = *reinterpret_cast<const fwdx8*>(wq + (2 * t) * 1024);
+        f.lo[t] = *reinterpret_cast<const fwdx8*>(wq + (2 * t + 1) * 1024);
     }
 }
 // 24 MFMAs of one group: tiles T0 .. T0+3, both column blocks, three split products each.  TO_P: the layer's last step, the finished
 // sums go to the (dead) previous accumulator set.
 template <int T0, bool TO_P>
-__device__ __forceinline__ void mma16(f32x4 (&accC)[2][16], f32x4 (&accP)[2][16], const XOp (&x)[2], const Frag16& f) {
+__device__ __forceinline__ void mma16(f32x4 (&accC)[2][16], f32x4 (&accP)[2][16], const FOp (&x)[2], const Frag16& f) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.hi[t], x[c].hi, accC[c][T0 + t], 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.hi[t], x[c].lo, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.lo[t], x[c].hi, a, 0, 0, 0);
+            f32x4 a = SNR_MFMA16(f.hi[t], x[c].hi, accC[c][T0 + t], 0, 0, 0);
+            a = SNR_MFMA16(f.hi[t], x[c].lo, a, 0, 0, 0);
+            a = SNR_MFMA16(f.lo[t], x[c].hi, a, 0, 0, 0);
             if (TO_P) accP[c][T0 + t] = a; else accC[c][T0 + t] = a;
         }
 }
 // one whole k32-step of NT16 tiles straight from a chunk (no fragment pipelining): enc_xyz and enc_viewdir's direction step
 template <int NT16>
-__device__ __forceinline__ void step_mma16(f32x4 (&acc)[2][16], const XOp (&x)[2], const char* ws /* chunk + step offset + lane*16 */) {
+__device__ __forceinline__ void step_mma16(f32x4 (&acc)[2][16], const FOp (&x)[2], const char* ws /* chunk + step offset + lane*16 */) {
 #pragma unroll
     for (int t = 0; t < NT16; ++t) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + (2 * t) * 1024);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ws + (2 * t + 1) * 1024);
+        const fwdx8 ah = *reinterpret_cast<const fwdx8*>(ws + (2 * t) * 1024);
+        const fwdx8 al = *reinterpret_cast<const fwdx8*>(ws + (2 * t + 1) * 1024);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, x[c].hi, acc[c][t], 0, 0, 0);
-            acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, x[c].lo, acc[c][t], 0, 0, 0);
-            acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, x[c].hi, acc[c][t], 0, 0, 0);
+            acc[c][t] = SNR_MFMA16(ah, x[c].hi, acc[c][t], 0, 0, 0);
+            acc[c][t] = SNR_MFMA16(ah, x[c].lo, acc[c][t], 0, 0, 0);
+            acc[c][t] = SNR_MFMA16(al, x[c].hi, acc[c][t], 0, 0, 0);
         }
     }
 }
@@ -289,22 +314,47 @@ struct Epi16 {
 // four values (features 16 T + 4 g .. +3 of point 16 c + n) -> elements 4*HALF .. +3 of the operand step; ReLU bits shifted into `mbits`
 // in arrival order (T ascending, e ascending; see store_masks16)
 template <int HALF, bool MASKS, bool ZADD, bool DUMP>
-__device__ __forceinline__ void epi16(const f32x4& acc, XOp& o, const Epi16& c, int T, int cblk, int g, uint32_t& mbits) {
+__device__ __forceinline__ void epi16(const f32x4& acc, FOp& o, const Epi16& c, int T, int cblk, int g, uint32_t& mbits) {
 #ifdef SNR_EXP_NOEPI
     return;
 #endif
     f32x4 z;
     if (ZADD) z = *reinterpret_cast<const f32x4*>(c.zl + 16 * T + 4 * g);
     f32x4 dv;
+#ifdef SNR_FWD_F16
+    // ReLU and the clamp to the fp16 range in one v_med3 (floor = -65504 for the layer without an activation); the pieces are packed two
+    // at a time with v_cvt_pkrtz_f16_f32 (the remainder x - hi is exact in fp32 whichever way hi was rounded)
+    const float lo_bound = c.floor == 0 ? 0.f : -65504.f;
+    float xv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = acc[e];           // bias already inside
+        if (MASKS) mbits = __builtin_amdgcn_alignbit(mbits, __builtin_bit_cast(uint32_t, a), 31);
+        const float y = __builtin_amdgcn_fmed3f(a, lo_bound, 65504.f);
+        xv[e] = ZADD ? y + z[e] : y;
+        if (DUMP) dv[e] = xv[e];
+    }
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    uint32_t (&hw)[4] = reinterpret_cast<uint32_t (&)[4]>(o.hi);
+    uint32_t (&lw)[4] = reinterpret_cast<uint32_t (&)[4]>(o.lo);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const h2 hp = __builtin_amdgcn_cvt_pkrtz(xv[2 * k], xv[2 * k + 1]);
+        const h2 lp = __builtin_amdgcn_cvt_pkrtz(xv[2 * k] - (float)hp[0], xv[2 * k + 1] - (float)hp[1]);
+        hw[2 * HALF + k] = __builtin_bit_cast(uint32_t, hp);
+        lw[2 * HALF + k] = __builtin_bit_cast(uint32_t, lp);
+    }
+#else
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float a = acc[e];           // bias already inside
         if (MASKS) mbits = __builtin_amdgcn_alignbit(mbits, __builtin_bit_cast(uint32_t, a), 31);
         const float y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, a), c.floor));
         const float xv = ZADD ? y + z[e] : y;
-        split_store(xv, o, 4 * HALF + e);
+        split_store_f(xv, o, 4 * HALF + e);
         if (DUMP) dv[e] = xv;
     }
+#endif
     if (DUMP) { if (c.dump[cblk]) *reinterpret_cast<f32x4*>(c.dump[cblk] + 16 * T) = dv; }
     if (HALF == 1) pin(o);
     if (MASKS) asm volatile("" : "+v"(mbits));
@@ -332,7 +382,7 @@ __device__ __forceinline__ void layer16(f32x4 (&accP)[2][16], Ring& ring, char* 
         const f32x4 b = *reinterpret_cast<const f32x4*>(c.bias + 16 * t + 4 * g);
         accC[0][t] = b; accC[1][t] = b;
     }
-    XOp xc[2], xn[2];
+    FOp xc[2], xn[2];
     epi16<0, MASKS, ZADD, DUMP>(accP[0][0], xc[0], c, 0, 0, g, mw[0]); epi16<1, MASKS, ZADD, DUMP>(accP[0][1], xc[0], c, 1, 0, g, mw[0]);
     epi16<0, MASKS, ZADD, DUMP>(accP[1][0], xc[1], c, 0, 1, g, mw[2]); epi16<1, MASKS, ZADD, DUMP>(accP[1][1], xc[1], c, 1, 1, g, mw[2]);
     Frag16 fa, fb;
@@ -472,7 +522,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     // to the wave: LDS operations of one wave execute in order); the operand steps then gather, for lane (n, gq), the features
     // 32 s + 16 (j >> 2) + 4 gq + (j & 3) of the points 16 c + n.
     const int n16 = lane & 15, gq = lane >> 4;
-    XOp x0[2][2];                                     // enc_xyz: [k32-step][column block]
+    FOp x0[2][2];                                     // enc_xyz: [k32-step][column block]
     char* xdir = lds + OFF_XDIR + wave * 4096 + lane * 16;
     {
         float* scw = reinterpret_cast<float*>(lds + OFF_PE) + (wave * 32) * PE_ROWF;
@@ -499,7 +549,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) split_store(pv[s][c][j], x0[s][c], j);
+                    for (int j = 0; j < 8; ++j) split_store_f(pv[s][c][j], x0[s][c], j);
         }
 #pragma unroll 1
         for (int i = 0; i < 6; ++i) {
@@ -521,11 +571,11 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {      // the direction step of enc_viewdir, parked in LDS until that layer: [column block][plane][lane] x 16 B
-            XOp d;
+            FOp d;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) split_store(dvv[c][j], d, j);
-            *reinterpret_cast<bf16x8*>(xdir + c * 2048) = d.hi;
-            *reinterpret_cast<bf16x8*>(xdir + c * 2048 + 1024) = d.lo;
+            for (int j = 0; j < 8; ++j) split_store_f(dvv[c][j], d, j);
+            *reinterpret_cast<fwdx8*>(xdir + c * 2048) = d.hi;
+            *reinterpret_cast<fwdx8*>(xdir + c * 2048 + 1024) = d.lo;
         }
     }
 
@@ -584,9 +634,9 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         const char* w = ring_acquire(ring, lds) + ln * 16;
         ring_pieces<0, 8>(ring, ln * 16u + 4096u);
         const char* xd = lds + OFF_XDIR + wave * 4096 + ln * 16;
-        XOp d[2];
-        d[0].hi = *reinterpret_cast<const bf16x8*>(xd);        d[0].lo = *reinterpret_cast<const bf16x8*>(xd + 1024);
-        d[1].hi = *reinterpret_cast<const bf16x8*>(xd + 2048); d[1].lo = *reinterpret_cast<const bf16x8*>(xd + 3072);
+        FOp d[2];
+        d[0].hi = *reinterpret_cast<const fwdx8*>(xd);        d[0].lo = *reinterpret_cast<const fwdx8*>(xd + 1024);
+        d[1].hi = *reinterpret_cast<const fwdx8*>(xd + 2048); d[1].lo = *reinterpret_cast<const fwdx8*>(xd + 3072);
         step_mma16<16>(accA, d, w);
     };
 #pragma unroll 1
@@ -1127,11 +1177,18 @@ __global__ void pack_bf16_kernel(const float* __restrict__ Wt, int n_out, int k_
             const int k = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
             if (row < k_in && k < n_out) v = Wt[(long long)k * k_in + row];
         }
-        const __bf16 hi = (__bf16)v;
-        const __bf16 lo = (__bf16)(v - (float)hi);
-        const long long base = (((long long)s * n_tiles + tile) * 2) * 512;      // bf16 elements; plane stride 512
-        dst[base + lane * 8 + j] = hi;
-        dst[base + 512 + lane * 8 + j] = lo;
+        const long long base = (((long long)s * n_tiles + tile) * 2) * 512;      // 16-bit elements; plane stride 512
+        if (!transpose) {                                // the forward stream in the forward chain's element type
+            const fwd_t hi = (fwd_t)v;
+            const fwd_t lo = (fwd_t)(v - (float)hi);
+            reinterpret_cast<fwd_t*>(dst)[base + lane * 8 + j] = hi;
+            reinterpret_cast<fwd_t*>(dst)[base + 512 + lane * 8 + j] = lo;
+        } else {
+            const __bf16 hi = (__bf16)v;
+            const __bf16 lo = (__bf16)(v - (float)hi);
+            dst[base + lane * 8 + j] = hi;
+            dst[base + 512 + lane * 8 + j] = lo;
+        }
     }
 }
 

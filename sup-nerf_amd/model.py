@@ -49,7 +49,7 @@ class _DecoderBase(nn.Module):
         self._packed = None
         self._packed_key = None
         # arithmetic of the per-point GEMMs: "fp32" (exact), "bf16x3" (split-bf16) or "auto" (render / optimise: bf16x3 where the shape
-        # allows it; training mode: exact-fp32 forward chain, split-bf16 backward chain and weight-gradient products, see forward)
+        # allows it; training mode: the same split kernels, see forward)
         self.precision = "auto"
         # False (optimise / inference, the default): the DECODER is a constant -- codes and poses receive gradients, no decoder weight does
         # (neither the per-point layers nor the per-object latent layers).  That is what the reference's optimisers use: their AdamW
@@ -162,17 +162,19 @@ class _DecoderBase(nn.Module):
             w = [p for p in self._per_point_params().values()]
             # ``precision`` decides the arithmetic of the step.  Evidence (60 AdamW steps against the same steps on the CPU oracle in float64,
             # tests/test_driver_gpu.py::test_training_outcome_fp32_and_bf16x3_track_the_oracle; all the combinations:
-            # tools/_diag/experiments/README.md): WHERE A RUN ENDS UP IS DECIDED BY THE FORWARD CHAIN.  With the exact-fp32 forward a run
-            # ends as far from the float64 run as the reference's own fp32 arithmetic does (loss curve 1.4e-6 - 2.2e-6 against the fp32
-            # oracle's 1.3e-6, weights 1.21e-3 of their movement against 1.21e-3) whether the backward chain and the products dW = G^T X run in
-            # fp32 or in split-bf16 (2^-17 per product, fp32 accumulation; the backward applies the ReLU pattern the forward SAVED, so it
-            # has nothing to flip); with the split-bf16 forward it ends 27x / 8x further (3.9e-5 - 4.1e-5, 1.1e-2: a pre-activation that
-            # lands on the other side of zero flips a ReLU and changes the function being differentiated) whatever runs behind it.  So
-            #   "auto"   = exact-fp32 forward chain + split-bf16 backward chain and products: the reference's outcome at 0.62 of the time,
+            # tools/_diag/experiments/README.md): WHERE A RUN ENDS UP IS DECIDED BY THE FORWARD CHAIN's arithmetic -- a pre-activation that
+            # lands on the other side of zero flips a ReLU and changes the function being differentiated; the backward chain applies the
+            # pattern the forward SAVED and has nothing to flip, and the products dW = G^T X do not care either.  With the exact-fp32
+            # forward a run ends as far from the float64 run as the reference's own fp32 arithmetic does (loss curve 1.4e-6 - 2.2e-6 against
+            # the fp32 oracle's 1.3e-6, weights 1.21e-3 of their movement against 1.21e-3) whatever runs behind it; with a forward on two
+            # BF16 pieces per operand (rounds 1-2, 2^-17 per product) it ended 27x / 8x further (3.9e-5, 1.1e-2); with the forward on two
+            # FP16 pieces (round 3, 2^-22 per product: the level of fp32 accumulation) it ends at the floor again: 2.1e-6 / 1.21e-3.  So
+            #   "auto"   = the split kernels throughout (fp16 pieces forward, bf16 pieces backward and in the products): the reference's
+            #              outcome at 0.45 of the exact step's time; exact fp32 where the split kernels do not take the shape,
             #   "fp32"   = exact fp32 throughout (the reference's arithmetic, product for product),
-            #   "bf16x3" = split-bf16 throughout, the caller's explicit choice (2.2x faster than "fp32");
-            #   a tuple (forward chain, backward chain, products) picks each piece.
-            prec = ("fp32", "auto", "bf16x3") if self.precision in (None, "auto") else self.precision
+            #   "bf16x3" = the split kernels, insisting (raises where unsupported);
+            #   a tuple (forward chain, backward chain[, products]) picks each piece.
+            prec = ("auto", "auto", "bf16x3") if self.precision in (None, "auto") else self.precision
             sig, rgb = ops.DecoderPointsTrain.apply(xyz.reshape(-1, 3), viewdir.reshape(-1, 3), lat, self.shape_blocks,
                                                     self.texture_blocks, prec, *w)
             return sig.view(*lead, 1), rgb.view(*lead, 3)

@@ -245,7 +245,7 @@ def c5_inputs():
     return dict(batch=batch, sc=torch.randn(B, 256, generator=g) * 0.3, tc=torch.randn(B, 256, generator=g) * 0.3)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "auto", "bf16x3"])      # auto = exact-fp32 forward chain + split-bf16 backward chain and weight-gradient products
+@pytest.mark.parametrize("precision", ["fp32", "auto", "bf16x3"])      # auto = the split kernels where the shape allows (here it does)
 def test_config5_training_step_full_size(amd, dev, oracle_params, c5_inputs, precision):
     """trainer.nerf_losses + backward on the HIP training path at BASELINE config 5's per-GPU size against the oracle's autograd: the NeRF
     half of ParallelModel.forward (src/trainer_unified_nuscenes.py:117-148) + loss_total.backward(), every decoder weight gradient and

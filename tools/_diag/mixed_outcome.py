@@ -42,6 +42,6 @@ c64, w64 = oracle_run(torch.float64); c32, w32 = oracle_run(torch.float32)
 init = {k: v.double() for k, v in oracle_params.items()}
 wd = lambda w: max(float((w[k] - w64[k]).norm()) / (float((w64[k] - init[k]).norm()) + 1e-12) for k in w64)
 print(f"fp32 oracle floor: loss curve {np.abs(c32 - c64).max():.2e}, weights {wd(w32):.2e}")
-for precision in (("fp32", "fp32", "fp32"), ("fp32", "fp32", "bf16x3"), ("fp32", "bf16x3", "bf16x3"), ("fp32", "bf16x3", "fp32"), ("bf16x3", "fp32", "fp32"), ("bf16x3", "bf16x3", "bf16x3")):
+for precision in [tuple(a.split(",")) for a in sys.argv[1:]] or (("fp32", "fp32", "fp32"), ("fp32", "fp32", "bf16x3"), ("fp32", "bf16x3", "bf16x3"), ("fp32", "bf16x3", "fp32"), ("bf16x3", "fp32", "fp32"), ("bf16x3", "bf16x3", "bf16x3")):
     c, w = gpu_run(precision)
     print(f"forward chain {precision[0]:7s} backward chain {precision[1]:7s} products {precision[2]:7s}: loss curve vs float64 {np.abs(c - c64).max():.2e}, final weights {wd(w):.2e}", flush=True)
