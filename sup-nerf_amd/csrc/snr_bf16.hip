@@ -1179,6 +1179,9 @@ __global__ void pack_bf16_kernel(const float* __restrict__ Wt, int n_out, int k_
         }
         const long long base = (((long long)s * n_tiles + tile) * 2) * 512;      // 16-bit elements; plane stride 512
         if (!transpose) {                                // the forward stream in the forward chain's element type
+#ifdef SNR_FWD_F16
+            v = fminf(fmaxf(v, -65504.f), 65504.f);      // (a weight beyond the fp16 range saturates instead of becoming an infinity)
+#endif
             const fwd_t hi = (fwd_t)v;
             const fwd_t lo = (fwd_t)(v - (float)hi);
             reinterpret_cast<fwd_t*>(dst)[base + lane * 8 + j] = hi;

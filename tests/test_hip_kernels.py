@@ -370,3 +370,28 @@ def test_pe_points_layout(amd, dev, P):
     assert out.shape == (P, 96)
     assert float((out - want).abs().max()) < 5e-7            # (the kernels' sin / cos: 9e-8 of float64, the CPU's likewise)
     assert torch.equal(out[:, :3], xyz) and torch.equal(out[:, 64:67], vd) and float(out[:, 63].abs().max()) == 0.0 and float(out[:, 91:].abs().max()) == 0.0
+
+
+def test_split_forward_saturates_beyond_the_fp16_range(amd, dev, oracle_params):
+    """The split kernels' forward chain carries every operand as two fp16 pieces (22 bits; the backward chain keeps bf16 pieces for the
+    gradients' range).  Activations are clamped to +-65504 in the ReLU's v_med3 and weights at packing time, so a decoder whose
+    activations leave the fp16 range SATURATES -- finite outputs, not infinities or NaNs -- while activations of ordinary size (here up to
+    a few hundred) are carried to fp32-accumulation accuracy.  The exact-fp32 kernels are the reference in both cases."""
+    g = torch.Generator().manual_seed(3)
+    P = 4096
+    xyz = (torch.rand(P, 3, generator=g) - 0.5).to(dev)
+    vd = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
+    lat = (torch.rand(1, 4, 256, generator=g) * 0.3).to(dev)
+    for scale, expect_close in ((100.0, True), (3.0e5, False)):
+        params = {k: v.clone() for k, v in oracle_params.items()}
+        params["encoding_xyz.0.weight"] *= scale                       # first-layer activations of order scale
+        params["shape_layer_1.0.weight"] /= scale                      # ... brought back by the next layer
+        m = amd.CodeNeRF(3, 1); m.load_state_dict(params); m = m.to(dev)
+        pk = m.packed_weights()
+        out = {prec: amd.ops.decoder_fwd(xyz, vd, lat, pk, 3, 1, precision=prec)[:2] for prec in ("fp32", "bf16x3")}
+        for t in out["bf16x3"]:
+            assert bool(torch.isfinite(t).all())
+        err = max(float((a - b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(out["bf16x3"], out["fp32"]))
+        print(f"[split forward, first-layer activations x {scale:g}] max relative difference from the fp32 kernels {err:.2e}")
+        if expect_close:
+            assert err < 2e-5, err
