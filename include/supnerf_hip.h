@@ -56,9 +56,11 @@ enum {
 enum { SNR_Z_SHARED = 0 /* (S,) */, SNR_Z_PER_OBJECT = 1 /* (B,S) */, SNR_Z_PER_RAY = 2 /* (N,S) */, SNR_Z_BOX = 3 /* none: box bounds */ };
 
 /* arithmetic of the decoder GEMMs.  SNR_FP32: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain.
- * SNR_BF16X3: every operand split into bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate (relative operand
- * error ~2^-17; 5x less matrix time).  SNR_BF16X3 needs shape_blocks + texture_blocks <= 4 and whole 32-point tiles per
- * object; snr_precision_supported() tells. */
+ * SNR_BF16X3: every fp32 operand split into two 16-bit pieces hi + lo, three 16-bit MFMAs per product, fp32 accumulate (5x less
+ * matrix time).  The FORWARD launches carry fp16 pieces (22 bits per operand, relative error ~2^-22 per product; activations are
+ * clamped to +-65504, weights likewise at packing time), the BACKWARD launches and snr_weight_grad bf16 pieces (~2^-17: gradients need
+ * the exponent range).  Needs shape_blocks + texture_blocks <= 4 and whole 32-point tiles per object;
+ * snr_precision_supported() tells. */
 enum { SNR_FP32 = 0, SNR_BF16X3 = 1 };
 int snr_precision_supported(int precision, int shape_blocks, int texture_blocks, int64_t points_per_obj);
 

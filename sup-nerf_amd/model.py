@@ -48,7 +48,7 @@ class _DecoderBase(nn.Module):
         self.rgb = nn.Sequential(nn.Linear(W, W // 2), nn.ReLU(), nn.Linear(W // 2, 3))
         self._packed = None
         self._packed_key = None
-        # arithmetic of the per-point GEMMs: "fp32" (exact), "bf16x3" (split-bf16) or "auto" (render / optimise: bf16x3 where the shape
+        # arithmetic of the per-point GEMMs: "fp32" (exact), "bf16x3" (split 16-bit pieces: fp16 forward, bf16 backward) or "auto" (render / optimise: bf16x3 where the shape
         # allows it; training mode: the same split kernels, see forward)
         self.precision = "auto"
         # False (optimise / inference, the default): the DECODER is a constant -- codes and poses receive gradients, no decoder weight does

@@ -19,7 +19,8 @@ PRECISIONS = {"fp32": FP32, "bf16x3": BF16X3}
 
 
 def resolve_precision(precision, shape_blocks, texture_blocks, points_per_obj, backward=False) -> int:
-    """'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16, ~2^-17 operand error, several times faster) or 'auto'
+    """'fp32' (exact fp32 MFMA), 'bf16x3' (the split kernels: every fp32 operand as two 16-bit pieces, three MFMAs per product, several times
+    faster -- fp16 pieces in the forward chain, ~2^-22 per product, bf16 pieces in the backward chain, ~2^-17) or 'auto'
     (bf16x3 where the kernel supports the configuration, else fp32).  Asking for 'bf16x3' where it is unsupported raises.
     A pair (forward, backward) names the two launches apart, e.g. ("fp32", "bf16x3"): the reference's forward values bit for bit in
     its own arithmetic, the gradient on the split-bf16 kernel (it applies the ReLU pattern the forward saved; 2^-17 per product) --
@@ -37,7 +38,7 @@ def resolve_precision(precision, shape_blocks, texture_blocks, points_per_obj, b
             if key not in _AUTO_DOWNGRADES:          # say it once per configuration: 'auto' is several times slower here
                 _AUTO_DOWNGRADES.add(key)
                 warnings.warn(f"supnerf_amd: precision 'auto' runs the exact fp32 kernels for shape_blocks={shape_blocks}, texture_blocks={texture_blocks}, "
-                              f"{points_per_obj} points per object: the split-bf16 kernels need shape_blocks + texture_blocks <= 4 and whole 32-point tiles "
+                              f"{points_per_obj} points per object: the split kernels need shape_blocks + texture_blocks <= 4 and whole 32-point tiles "
                               "per object", RuntimeWarning, stacklevel=3)
         return BF16X3 if ok else FP32
     if precision not in PRECISIONS:
