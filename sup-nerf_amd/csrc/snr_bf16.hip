@@ -335,12 +335,16 @@ __device__ __forceinline__ void epi16(const f32x4& acc, FOp& o, const Epi16& c, 
         if (DUMP) dv[e] = xv[e];
     }
     typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    float one_ = 1.0f;
+    asm("" : "+v"(one_));          // (opaque: a literal 1.0 would be folded to a subtraction, and the conversion would come back)
     uint32_t (&hw)[4] = reinterpret_cast<uint32_t (&)[4]>(o.hi);
     uint32_t (&lw)[4] = reinterpret_cast<uint32_t (&)[4]>(o.lo);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const h2 hp = __builtin_amdgcn_cvt_pkrtz(xv[2 * k], xv[2 * k + 1]);
-        const h2 lp = __builtin_amdgcn_cvt_pkrtz(xv[2 * k] - (float)hp[0], xv[2 * k + 1] - (float)hp[1]);
+        // the remainder x - hi as ONE v_fma_mix_f32 (f32 x 1 - f16 piece; exact) instead of v_cvt_f32_f16 + v_sub_f32: three VALU
+        // instructions per value in this epilogue where bf16 pieces took four (forward -1.5 %, forward with ReLU bits -2.7 %)
+        const h2 lp = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(xv[2 * k], one_, -(float)hp[0]), __builtin_fmaf(xv[2 * k + 1], one_, -(float)hp[1]));
         hw[2 * HALF + k] = __builtin_bit_cast(uint32_t, hp);
         lw[2 * HALF + k] = __builtin_bit_cast(uint32_t, lp);
     }
