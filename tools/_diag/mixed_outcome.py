@@ -9,7 +9,7 @@ from oracle import supnerf_oracle as O
 T = supnerf_amd.trainer
 dev = torch.device("cuda:0")
 oracle_params = O.init_decoder_params(seed=0, sigma_bias=-2.0)
-STEPS, B, n, S = 60, 2, 32, 64
+STEPS, B, n, S = int(os.environ.get("SNR_STEPS", "60")), int(os.environ.get("SNR_B", "2")), int(os.environ.get("SNR_N", "32")), 64
 g = torch.Generator().manual_seed(5)
 batches = [dict(code_idx=torch.tensor([(2 * k) % 6, (2 * k + 3) % 6]), xyz=torch.rand(B, n, S, 3, generator=g) - 0.5,
                 viewdir=torch.nn.functional.normalize(torch.randn(B, n, 1, 3, generator=g), dim=-1).repeat(1, 1, S, 1),
@@ -28,6 +28,7 @@ def oracle_run(dtype, seed_codes=4):
         opt.zero_grad()
         total = O.training_losses(p, b["xyz"], b["viewdir"], w_sc[b["code_idx"]], w_tc[b["code_idx"]], b["z_vals"], b["rgb_tgt"], b["occ_pixels"], 0.1)[0]
         total.backward(); opt.step(); curve.append(float(total))
+        if it % 20 == 0: print(f"  oracle {dtype} step {it}", flush=True)
     return np.array(curve), {k: v.detach().double() for k, v in p.items()}
 def gpu_run(precision):
     m = supnerf_amd.CodeNeRF(3, 1); m.load_state_dict(oracle_params, strict=True); m.precision = precision
