@@ -142,6 +142,33 @@ def test_rays_and_depths_match_oracle(amd, golden):
     assert float((a - torch.linspace(9.25, 14.5, 64)).abs().max()) < 2e-6
 
 
+def test_precision_names_pairs_and_triples(amd):
+    """``precision``: one name for every launch, a pair (forward, backward) or a training triple (forward chain, backward chain,
+    products); 'auto' falls back to exact fp32 where the split kernels do not take the shape, an explicit 'bf16x3' raises there."""
+    ops = amd.ops
+    import warnings
+    ok = dict(shape_blocks=3, texture_blocks=1, points_per_obj=4096)
+    assert ops.resolve_precision("fp32", **ok) == ops.FP32 and ops.resolve_precision("bf16x3", **ok) == ops.BF16X3
+    assert ops.resolve_precision("auto", **ok) == ops.BF16X3 and ops.resolve_precision(None, **ok) == ops.BF16X3
+    pair = ("fp32", "bf16x3")
+    assert ops.resolve_precision(pair, **ok) == ops.FP32 and ops.resolve_precision(pair, backward=True, **ok) == ops.BF16X3
+    triple = ("auto", "fp32", "bf16x3")
+    assert ops.resolve_precision(triple, **ok) == ops.BF16X3 and ops.resolve_precision(triple, backward=True, **ok) == ops.FP32
+    with pytest.raises(amd.SnrError):
+        ops.resolve_precision(("fp32",), **ok)
+    with pytest.raises(amd.SnrError):
+        ops.resolve_precision("fp16", **ok)
+    big = dict(shape_blocks=5, texture_blocks=5, points_per_obj=4096)          # SUPNeRF's default decoder: ten blocks
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert ops.resolve_precision("auto", **big) == ops.FP32
+        assert ops.resolve_precision(("auto", "auto"), backward=True, **big) == ops.FP32
+    with pytest.raises(amd.SnrError):
+        ops.resolve_precision("bf16x3", **big)
+    with pytest.raises(amd.SnrError):
+        ops.resolve_precision("bf16x3", shape_blocks=3, texture_blocks=1, points_per_obj=35)      # a partial 32-point tile per object
+
+
 def test_frame_matrices(amd):
     U = amd.utils
     g = torch.Generator().manual_seed(0)
