@@ -157,6 +157,8 @@ class Clock:
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
+        torch.cuda.synchronize()
+        self.last_local = time.perf_counter() - t0          # this rank's own time for its own launches (the per-rank record)
         self.barrier()
         dt = time.perf_counter() - t0
         if self.dist is not None:
@@ -164,6 +166,20 @@ class Clock:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
+
+    def rank_records(self, rank, rays_per_s):
+        """One record per rank, all-gathered over the communicator: evidence that N DISTINCT devices joined it (device index, PCI
+        bus id, uuid) and what each of them rendered on its own clock."""
+        idx = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(idx)
+        bus = "%04x:%02x:%02x" % tuple(int(getattr(pr, k, -1)) & 0xFFFF for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        rec = {"rank": rank, "device_index": idx, "pci_bus_id": bus, "uuid": str(getattr(pr, "uuid", "")), "name": pr.name,
+               "rays_per_s": rays_per_s}
+        if self.dist is None:
+            return [rec]
+        out = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(out, rec)
+        return sorted(out, key=lambda r: r["rank"])
 
     @staticmethod
     def events(fn, steps):
@@ -183,6 +199,7 @@ def roofline(precision, kern_ms, which):
     traffic, src = profile_traffic(precision, which)
     return {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[precision],
             "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": src,
+            "traffic_measured_in_run": False,      # (the counters come from the committed rocprofv3 --pmc profile named above, not from this run)
             "kernel": (FWD_KERNEL if which == "fwd" else BWD_KERNEL)[precision], "kernel_ms": kern_ms, "flop_per_launch": N_RAYS * FLOP_PER_RAY,
             "mfma_pipe_frac": ISSUE_FACTOR[precision] * achieved / PEAK_TFLOPS[precision],
             "note": "achieved = ALGORITHMIC flops (57.56 MFLOP/ray" + (", optimise-mode backward = dX only: the same count" if which == "bwd" else "")
@@ -308,6 +325,7 @@ def main():
     # ---- headline: the contract's wall clock around EXACTLY --steps launches, in the reference's arithmetic unless asked otherwise
     elapsed = clock.wall(lambda: step(prec), args.steps, args.warmup)
     value = world * N_RAYS * args.steps / elapsed
+    ranks = clock.rank_records(rank, N_RAYS * args.steps / clock.last_local)
     kern_ms = clock.events(lambda: step(prec), args.steps)
     result = {
         "metric": "rays/sec at 4096 rays x 64 samples (fused render forward)",
@@ -318,6 +336,7 @@ def main():
                                "4096 rays x 64 samples, family-A render (render_rays_v2 tail)", "precision": prec,
                    "rays": N_RAYS, "samples": N_SAMPLES, "objects_per_gpu": 1, "sharding": "objects across ranks, no data-path collective"},
         "roofline": roofline(prec, kern_ms, "fwd"),
+        "ranks": ranks, "distinct_devices": len({(r["pci_bus_id"], r["uuid"]) for r in ranks}),
     }
     if args.headline_only:
         if rank == 0:

@@ -923,3 +923,90 @@ def eval_curves(saved: dict, max_iter: int):
     T = np.asarray([torch.stack(v).numpy()[:max_iter] for v in saved["T_eval"].values()], dtype=np.float64)
     return ps.mean(0), (de * cnt[:, None]).sum(0) / cnt.sum(), R.mean(0) / np.pi * 180, T.mean(0)
 
+
+
+# --------------------------------------------------------------------------
+# feed-forward pose refinement that fills the loop's pose table
+# (src/optimizer_nuscenes.py:451-551; its start_wt_est_pose / PnP branch is cv2 and not restated)
+# --------------------------------------------------------------------------
+
+def rotvec_to_matrix(v: Tensor) -> Tensor:
+    """(...,3) rotation vector -> (...,3,3), Rodrigues.  Stands in for ``pytorch3d.transforms.axis_angle_to_matrix``
+    (src/optimizer_nuscenes.py:539; pytorch3d is not installed and unpinned in the reference: PARITY UNPINNED for this function,
+    checked against scipy only)."""
+    theta = torch.linalg.norm(v, dim=-1, keepdim=True)
+    axis = v / theta.clamp_min(1e-12)
+    x, y, z = axis[..., 0], axis[..., 1], axis[..., 2]
+    o = torch.zeros_like(x)
+    Kx = torch.stack([torch.stack([o, -z, y], -1), torch.stack([z, o, -x], -1), torch.stack([-y, x, o], -1)], -2)
+    s, c = torch.sin(theta)[..., None], torch.cos(theta)[..., None]
+    eye = torch.eye(3, dtype=v.dtype).expand(Kx.shape)
+    return eye + s * Kx + (1 - c) * (Kx @ Kx)
+
+
+def matrix_to_rotvec(R: Tensor) -> Tensor:
+    """(...,3,3) -> (...,3) with angle in [0, pi).  Stands in for ``pytorch3d.transforms.matrix_to_axis_angle``
+    (src/optimizer_nuscenes.py:537; PARITY UNPINNED like ``rotvec_to_matrix``); valid away from angle pi."""
+    cos = ((R[..., 0, 0] + R[..., 1, 1] + R[..., 2, 2] - 1) / 2).clamp(-1, 1)
+    ang = torch.acos(cos)
+    w = torch.stack([R[..., 2, 1] - R[..., 1, 2], R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] - R[..., 0, 1]], -1)
+    s = torch.sin(ang)
+    scale = torch.where(s > 1e-6, ang / (2 * s.clamp_min(1e-6)), torch.full_like(s, 0.5))          # (acos gives [0, pi]: sin >= 0)
+    return w * scale[..., None]
+
+
+def roi_normalised_points(pts: Tensor, roi: Tensor) -> Tuple[Tensor, Tensor]:
+    """``normalize_by_roi(pts, roi, need_square=True)`` (src/utils.py:1175-1197): (N,2,n) pixel points relative to the roi centre,
+    divided by the roi's LONGER side (not half of it).  Returns (points, longer side (N,))."""
+    w, h = roi[:, 2] - roi[:, 0], roi[:, 3] - roi[:, 1]
+    cx, cy = (roi[:, 2] + roi[:, 0]) / 2, (roi[:, 3] + roi[:, 1]) / 2
+    out = pts.clone()
+    out[:, 0, :] -= cx.unsqueeze(-1)
+    out[:, 1, :] -= cy.unsqueeze(-1)
+    dim = torch.maximum(w, h)
+    out /= dim.view(-1, 1, 1)
+    return out, dim
+
+
+def pose_head(params: Dict[str, Tensor], im_feat: Tensor, box_uv: Tensor) -> Tensor:
+    """``SUPNeRF.pose_update`` (src/model_supnerf.py:226-239) from a state-dict: pose_layer_0.. encode the 16 projected-corner
+    coordinates, regress_layer_0.. take [image feature | pose feature], out_delta_layer gives the 6-vector."""
+    f, j = box_uv, 0
+    while f"pose_layer_{j}.0.weight" in params:
+        f = torch.relu(F.linear(f, params[f"pose_layer_{j}.0.weight"], params[f"pose_layer_{j}.0.bias"]))
+        j += 1
+    d, j = torch.cat([im_feat, f], -1), 0
+    while f"regress_layer_{j}.0.weight" in params:
+        d = torch.relu(F.linear(d, params[f"regress_layer_{j}.0.weight"], params[f"regress_layer_{j}.0.bias"]))
+        j += 1
+    return F.linear(d, params["out_delta_layer.weight"], params["out_delta_layer.bias"])
+
+
+def pose_refine_step(pose_update, im_feat: Tensor, src_pose: Tensor, wlh: Tensor, roi: Tensor, K: Tensor, K_inv: Tensor,
+                     to_rotvec=matrix_to_rotvec, to_matrix=rotvec_to_matrix) -> Tensor:
+    """``fw_pose_one_step`` (src/optimizer_nuscenes.py:509-551).  ``pose_update(im_feat, uv16)`` is the pose head.  The two
+    rotation conversions are arguments so that the fixture generator can run the reference's building blocks around the SAME
+    conversions (pytorch3d is absent)."""
+    uv = project_points(box_corners(src_pose, wlh), K)                   # :517 corners_of_box_batch + view_points_batch(normalize=True)
+    uv_n, dim = roi_normalised_points(uv[:, :2, :], roi)                 # :520
+    delta = pose_update(im_feat, uv_n.reshape(im_feat.shape[0], -1)).clone()     # :523-527
+    delta[:, :3] *= (torch.pi * 2)                                       # :531
+    delta[:, 3:5] *= dim.unsqueeze(-1)                                   # :532
+    delta[:, 5] += 1                                                     # :533
+    pred_R = to_matrix(to_rotvec(src_pose[:, :, :3]) + delta[:, :3])     # :536-539
+    T_src = src_pose[:, :, 3:]
+    uvw = torch.matmul(K, T_src)                                         # :542
+    pred_u = uvw[:, 0] / uvw[:, 2] + delta[:, 3:4]
+    pred_v = uvw[:, 1] / uvw[:, 2] + delta[:, 4:5]
+    pred_Z = src_pose[:, 2, 3:] * delta[:, 5:]
+    pred_T = torch.matmul(K_inv, torch.cat([pred_u * pred_Z, pred_v * pred_Z, pred_Z], dim=1).unsqueeze(-1))     # :546-547
+    return torch.cat([pred_R, pred_T], dim=2)
+
+
+def pose_refine_table(pose_update, im_feat, src_pose, wlh, roi, K, K_inv, iters=3, **conv) -> Tensor:
+    """``fw_pose_update`` (src/optimizer_nuscenes.py:451-507, start_wt_est_pose False): (B, iters+1, 3, 4), the start pose first."""
+    table = [src_pose]
+    with torch.no_grad():
+        for _ in range(iters):
+            table.append(pose_refine_step(pose_update, im_feat, table[-1], wlh, roi, K, K_inv, **conv))
+    return torch.stack(table, dim=1)

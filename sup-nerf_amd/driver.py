@@ -131,6 +131,54 @@ def gather_metric_rows(rows: torch.Tensor, ids: torch.Tensor, n_items: int, grou
     return out
 
 
+# ------------------------------------------------------------------ the stock pose head in the loop (src/optimizer_nuscenes.py:451-551)
+def _box_corners(obj_pose, wlh):
+    """(B,3,8) box corners in the camera frame: ``corners_of_box_batch(obj_pose, wlh)`` (src/utils.py:1110-1148, nuScenes order: x
+    forward, y left, z up)."""
+    sx = torch.tensor([1, 1, 1, 1, -1, -1, -1, -1], dtype=wlh.dtype, device=wlh.device)
+    sy = torch.tensor([1, -1, -1, 1, 1, -1, -1, 1], dtype=wlh.dtype, device=wlh.device)
+    sz = torch.tensor([1, 1, -1, -1, 1, 1, -1, -1], dtype=wlh.dtype, device=wlh.device)
+    local = torch.stack([wlh[:, 1:2] / 2 * sx, wlh[:, 0:1] / 2 * sy, wlh[:, 2:3] / 2 * sz], dim=1)
+    return torch.matmul(obj_pose[:, :, :3], local) + obj_pose[:, :, 3:4]
+
+
+def fw_pose_one_step(model, im_feat, src_pose, wlh, roi, K, K_inv):
+    """One step of the feed-forward pose refiner, ``OptimizerNuScenes.fw_pose_one_step`` (src/optimizer_nuscenes.py:509-551): project
+    the current box (``corners_of_box_batch`` + ``view_points_batch(normalize=True)``), normalise the 8 corners by the roi
+    (``normalize_by_roi(need_square=True)``, src/utils.py:1175-1197), let the STOCK pose head ``model.pose_update`` (plain PyTorch,
+    src/model_supnerf.py:226-239) regress a 6-vector, and apply it: rotation vector += 2 pi d[:3]; projected centre += d[3:5] * roi size;
+    depth *= (d[5] + 1).  (B,3,4) object poses in, (B,3,4) out.  Rotation conversions: Rodrigues (``axis_angle_to_matrix`` above; the
+    reference calls pytorch3d, un-pinned)."""
+    uvw = torch.matmul(K, _box_corners(src_pose, wlh))
+    uv = (uvw / uvw[:, 2:3, :])[:, :2, :]
+    w_, h_ = roi[:, 2] - roi[:, 0], roi[:, 3] - roi[:, 1]
+    cx, cy = (roi[:, 2] + roi[:, 0]) / 2, (roi[:, 3] + roi[:, 1]) / 2
+    dim = torch.maximum(w_, h_)
+    uv_n = torch.stack([uv[:, 0, :] - cx.unsqueeze(-1), uv[:, 1, :] - cy.unsqueeze(-1)], dim=1) / dim.view(-1, 1, 1)
+    B = im_feat.shape[0]
+    d = model.pose_update(im_feat, uv_n.reshape(B, -1))
+    d_rot, d_uv, d_z = d[:, :3] * (math.pi * 2), d[:, 3:5] * dim.unsqueeze(-1), d[:, 5:] + 1
+    pred_R = axis_angle_to_matrix(matrix_to_axis_angle(src_pose[:, :, :3]) + d_rot)
+    c = torch.matmul(K, src_pose[:, :, 3:])
+    pred_u = c[:, 0] / c[:, 2] + d_uv[:, 0:1]
+    pred_v = c[:, 1] / c[:, 2] + d_uv[:, 1:2]
+    pred_Z = src_pose[:, 2, 3:] * d_z
+    pred_T = torch.matmul(K_inv, torch.cat([pred_u * pred_Z, pred_v * pred_Z, pred_Z], dim=1).unsqueeze(-1))
+    return torch.cat([pred_R, pred_T], dim=2)
+
+
+def fw_pose_update(model, im_feat, src_pose, wlh, roi, K, K_inv, iters=3):
+    """``OptimizerNuScenes.fw_pose_update`` (src/optimizer_nuscenes.py:451-507) without its PnP start (``start_wt_est_pose``: cv2): the
+    start pose followed by ``iters`` refinement steps -> the pose table (B, iters + 1, 3, 4) that the loop's first ``reg_iters + 1``
+    iterations render at (:641-651,684-689); the optimiser's ``rot_vec`` / ``trans_vec`` start from its last entry (:652,664-666).
+    All of it stock PyTorch on the inputs' device, under ``no_grad`` like the caller (:641)."""
+    with torch.no_grad():
+        table = [src_pose]
+        for _ in range(iters):
+            table.append(fw_pose_one_step(model, im_feat, table[-1], wlh, roi, K, K_inv))
+        return torch.stack(table, dim=1)
+
+
 # ------------------------------------------------------------------ one object
 def make_optimizer(shapecode, texturecode, rot_vec, trans_vec, lr):
     """AdamW over four groups (src/optimizer_nuscenes.py:1762-1769)."""
@@ -150,26 +198,36 @@ def losses(rgb_rays, acc_trans_rays, rgb_tgt, occ_pixels, loss_occ_coef):
 
 
 def optimize_object(model, device, obj: Dict, hpams: dict, shapecode0, texturecode0, pose_noise=(0.05, 0.3), reg_iters=3,
-                    n_lidar=64, seed=0, log=None, jitter=None, info: Optional[dict] = None):
+                    n_lidar=64, seed=0, log=None, jitter=None, info: Optional[dict] = None, pose_per_iter=None):
     """Optimise codes and object pose of one object against its (synthetic) target.  Returns a metric tensor
     (num_opts, 4) = [psnr, depth_err, rot_err, trans_err] per iteration, and the final codes / pose.
 
     With a native decoder this is the fused iteration of ``optimize_objects_batched`` at one object (about thirty launches, no host
     round trip), fed with the depth jitter the reference's loop would have drawn: two ``torch.rand(S)`` per iteration from the global
     CPU generator, in order.  ``optimize_object_api`` is the same loop written against the public functions, call for call like the
-    reference (needed for ``sym_aug``, which flips a python coin inside every render call, for foreign decoders and for ``log``)."""
+    reference (needed for ``sym_aug``, which flips a python coin inside every render call, for foreign decoders and for ``log``).
+
+    ``pose_per_iter`` ((reg_iters + 1, 3, 4) OBJECT poses in the camera frame, e.g. from ``fw_pose_update``; None = the noise-perturbed
+    ground truth): the loop's first ``reg_iters + 1`` iterations render at these poses and the optimiser's ``rot_vec`` / ``trans_vec`` start
+    from the last one (src/optimizer_nuscenes.py:641-668,684-689)."""
+    if pose_per_iter is not None:
+        pose_per_iter = torch.as_tensor(pose_per_iter, dtype=torch.float32).reshape(-1, 3, 4)
+        if pose_per_iter.shape[0] != reg_iters + 1:
+            raise U.SnrError(f"pose_per_iter holds {pose_per_iter.shape[0]} poses, the loop renders reg_iters + 1 = {reg_iters + 1} of them")
     if not U._is_native(model) or hpams.get("sym_aug", 0) or log is not None or not U.ops.fused_supported(hpams["n_samples"]):
-        return optimize_object_api(model, device, obj, hpams, shapecode0, texturecode0, pose_noise, reg_iters, n_lidar, seed, log, jitter, info)
+        return optimize_object_api(model, device, obj, hpams, shapecode0, texturecode0, pose_noise, reg_iters, n_lidar, seed, log, jitter, info,
+                                   pose_per_iter=pose_per_iter)
     T, S = hpams["optimize"]["num_opts"], hpams["n_samples"]
     if jitter is None:
         jitter = torch.stack([torch.stack([torch.rand(S), torch.rand(S)]) for _ in range(T)]) if T else torch.zeros(0, 2, S)
     m, sc, tc, pose = optimize_objects_batched(model, device, [obj], hpams, shapecode0, texturecode0, [seed], pose_noise, reg_iters, n_lidar,
-                                               jitter=jitter[:, :, None, :], info=info)
+                                               jitter=jitter[:, :, None, :], info=info,
+                                               pose_per_iter=None if pose_per_iter is None else pose_per_iter[None])
     return m[0].cpu(), sc, tc, pose[0]
 
 
 def optimize_object_api(model, device, obj: Dict, hpams: dict, shapecode0, texturecode0, pose_noise=(0.05, 0.3), reg_iters=3,
-                        n_lidar=64, seed=0, log=None, jitter=None, info: Optional[dict] = None):
+                        n_lidar=64, seed=0, log=None, jitter=None, info: Optional[dict] = None, pose_per_iter=None):
     """``optimize_object`` through the public render API, one call per reference call (src/optimizer_nuscenes.py:674-783): ~350 launches
     per iteration, host-bound at one object."""
     opt = hpams["optimize"]
@@ -185,6 +243,10 @@ def optimize_object_api(model, device, obj: Dict, hpams: dict, shapecode0, textu
     gt_pose = torch.cat([R_gt, t_gt], -1)
     rot_vec = (matrix_to_axis_angle(R_gt[None]) + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[0]).to(dev)
     trans_vec = (t_gt.T + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[1]).to(dev)
+    if pose_per_iter is not None:          # the pose head's table: start from its last pose (src/optimizer_nuscenes.py:652,664-666)
+        pose_per_iter = torch.as_tensor(pose_per_iter, dtype=torch.float32).reshape(-1, 3, 4).to(dev)
+        rot_vec = matrix_to_axis_angle(pose_per_iter[-1, :3, :3][None]).contiguous()
+        trans_vec = pose_per_iter[-1, :3, 3][None].clone()
     rot_vec.requires_grad_(); trans_vec.requires_grad_()
     shapecode = shapecode0.detach().clone().to(dev).requires_grad_()
     texturecode = texturecode0.detach().clone().to(dev).requires_grad_()
@@ -202,8 +264,11 @@ def optimize_object_api(model, device, obj: Dict, hpams: dict, shapecode0, textu
         optim.zero_grad()
         if jitter is not None:                                   # (num_opts, 2, S): the two draws of this iteration (tests)
             U.JITTER_OVERRIDE = jitter[it, 0]
-        R = axis_angle_to_matrix(rot_vec[0])
-        t = trans_vec[0].unsqueeze(-1)
+        if pose_per_iter is not None and it <= reg_iters:        # "the first a few to load pre-computed poses" (:684-689)
+            R, t = pose_per_iter[it, :3, :3], pose_per_iter[it, :3, 3:]
+        else:
+            R = axis_angle_to_matrix(rot_vec[0])
+            t = trans_vec[0].unsqueeze(-1)
         if not opt.get("opt_cam_pose", 0):                       # object pose is optimised: invert to camera-in-object
             Rc = R.transpose(-2, -1)
             cam2opt = torch.cat([Rc, -Rc @ t], -1)
@@ -240,20 +305,25 @@ def optimize_object_api(model, device, obj: Dict, hpams: dict, shapecode0, textu
 
 # ------------------------------------------------------------------ many objects per launch (BASELINE config 3)
 def optimize_objects_batched(model, device, objs: List[Dict], hpams: dict, shapecodes0, texturecodes0, seeds: Sequence[int],
-                             pose_noise=(0.05, 0.3), reg_iters=3, n_lidar=64, jitter=None, info: Optional[dict] = None):
+                             pose_noise=(0.05, 0.3), reg_iters=3, n_lidar=64, jitter=None, info: Optional[dict] = None, pose_per_iter=None):
     """The iteration of ``optimize_object`` for B objects at once: ONE fused forward, one backward and one depth render of the lidar pixels
     per iteration for all of them (per-object codes, poses, depth tables and targets; the loss is the sum of the per-object losses, so
     every object sees exactly its own gradient), AdamW over the stacked leaves in one launch, metrics kept on the device until the end --
     no host round trip inside the loop (``_optimize_fused``: ~24 launches per iteration for any B).  Jitter: ``jitter``
     (num_opts, 2, B, S) or, by default, drawn up front from one CPU generator per object (seeded like the per-object loop seeds its
     RandomState).  ``info`` (optional dict) receives ``lidar_count`` (B,): the number of depth pixels behind every object's depth metric.
+    ``pose_per_iter`` (B, reg_iters + 1, 3, 4): every object's pose table for the render-only iterations, see ``optimize_object``.
     Returns metrics (B, num_opts, 4), shape codes, texture codes, poses (B,3,4).
     (Round 2 also carried a HIP-graph replay of the torch-op iteration; it lost to this eager fused loop, 2.3 vs 1.3 ms per iteration, and
     is gone.)"""
     dev = torch.device(device)
     if hpams.get("sym_aug", 0):
         raise U.SnrError("optimize_objects_batched: sym_aug draws one python coin per object and iteration; use optimize_object")
-    return _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, pose_noise, reg_iters, n_lidar, jitter, info)
+    if pose_per_iter is not None:
+        pose_per_iter = torch.as_tensor(pose_per_iter, dtype=torch.float32)
+        if tuple(pose_per_iter.shape) != (len(objs), reg_iters + 1, 3, 4):
+            raise U.SnrError(f"pose_per_iter must be (B, reg_iters + 1, 3, 4) = ({len(objs)}, {reg_iters + 1}, 3, 4), got {tuple(pose_per_iter.shape)}")
+    return _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, pose_noise, reg_iters, n_lidar, jitter, info, pose_per_iter)
 
 
 def _lidar_pixels(ob, rs, n_lidar):
@@ -272,7 +342,7 @@ def _lidar_pixels(ob, rs, n_lidar):
     return xs[pick], ys[pick], None
 
 
-def _loop_inputs(objs, seeds, hpams, pose_noise, n_lidar, dev):
+def _loop_inputs(objs, seeds, hpams, pose_noise, n_lidar, dev, pose_per_iter=None):
     """Per-object constants of the loop, built once on the host and moved to the device: perturbed start pose, ground truth, the pixel
     direction tables [(px-cx)/fx, (py-cy)/fy, 1] of the render grid and of the lidar pixels (every object keeps ITS OWN count: the tables
     are padded to the largest, the metric kernel averages each object's first ``lid_cnt`` entries), measured depths when the objects
@@ -285,6 +355,9 @@ def _loop_inputs(objs, seeds, hpams, pose_noise, n_lidar, dev):
         t_gt = -R_gt @ ob["cam_pose"][:, 3:]
         rot0.append(matrix_to_axis_angle(R_gt[None]) + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[0])
         tr0.append(t_gt.T + torch.from_numpy(rs.randn(1, 3).astype(np.float32)) * pose_noise[1])
+        if pose_per_iter is not None:      # (the draws above still happen: the lidar pixels below come from the same RandomState)
+            last = pose_per_iter[len(rot0) - 1, -1]
+            rot0[-1], tr0[-1] = matrix_to_axis_angle(last[:3, :3][None]), last[:3, 3][None].clone()
         gtR.append(R_gt); gtT.append(t_gt.reshape(3))
         x_vec, y_vec, depth = _lidar_pixels(ob, rs, n_lidar)
         x0, y0, x1, y1 = [int(v) for v in ob["roi"]]
@@ -315,7 +388,8 @@ def _loop_inputs(objs, seeds, hpams, pose_noise, n_lidar, dev):
                 tgt=st(tgt), occ=st(occ), diag=torch.tensor([float(ob["obj_diag"]) for ob in objs], device=dev), n_lidar=n_l)
 
 
-def _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, pose_noise, reg_iters, n_lidar, jitter, info=None):
+def _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, pose_noise, reg_iters, n_lidar, jitter, info=None,
+                    pose_per_iter=None):
     """The iteration as ~30 launches for any number of objects: pose -> rays + depths (one launch), the per-object layers (two GEMMs),
     fused render, loss tail (one launch), backward = their four backward launches, the 64-pixel depth render, the metric row (one
     launch), AdamW over the four parameter groups (one launch).  Nothing reads back until the loop has finished."""
@@ -323,7 +397,7 @@ def _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, 
     opt = hpams["optimize"]
     S, im_sz, T = hpams["n_samples"], hpams["render_im_sz"], opt["num_opts"]
     B, n = len(objs), im_sz * im_sz
-    c = _loop_inputs(objs, seeds, hpams, pose_noise, n_lidar, dev)
+    c = _loop_inputs(objs, seeds, hpams, pose_noise, n_lidar, dev, pose_per_iter)
     n_l = c["n_lidar"]
     rot_vec, trans_vec = c["rot0"].requires_grad_(), c["tr0"].requires_grad_()
     shapecode = shapecodes0.detach().clone().to(dev).contiguous().requires_grad_()
@@ -349,19 +423,42 @@ def _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, 
     cfg = ops.RenderCfg(S, ops.Z_PER_OBJECT, n, sb, tb, frame=frame, precision=model.precision)
     cfg_l = ops.RenderCfg(S, ops.Z_PER_OBJECT, n_l, sb, tb, frame=frame, precision=model.precision)
     packed = model.packed_weights()
+    table = None
+    if pose_per_iter is not None:
+        # the render-only iterations' camera poses, made once: cam2opt = [R^T | -R^T t] of the table's object poses unless the camera pose
+        # itself is what is optimised (src/optimizer_nuscenes.py:684-699); (reg_iters + 1, B, 3, 4) on the device
+        P = pose_per_iter.to(dev).permute(1, 0, 2, 3)
+        if not opt_cam:
+            Rt = P[..., :3].transpose(-1, -2)
+            P = torch.cat([Rt, -Rt @ P[..., 3:]], dim=-1)
+        table = P.contiguous()
     frozen = [p for p in model.parameters() if p.requires_grad]     # the decoder is a constant of this loop (the reference leaves its
     for p in frozen:                                                 # weights trainable and pays for unused weight gradients)
         p.requires_grad_(False)
     try:
         for it in range(T):
-            cam2opt, rays_o, viewdir, z = ops.PoseRays.apply(rot_vec, trans_vec, c["cam"], half, jitter[it, 0], S, opt_cam)
+            from_table = table is not None and it <= reg_iters
+            if from_table:      # a pre-computed pose per object: rays straight from the (3,4) camera poses (snr_cam_rays_fwd), nothing to differentiate
+                rays_o, viewdir, z = ops.CamRays.apply(table[it], c["cam"], half, jitter[it, 0], S)
+            else:
+                cam2opt, rays_o, viewdir, z = ops.PoseRays.apply(rot_vec, trans_vec, c["cam"], half, jitter[it, 0], S, opt_cam)
             lat = model.latent_terms(shapecode, texturecode)
             cfg.latent_bias = cfg_l.latent_bias = model.latent_biases(lat)
+            if it == 0:         # which arithmetic the loop runs in: "auto" is decided (and range-checked) once, on the first iteration's batch
+                prec = model._auto_precision(model.precision, n * S, lambda p_: ops.render_probe(rays_o.detach(), viewdir.detach(), z, c["diag"], None,
+                                                                                                 lat.detach(), packed, cfg, p_))
+                cfg.precision = prec
+                cfg_l.precision = prec if (prec != "bf16x3" or ops.split_supported(sb, tb, n_l * S)) else "fp32"
             rgb, depth, acc = ops.FusedRender.apply(rays_o, viewdir, z, c["diag"], None, lat, packed, cfg)
             loss, lm = ops.LossTail.apply(rgb, acc, c["tgt"], c["occ"], coef, n)
-            torch.autograd.backward(loss, ones)
+            if it > reg_iters:  # (the gradients of a render-only iteration are cleared unread, :676,768-769: not computed here)
+                torch.autograd.backward(loss, ones)
             with torch.no_grad():
-                c2o, lo, lv, lz = ops.PoseRays.apply(rot_vec.detach(), trans_vec.detach(), c["lid"], half, jitter[it, 1], S, opt_cam)
+                if from_table:
+                    c2o = table[it]
+                    lo, lv, lz = ops.CamRays.apply(c2o, c["lid"], half, jitter[it, 1], S)
+                else:
+                    c2o, lo, lv, lz = ops.PoseRays.apply(rot_vec.detach(), trans_vec.detach(), c["lid"], half, jitter[it, 1], S, opt_cam)
                 d_vec = ops.render_fwd(lo, lv, lz, c["diag"], None, lat.detach(), packed, cfg_l)[1]
                 out4 = torch.cat([loss.detach()[:, None], lm], dim=1)
                 ops.metric_row(out4, d_vec.view(B, n_l), depth0, it == 0 and not measured, c2o, c["gtR"], c["gtT"], opt_cam, metrics[it],

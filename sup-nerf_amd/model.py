@@ -12,6 +12,9 @@ What runs where:
   * ``fused_render`` additionally fuses sampling, frame transforms, positional encoding and the
     alpha composite into the same launch (used by ``supnerf_amd.utils`` / ``supnerf_amd.renderer``).
 """
+import importlib
+import sys
+import threading
 from typing import Optional
 
 import torch
@@ -22,16 +25,20 @@ from . import ops
 from ._lib import SnrError
 
 
+# One lock for the two per-module weight caches (packed stream, stacked latent layers): the decoder is entered from one thread per GPU under
+# nn.DataParallel (src/trainer_unified_nuscenes.py:227-229) and a lock on the module itself would not survive ``replicate`` / deepcopy.
+_CACHE_LOCK = threading.RLock()
+
+# the arithmetic a newly built decoder starts in (``model.precision``); ``python -m supnerf_amd.run --precision fp32 script.py`` sets it
+# for a caller whose code never mentions the attribute
+DEFAULT_PRECISION = "auto"
+
+
 class _DecoderBase(nn.Module):
     """Layer set of src/model_supnerf.py:184-199 and the HIP forward."""
 
     def _build_decoder(self, shape_blocks, texture_blocks, W, num_xyz_freq, num_dir_freq, latent_dim):
-        if W != 256 or latent_dim != 256 or num_xyz_freq != 10 or num_dir_freq != 4:
-            raise SnrError("the gfx950 kernels are built for W=256, latent_dim=256, num_xyz_freq=10, num_dir_freq=4 "
-                           "(every shipped SUP-NeRF config); got "
-                           f"W={W}, latent_dim={latent_dim}, num_xyz_freq={num_xyz_freq}, num_dir_freq={num_dir_freq}")
-        if not (0 <= shape_blocks <= 8 and 0 <= texture_blocks <= 8):
-            raise SnrError("shape_blocks / texture_blocks must be in 0..8")
+        self._check_shape(shape_blocks, texture_blocks, W, num_xyz_freq, num_dir_freq, latent_dim)
         self.shape_blocks, self.texture_blocks = shape_blocks, texture_blocks
         self.num_xyz_freq, self.num_dir_freq = num_xyz_freq, num_dir_freq
         d_xyz, d_viewdir = 3 + 6 * num_xyz_freq, 3 + 6 * num_dir_freq
@@ -46,11 +53,29 @@ class _DecoderBase(nn.Module):
             setattr(self, f"texture_latent_layer_{j + 1}", nn.Sequential(nn.Linear(latent_dim, W), nn.ReLU()))
             setattr(self, f"texture_layer_{j + 1}", nn.Sequential(nn.Linear(W, W), nn.ReLU()))
         self.rgb = nn.Sequential(nn.Linear(W, W // 2), nn.ReLU(), nn.Linear(W // 2, 3))
+        self._init_hip_state()
+
+    @staticmethod
+    def _check_shape(shape_blocks, texture_blocks, W, num_xyz_freq, num_dir_freq, latent_dim):
+        if W != 256 or latent_dim != 256 or num_xyz_freq != 10 or num_dir_freq != 4:
+            raise SnrError("the gfx950 kernels are built for W=256, latent_dim=256, num_xyz_freq=10, num_dir_freq=4 "
+                           "(every shipped SUP-NeRF config); got "
+                           f"W={W}, latent_dim={latent_dim}, num_xyz_freq={num_xyz_freq}, num_dir_freq={num_dir_freq}")
+        if not (0 <= shape_blocks <= 8 and 0 <= texture_blocks <= 8):
+            raise SnrError("shape_blocks / texture_blocks must be in 0..8")
+
+    def _init_hip_state(self):
+        """Everything the HIP forward keeps on the module besides the reference's own layers (also called on a reference class that
+        ``hip_decoder_class`` grafted the forward onto)."""
         self._packed = None
         self._packed_key = None
         # arithmetic of the per-point GEMMs: "fp32" (exact), "bf16x3" (split 16-bit pieces: fp16 forward, bf16 backward) or "auto" (render / optimise: bf16x3 where the shape
         # allows it; training mode: the same split kernels, see forward)
-        self.precision = "auto"
+        self.precision = DEFAULT_PRECISION
+        # what the last launch actually ran in, and why (queryable record of "auto"'s decision, see ops.PrecisionRecord)
+        self.last_precision = None
+        # range guard of "auto" (fp16 pieces saturate at +-65504): verdict per weight version, see _auto_precision
+        self._guard = {"key": None, "verdict": None, "calls": 0, "detail": None}
         # False (optimise / inference, the default): the DECODER is a constant -- codes and poses receive gradients, no decoder weight does
         # (neither the per-point layers nor the per-object latent layers).  That is what the reference's optimisers use: their AdamW
         # holds codes and pose only (src/optimizer_nuscenes.py:1762-1769); the weight gradients torch computes there are never read.
@@ -73,10 +98,75 @@ class _DecoderBase(nn.Module):
     def packed_weights(self) -> torch.Tensor:
         pp = self._per_point_params()
         key = tuple((p.data_ptr(), p._version) for p in pp.values())      # (a move to another device changes data_ptr)
-        if self._packed is None or key != self._packed_key:
-            self._packed = ops.pack_weights(pp, self.shape_blocks, self.texture_blocks)
-            self._packed_key = key
-        return self._packed
+        dev = next(iter(pp.values())).device
+        sk = (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+        with _CACHE_LOCK:
+            # One entry per (device, stream): a buffer packed a moment ago by another thread on ITS stream may not be written yet as far
+            # as this thread's stream is concerned (re-entrancy: one thread per GPU under nn.DataParallel, or a caller's own thread pool
+            # on one module), and a DataParallel replica starts from a shallow copy of its source's attributes on another device.
+            cache = self.__dict__.setdefault("_packed_by_stream", {})
+            ent = cache.get(sk)
+            if ent is None or ent[0] != key:
+                while len(cache) >= 8:
+                    cache.pop(next(iter(cache)))
+                ent = cache[sk] = (key, ops.pack_weights(pp, self.shape_blocks, self.texture_blocks))
+            self._packed_key, self._packed = ent             # (the latest, for callers that bind the C ABI themselves: INTEGRATION.md B)
+            return ent[1]
+
+    # ---- which arithmetic a call runs in: the recorded, queryable decision of "auto"
+    def _auto_precision(self, requested, points_per_obj, probe, train=False):
+        """Resolve ``requested`` (the module's ``precision`` or a per-call override) for one forward / backward pair and record the
+        decision in ``self.last_precision`` = {"requested", "forward", "backward", "reason"}.
+
+        Explicit requests ("fp32", "bf16x3", tuples) pass through.  "auto" picks the split kernels where the library takes the shape
+        (<= 4 blocks, whole 32-point tiles per object) -- and, because their forward chain carries fp16 pieces (activations clamp at
+        +-65504 inside the ReLU, weights are packed clamped), only after THIS decoder has been seen to stay in range: the first ``auto``
+        call of a weight version runs the same batch once more in exact fp32 (``probe(precision)`` -> outputs; 1.75 ms at 4096 x 64),
+        compares, counts clamped weights, and on disagreement beyond ops.RANGE_TOL downgrades the model to fp32 with a warning.  One host
+        read per weight version; nothing in the steady state.  Training (weights change every step) and DataParallel replicas (re-made
+        every step) re-check on calls 1, 2, 4, 8, ... and every 1024th."""
+        sb, tb = self.shape_blocks, self.texture_blocks
+        if requested not in (None, "auto"):
+            f, b = ops.precision_pair(requested, sb, tb, points_per_obj)
+            self.last_precision = {"requested": requested, "forward": f, "backward": b, "reason": "requested"}
+            return requested
+        if not ops.split_supported(sb, tb, points_per_obj):
+            ops.resolve_precision("auto", sb, tb, points_per_obj)          # (says so once per configuration)
+            self.last_precision = {"requested": "auto", "forward": "fp32", "backward": "fp32",
+                                   "reason": f"shape: the split kernels need shape_blocks + texture_blocks <= 4 and whole 32-point tiles per object "
+                                             f"(got {sb} + {tb} blocks, {points_per_obj} points per object)"}
+            return "fp32"
+        with _CACHE_LOCK:
+            g = self._guard
+            g["calls"] += 1
+            n = g["calls"]
+            if train or getattr(self, "_is_replica", False):
+                due = g["verdict"] is None or (n & (n - 1)) == 0 or n % 1024 == 0
+            else:
+                due = g["key"] != self._packed_key or g["verdict"] is None
+            if due:
+                import warnings
+                with torch.no_grad():
+                    bad = ops.outputs_disagree(probe("bf16x3"), probe("fp32"))
+                    clamped = ops.clamped_weight_count(self._per_point_params().values())
+                    bad, clamped = [int(v) for v in torch.stack([bad, clamped]).tolist()]           # the one host read
+                g["key"], g["detail"] = self._packed_key, {"values_out_of_tolerance": bad, "weights_beyond_fp16_range": clamped}
+                if bad or clamped:
+                    if g["verdict"] != "fp32":
+                        warnings.warn(f"supnerf_amd: precision 'auto' runs this decoder on the exact fp32 kernels: its split-fp16 forward left "
+                                      f"the fp32 forward's values ({bad} outputs beyond {ops.RANGE_TOL:g} relative, {clamped} weights beyond "
+                                      f"+-{ops.FP16_MAX:g}); activations or weights exceed the fp16 range", RuntimeWarning, stacklevel=4)
+                    g["verdict"] = "fp32"
+                else:
+                    g["verdict"] = "bf16x3"
+            verdict, detail = g["verdict"], g["detail"]
+        if verdict == "fp32":
+            self.last_precision = {"requested": "auto", "forward": "fp32", "backward": "fp32",
+                                   "reason": f"range guard: split forward disagreed with the fp32 forward ({detail})"}
+            return "fp32"
+        self.last_precision = {"requested": "auto", "forward": "bf16x3", "backward": "bf16x3",
+                               "reason": f"split kernels: shape supported, range guard passed ({detail})"}
+        return "bf16x3"
 
     # ---- the per-object layers as two GEMMs (one for all latent layers, one for all folded biases) when their weights are constants
     def _latent_params(self):
@@ -92,8 +182,13 @@ class _DecoderBase(nn.Module):
         Row block 0 of W_lat multiplies the shape code, row block 1 the texture code; every latent layer owns one column block."""
         lat, nxt = self._latent_params()
         ps = [q for l in lat + nxt for q in (l._parameters["weight"], l._parameters["bias"])]
-        key = tuple((q.data_ptr(), q._version) for q in ps)
-        if getattr(self, "_stack_key", None) != key:
+        dev = ps[0].device
+        key = tuple((q.data_ptr(), q._version) for q in ps) + (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+        with _CACHE_LOCK:
+            return self._stacked_locked(lat, nxt, ps, key)
+
+    def _stacked_locked(self, lat, nxt, ps, key):
+        if getattr(self, "_stack_key", None) != key:          # (one slot, keyed by weights + device + stream like the packed stream)
             n, W = len(lat), 256
             with torch.no_grad():
                 dev = ps[0].device
@@ -174,21 +269,59 @@ class _DecoderBase(nn.Module):
             #   "fp32"   = exact fp32 throughout (the reference's arithmetic, product for product),
             #   "bf16x3" = the split kernels, insisting (raises where unsupported);
             #   a tuple (forward chain, backward chain[, products]) picks each piece.
-            prec = ("auto", "auto", "bf16x3") if self.precision in (None, "auto") else self.precision
-            sig, rgb = ops.DecoderPointsTrain.apply(xyz.reshape(-1, 3), viewdir.reshape(-1, 3), lat, self.shape_blocks,
-                                                    self.texture_blocks, prec, *w)
+            x3, d3 = xyz.reshape(-1, 3), viewdir.reshape(-1, 3)
+            ppo, probe_pts = self._points_shape(x3, d3, lat, pad=lat.shape[1] > 0)
+            prec = self.precision
+            if prec in (None, "auto"):
+                packed = ops._packed_for(ops.per_point_tensor_names(self.shape_blocks, self.texture_blocks), w, self.shape_blocks,
+                                         self.texture_blocks)
+                first = self._auto_precision("auto", ppo, lambda p: ops.decoder_fwd(*probe_pts(), lat.detach(), packed, self.shape_blocks,
+                                                                                    self.texture_blocks, precision=p)[:2], train=True)
+                prec = ("auto", "auto", "bf16x3") if first == "bf16x3" else "fp32"
+            else:
+                self._auto_precision(prec, ppo, None)
+            sig, rgb = ops.DecoderPointsTrain.apply(x3, d3, lat, self.shape_blocks, self.texture_blocks, prec, *w)
             return sig.view(*lead, 1), rgb.view(*lead, 3)
-        sig, rgb = ops.DecoderPoints.apply(xyz.reshape(-1, 3), viewdir.reshape(-1, 3), lat, self.packed_weights(),
-                                           self.shape_blocks, self.texture_blocks, self.precision)
+        x3, d3 = xyz.reshape(-1, 3), viewdir.reshape(-1, 3)
+        packed = self.packed_weights()
+        need_lat = torch.is_grad_enabled() and lat.requires_grad and self.shape_blocks + self.texture_blocks > 0
+        ppo, probe_pts = self._points_shape(x3, d3, lat, pad=need_lat)
+        prec = self._auto_precision(self.precision, ppo, lambda p: ops.decoder_fwd(*probe_pts(), lat.detach(), packed, self.shape_blocks,
+                                                                                   self.texture_blocks, precision=p)[:2])
+        sig, rgb = ops.DecoderPoints.apply(x3, d3, lat, packed, self.shape_blocks, self.texture_blocks, prec)
         return sig.view(*lead, 1), rgb.view(*lead, 3)
+
+    @staticmethod
+    def _points_shape(x3, d3, lat, pad):
+        """(points per object as the operators will launch them -- they pad ragged objects to whole 32-point tiles when latent gradients
+        are wanted --, a thunk giving the point tensors in that shape for the range guard's probe launches)."""
+        B = max(lat.shape[0], 1)
+        P = x3.shape[0]
+        per_obj = P // B
+        n_pad = ops._tile_pad(per_obj) if (pad and P % B == 0 and P > 0) else 0
+        if not n_pad:
+            return per_obj, lambda: (x3.detach(), d3.detach())
+        return n_pad, lambda: (ops._pad_rows(x3.detach(), B, per_obj, n_pad), ops._pad_rows(d3.detach(), B, per_obj, n_pad))
 
     def fused_render(self, rays_o, rays_d, t_vals, xyz_div, z_scale, shape_latent, texture_latent, cfg: "ops.RenderCfg"):
         """rays -> (rgb (N,3), depth (N,), acc_trans (N,)) in one launch (see ops.FusedRender)."""
         lat = self.latent_terms(shape_latent, texture_latent)
-        if cfg.precision is None:
-            cfg.precision = self.precision
+        packed = self.packed_weights()
         cfg.latent_bias = self.latent_biases(lat)
-        return ops.FusedRender.apply(rays_o, rays_d, t_vals, xyz_div, z_scale, lat, self.packed_weights(), cfg)
+        n, S = cfg.rays_per_obj, cfg.n_samples
+        need_lat = torch.is_grad_enabled() and lat.requires_grad and self.shape_blocks + self.texture_blocks > 0
+        n_launch = (ops._tile_pad(n, S) or n) if need_lat else n
+
+        def probe(p):
+            ro, rd, tv, zs, c = rays_o.detach(), rays_d.detach(), None if t_vals is None else t_vals.detach(), z_scale, cfg
+            if n_launch != n:               # ragged objects: padded with dummy rays exactly like FusedRender will (their outputs are compared too)
+                if tv is None and c.z_mode == ops.Z_BOX and c.rng is None:
+                    tv = torch.zeros(ro.shape[0], S, device=ro.device)          # (any jitter serves a range check; the generator is not touched)
+                ro, rd, tv, zs, c = ops.pad_render_inputs(ops._f32c(ro), ops._f32c(rd), ops._f32c(tv), ops._f32c(zs), c, ro.shape[0] // n, n, n_launch)
+            return ops.render_probe(ro, rd, tv, xyz_div, zs, lat.detach(), packed, c, p)
+
+        cfg.precision = self._auto_precision(self.precision if cfg.precision is None else cfg.precision, n_launch * S, probe)
+        return ops.FusedRender.apply(rays_o, rays_d, t_vals, xyz_div, z_scale, lat, packed, cfg)
 
 
 class CodeNeRF(_DecoderBase):
@@ -199,17 +332,52 @@ class CodeNeRF(_DecoderBase):
         self._build_decoder(shape_blocks, texture_blocks, W, num_xyz_freq, num_dir_freq, latent_dim)
 
 
-class SUPNeRF(_DecoderBase):
-    """Decoder + pose-update head of src/model_supnerf.py:164-269 (same constructor keywords).
+_REF_MODEL_MODULES = ("model_supnerf", "src.model_supnerf")
 
-    ``img_encoder`` is the caller's stock-PyTorch image encoder (the reference's ResNet ``ImgEncoder``,
-    src/model_supnerf.py:17-152, is outside this package); ``encode_img`` forwards to it."""
+
+def _resolve_ref_encoder(module=None):
+    """The caller's own ``ImgEncoder`` and ``BasicBlock`` (src/model_supnerf.py:13,17): looked up at run time in the reference's module --
+    ``sys.path.insert(0, 'src')`` is the first thing its entry scripts do (optimize_nuscenes.py:1-3) -- never stored here."""
+    tried = []
+    for name in ([module] if module is not None else []) + list(_REF_MODEL_MODULES):
+        mod = name if not isinstance(name, str) else sys.modules.get(name)
+        if mod is None:
+            try:
+                mod = importlib.import_module(name)
+            except Exception as e:                       # noqa: BLE001  (ModuleNotFoundError, or the module's own imports failing)
+                tried.append(f"{name}: {type(e).__name__}: {e}")
+                continue
+        enc = getattr(mod, "ImgEncoder", None)
+        # an installed module's SUPNeRF was replaced; its encoder never is.  BasicBlock is torchvision's, imported by that module.
+        block = getattr(mod, "BasicBlock", None)
+        if enc is not None and block is not None:
+            return enc, block
+        tried.append(f"{getattr(mod, '__name__', mod)}: no ImgEncoder / BasicBlock in it")
+    raise SnrError("SUPNeRF was built without an img_encoder and the reference's own ImgEncoder is not importable (it stays the caller's "
+                   "stock PyTorch module: put the reference's src/ on sys.path, or pass img_encoder=...).  Tried: " + "; ".join(tried))
+
+
+class SUPNeRF(_DecoderBase):
+    """Decoder + pose-update head of src/model_supnerf.py:164-269 (same constructor keywords, same state-dict).
+
+    The ResNet image encoder (src/model_supnerf.py:17-152) is outside this package and stays the caller's stock PyTorch module:
+    ``SUPNeRF(**hpams['net_hyperparams'])`` -- the call of src/optimizer_nuscenes.py:1785 -- resolves the reference's ``ImgEncoder`` from the
+    caller's importable ``model_supnerf`` and constructs it exactly as src/model_supnerf.py:168-175 does, so that a strict
+    ``load_state_dict(saved['model_params'])`` (:1796) finds every ``img_encoder.*`` key.  ``img_encoder=<module>`` supplies one instead;
+    ``img_encoder=False`` builds the decoder + pose head alone (``encode_img`` then raises)."""
+
+    _ref_module = None            # supnerf_amd.install binds the class it puts into a reference module to that module
 
     def __init__(self, shape_blocks=5, texture_blocks=5, pose_blocks=3, regress_blocks=3, latent_dim=256, pose_dim=16,
                  num_xyz_freq=10, num_dir_freq=4, norm_layer_type="BatchNorm2d", pose_shortcut=False, pred_wlh=False,
                  img_encoder: Optional[nn.Module] = None):
         super().__init__()
-        if img_encoder is not None:
+        self._check_shape(shape_blocks, texture_blocks, latent_dim, num_xyz_freq, num_dir_freq, latent_dim)
+        if img_encoder is None:
+            enc_cls, block = _resolve_ref_encoder(self._ref_module)
+            norm = nn.InstanceNorm2d if norm_layer_type == "InstanceNorm2d" else nn.BatchNorm2d
+            self.img_encoder = enc_cls(block, [3, 4, 6, 3], num_classes=latent_dim, norm_layer=norm, pred_wlh=pred_wlh)
+        elif img_encoder is not False:
             self.img_encoder = img_encoder
         W = latent_dim
         self.pose_shortcut, self.pred_wlh = pose_shortcut, pred_wlh
@@ -226,7 +394,7 @@ class SUPNeRF(_DecoderBase):
     def encode_img(self, img):
         """src/model_supnerf.py:218-224 (stock PyTorch)."""
         if not hasattr(self, "img_encoder"):
-            raise SnrError("SUPNeRF was built without an img_encoder (the ResNet encoder stays a stock PyTorch module)")
+            raise SnrError("this SUPNeRF was built with img_encoder=False (the ResNet encoder stays the caller's stock PyTorch module)")
         out = self.img_encoder(img, self.pose_shortcut)
         if self.pred_wlh:
             return out
@@ -241,3 +409,39 @@ class SUPNeRF(_DecoderBase):
         for j in range(1, self.regress_blocks):
             d = getattr(self, f"regress_layer_{j}")(d)
         return self.out_delta_layer(d)
+
+
+
+# ------------------------------------------------------------------------------------ the HIP forward on a reference class
+_GRAFTED = {}
+
+
+def hip_decoder_class(ref_cls):
+    """A subclass of one of the REFERENCE's own decoder classes -- ``SUPNeRF`` (src/model_supnerf.py:164), ``CodeNeRF``
+    (src/model_codenerf.py:13), ``AutoRFMix`` (src/model_autorf.py:190): the same layer names, hence the same ``forward`` text
+    (src/model_supnerf.py:241-269) -- whose constructor, state-dict, image encoder and pose head are the reference's and whose
+    ``forward`` / ``fused_render`` are this package's.  ``supnerf_amd.install`` puts these into the caller's modules, so that
+    ``SUPNeRF(**hpams['net_hyperparams'])`` + strict ``load_state_dict`` + ``encode_img`` + ``pose_update`` + ``nn.DataParallel`` run
+    unchanged.  Nothing of the reference is stored: the class is built from the caller's class object at run time."""
+    if isinstance(ref_cls, type) and issubclass(ref_cls, _DecoderBase):
+        return ref_cls
+    hit = _GRAFTED.get(ref_cls)
+    if hit is not None:
+        return hit
+
+    def __init__(self, *args, **kwargs):
+        ref_cls.__init__(self, *args, **kwargs)
+        lin = self.encoding_xyz[0]
+        W, d_xyz = lin.out_features, lin.in_features
+        d_dir = self.encoding_viewdir[0].in_features - W
+        n_lat = self.shape_blocks + self.texture_blocks
+        latent_dim = getattr(self, "shape_latent_layer_1" if self.shape_blocks else "texture_latent_layer_1")[0].in_features if n_lat else W
+        self._check_shape(self.shape_blocks, self.texture_blocks, W, (d_xyz - 3) // 6, (d_dir - 3) // 6, latent_dim)
+        self._init_hip_state()
+
+    cls = type(ref_cls.__name__, (_DecoderBase, ref_cls), {
+        "__init__": __init__, "__module__": ref_cls.__module__, "__qualname__": ref_cls.__qualname__,
+        "__doc__": f"{ref_cls.__module__}.{ref_cls.__name__} with supnerf_amd's HIP forward (supnerf_amd.model.hip_decoder_class).",
+        "__supnerf_amd_original__": ref_cls})
+    _GRAFTED[ref_cls] = cls
+    return cls

@@ -5,7 +5,9 @@ There is no CPU/eager fallback -- a CPU tensor raises."""
 import copy
 import ctypes as C
 import math
+import threading
 import warnings
+import weakref
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -48,6 +50,41 @@ def resolve_precision(precision, shape_blocks, texture_blocks, points_per_obj, b
         raise SnrError(f"precision {precision!r} is not available for shape_blocks={shape_blocks}, texture_blocks={texture_blocks}, "
                        f"{points_per_obj} points per object (needs <= 4 blocks in total and whole 32-point tiles per object)")
     return code
+
+
+PRECISION_NAMES = {FP32: "fp32", BF16X3: "bf16x3"}
+FP16_MAX = 65504.0
+# what the range guard of precision "auto" accepts between the split forward and the exact-fp32 forward of the same launch: |a - b| <=
+# RANGE_TOL * max(1, |b|) per value (measured distance of a healthy decoder: 6e-8 .. 1.6e-6)
+RANGE_TOL = 1e-5
+
+
+def precision_pair(precision, shape_blocks, texture_blocks, points_per_obj):
+    """(forward, backward) arithmetic names a launch pair with this request would run in."""
+    f = resolve_precision(precision, shape_blocks, texture_blocks, points_per_obj)
+    b = resolve_precision(precision, shape_blocks, texture_blocks, points_per_obj, backward=True)
+    return PRECISION_NAMES[f], PRECISION_NAMES[b]
+
+
+def split_supported(shape_blocks, texture_blocks, points_per_obj) -> bool:
+    return bool(_lib.lib().snr_precision_supported(BF16X3, shape_blocks, texture_blocks, int(points_per_obj)))
+
+
+def outputs_disagree(split_outs, exact_outs, tol=RANGE_TOL):
+    """0-dim device tensor: how many values of the split-arithmetic outputs are non-finite where the exact ones are finite, or further
+    than ``tol * max(1, |exact|)`` from them (one host read decides; the range guard of ``auto``)."""
+    bad = None
+    for a, b in zip(split_outs, exact_outs):
+        a, b = a.detach().reshape(-1), b.detach().reshape(-1)
+        fin = torch.isfinite(b)
+        n = ((~torch.isfinite(a)) & fin).sum() + (((a - b).abs() > tol * b.abs().clamp_min(1.0)) & fin).sum()
+        bad = n if bad is None else bad + n
+    return bad
+
+
+def clamped_weight_count(params) -> torch.Tensor:
+    """0-dim device tensor: entries of the per-point weights beyond the fp16 range -- the split forward packs them clamped to +-65504."""
+    return sum((p.detach().abs() > FP16_MAX).sum() for p in params)
 
 
 def _need_gpu(*ts):
@@ -672,17 +709,27 @@ def pe_points(xyz, viewdir):
 
 
 _PACK_CACHE = {}
+_PACK_LOCK = threading.Lock()
 
 
 def _packed_for(names, weights, shape_blocks, texture_blocks):
     """The packed stream of these per-point weights, re-packed only when a tensor changed (every optimiser step bumps the versions; an
-    evaluation pass between two steps, or a second forward before the update, re-uses the buffer)."""
-    key = (shape_blocks, texture_blocks) + tuple((w.data_ptr(), w._version, str(w.device)) for w in weights)
-    hit = _PACK_CACHE.get("k")
-    if hit is not None and hit[0] == key:
-        return hit[1]
+    evaluation pass between two steps, or a second forward before the update, re-uses the buffer).  One slot per device (DataParallel enters
+    from one thread per GPU).  A hit must PROVE identity: the entry holds weak references to the very tensors it was packed from, and
+    ``ref() is w`` is required for every one -- (data_ptr, _version) alone would also match a NEW model whose weights the caching
+    allocator placed at a freed model's addresses (same construction, same version counters), and the step would silently run on the
+    old model's weights."""
+    dev = (weights[0].device, torch.cuda.current_stream(weights[0].device).cuda_stream if weights[0].is_cuda else 0)   # (one slot per device AND stream)
+    key = (shape_blocks, texture_blocks) + tuple((w.data_ptr(), w._version) for w in weights)
+    with _PACK_LOCK:
+        hit = _PACK_CACHE.get(dev)
+        if hit is not None and hit[0] == key and len(hit[1]) == len(weights) and all(r() is w for r, w in zip(hit[1], weights)):
+            return hit[2]
     packed = pack_weights(dict(zip(names, weights)), shape_blocks, texture_blocks)
-    _PACK_CACHE["k"] = (key, packed)
+    with _PACK_LOCK:
+        while len(_PACK_CACHE) >= 16:
+            _PACK_CACHE.pop(next(iter(_PACK_CACHE)))
+        _PACK_CACHE[dev] = (key, [weakref.ref(w) for w in weights], packed)
     return packed
 
 
@@ -833,6 +880,21 @@ def reserve_rand_like(dev, numel):
     return seed, offset, threads
 
 
+def render_probe(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg, precision):
+    """The fused forward once more, without autograd and WITHOUT consuming the device generator (box sampling with in-kernel jitter draws
+    from the state the real launch is about to reserve): (rgb, depth, acc_trans) in ``precision``.  Used by the range guard of ``auto``."""
+    c = copy.copy(cfg)
+    c.precision = precision
+    with torch.no_grad():
+        if c.z_mode == Z_BOX and t_vals is None and c.rng is None:
+            dev = torch.device(rays_o.device)
+            gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+            off = gen.get_offset()
+            c.rng = reserve_rand_like(dev, rays_o.shape[0] * c.n_samples)
+            gen.set_offset(off)
+        return render_fwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, c)[:3]
+
+
 def fused_supported(n_samples: int) -> bool:
     """The single-launch render needs every ray inside one 128-point workgroup tile."""
     return 1 <= n_samples <= 128 and 128 % n_samples == 0
@@ -898,6 +960,27 @@ def render_fwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg: Re
     return rgb, depth, acc, sig, rgbs, masks
 
 
+def pad_render_inputs(rays_o, rays_d, t_vals, z_scale, cfg, B, n, n_pad):
+    """Every object's n rays padded to n_pad with dummy rays (whole 32-point wave tiles per object); returns the padded operands and a
+    copy of ``cfg`` for the padded launch.  Box sampling with in-kernel jitter (Z_BOX, no jitter tensor): the kernel's Philox stream is
+    indexed by the LAUNCH's point index, which padding shifts -- so the reference's draw, ``torch.rand_like`` of the caller's (N,S) table
+    (src/renderer.py:40: the same numbers and the same generator consumption), is materialised BEFORE padding and padded like any other
+    jitter table; seeded parity with the reference survives ragged ray counts."""
+    cfg = copy.copy(cfg)
+    if cfg.z_mode == Z_BOX and t_vals is None and cfg.rng is None:
+        t_vals = torch.rand(B * n, cfg.n_samples, device=rays_o.device)
+    rays_o, rays_d = _pad_rows(rays_o, B, n, n_pad), _pad_rows(rays_d, B, n, n_pad)
+    if cfg.z_mode in (Z_PER_RAY, Z_BOX) and t_vals is not None:
+        t_vals = _pad_rows(t_vals, B, n, n_pad)
+    if z_scale is not None and z_scale.numel() == B * n:
+        z_scale = _pad_rows(z_scale, B, n, n_pad)
+    cfg.rays_per_obj = n_pad
+    if cfg.z_mode == Z_BOX:             # (a dummy ray with direction 0 would divide 0 by 0 in the slab test: give it any unit direction)
+        rays_d = rays_d.clone()
+        rays_d.view(B, n_pad, 3)[:, n:, 2] = 1.0
+    return rays_o, rays_d, t_vals, z_scale, cfg
+
+
 class FusedRender(torch.autograd.Function):
     """rays -> (rgb, depth, acc_trans) in one launch; backward in one launch (+ a small reduction).  ``t_vals``: the depths in
     ``cfg.z_mode``'s layout; for Z_BOX the (N,S) jitter, or None (drawn in the kernel).  Gradients: rays_o, rays_d, latent always; t_vals for
@@ -916,15 +999,7 @@ class FusedRender(torch.autograd.Function):
         ctx.pad = (B, n, n_pad)
         cfg = copy.copy(cfg)                    # (the launch's generator state is recorded in it: one copy per call)
         if n_pad:
-            rays_o, rays_d = _pad_rows(rays_o, B, n, n_pad), _pad_rows(rays_d, B, n, n_pad)
-            if cfg.z_mode in (Z_PER_RAY, Z_BOX) and t_vals is not None:
-                t_vals = _pad_rows(t_vals, B, n, n_pad)
-            if z_scale is not None and z_scale.numel() == B * n:
-                z_scale = _pad_rows(z_scale, B, n, n_pad)
-            cfg.rays_per_obj = n_pad
-            if cfg.z_mode == Z_BOX:             # (a dummy ray with direction 0 would divide 0 by 0 in the slab test: give it any unit direction)
-                rays_d = rays_d.clone()
-                rays_d.view(B, n_pad, 3)[:, n:, 2] = 1.0
+            rays_o, rays_d, t_vals, z_scale, cfg = pad_render_inputs(rays_o, rays_d, t_vals, z_scale, cfg, B, n, n_pad)
         rgb, depth, acc, sig, rgbs, masks = render_fwd(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, cfg, save_for_bwd=need)
         if need:
             ctx.save_for_backward(rays_o, rays_d, t_vals, xyz_div, z_scale, latent, packed, sig, rgbs, masks)

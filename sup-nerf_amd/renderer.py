@@ -37,16 +37,14 @@ def _box_constants(obj_sz, B, dev):
     """(diag, box_half (B,3), z_scale (B,)) on ``dev`` for B objects of size obj_sz = (w, l, h), cached: the half extents
     (l, w, h) / diag and the frame scale diag / 2 of src/renderer.py:92-103 never change for an object."""
     sz = np.asarray(obj_sz)
-    key = (tuple(float(v) for v in sz.reshape(-1)), str(sz.dtype), int(B), str(dev))
+    key = (tuple(float(v) for v in sz.reshape(-1)), str(sz.dtype), int(B), U._stream_key(dev))
     hit = _BOX_CONST.get(key)
     if hit is None:
         diag = np.linalg.norm(sz).astype(np.float32)
         w, l, h = sz
         half = np.asarray([l / diag, w / diag, h / diag]).astype(np.float32)
-        hit = (diag, torch.from_numpy(half).to(dev)[None, :].repeat(B, 1).contiguous(), torch.full((B,), float(diag / 2), device=dev))
-        if len(_BOX_CONST) >= 64:
-            _BOX_CONST.pop(next(iter(_BOX_CONST)))
-        _BOX_CONST[key] = hit
+        hit = U._cache_put(_BOX_CONST, key, (diag, torch.from_numpy(half).to(dev)[None, :].repeat(B, 1).contiguous(),
+                                             torch.full((B,), float(diag / 2), device=dev)), limit=64)
     return hit
 
 

@@ -129,32 +129,35 @@ class GradBucket:
         self.flat.div_(world)
         if not self.rows:
             return
-        # every rank sends its unique touched rows, padded to the common length with index -1 (zero rows); one all-gather of the indices
-        # and one of the [table 0 | table 1 | ...] gradient rows
+        # Every rank sends the rows its batch touched -- B index slots and B gradient rows, B = this rank's batch size, known on the HOST
+        # (the ranks of a step hold equal slices) -- in one all-gather of the indices and one of the [table 0 | table 1 | ...] rows.  No
+        # device -> host read anywhere: a row touched twice holds the sum already and must travel once, so duplicates are blanked (index
+        # -1, zero payload) by a sort + first-occurrence mask of fixed length instead of torch.unique (dynamic size = a sync), and the
+        # common width is B itself instead of the gathered maximum of the unique counts (round 3: two syncs per step).
         dev = self.flat.device
-        uniq = torch.unique(self._touched)            # (a row touched twice holds the sum already: it must travel once)
-        n_mine = torch.tensor([uniq.numel()], device=dev, dtype=torch.int64)
-        sizes = [torch.zeros_like(n_mine) for _ in range(world)]
-        dist.all_gather(sizes, n_mine, group=self.group)
-        width = int(max(int(v) for v in sizes))
-        idx = torch.full((width,), -1, dtype=torch.int64, device=dev)
-        idx[:uniq.numel()] = uniq
-        cols = sum(p.shape[1] for p in self.rows)
-        payload = torch.zeros(width, cols, device=dev)
-        payload[:uniq.numel()] = torch.cat([p.grad[uniq] for p in self.rows], dim=1)
+        t = self._touched
+        width = int(t.numel())
+        srt, _ = torch.sort(t)
+        first = torch.ones_like(srt, dtype=torch.bool)
+        first[1:] = srt[1:] != srt[:-1]
+        idx = torch.where(first, srt, torch.full_like(srt, -1))
+        payload = torch.cat([p.grad[srt] for p in self.rows], dim=1) * first[:, None].to(self.flat.dtype)
         all_idx = [torch.empty_like(idx) for _ in range(world)]
         all_rows = [torch.empty_like(payload) for _ in range(world)]
         dist.all_gather(all_idx, idx, group=self.group)
         dist.all_gather(all_rows, payload, group=self.group)
-        idx_cat, rows_cat = torch.cat(all_idx), torch.cat(all_rows)
-        keep = idx_cat >= 0
-        idx_cat, rows_cat = idx_cat[keep], rows_cat[keep]
+        # Rebuild the summed rows identically on every rank: one index_add_ PER RANK, in rank order.  Inside one rank's contribution every
+        # real index occurs once (the blanked slots point at row 0 with a zero payload: adding an exact zero commutes), so no atomic ever
+        # chooses the order of two non-zero addends -- a single index_add_ over the concatenation would (three ranks on one row would give
+        # replicas that differ in the last bit and drift apart: nothing re-synchronises the tables).
         off = 0
         for p in self.rows:
-            p.grad[uniq] = 0                                              # (this rank's own rows come back with everybody's)
-            p.grad.index_add_(0, idx_cat, rows_cat[:, off:off + p.shape[1]] / world)      # rank order: the same sum on every rank
+            p.grad[t] = 0                                                 # (this rank's own rows come back with everybody's)
+            for r in range(world):
+                p.grad.index_add_(0, all_idx[r].clamp_min(0), all_rows[r][:, off:off + p.shape[1]] / world)
             off += p.shape[1]
-        self._touched = torch.unique(idx_cat)
+        self._touched = torch.cat(all_idx).clamp_min(0)                    # (for zero(): duplicates and the blanked slots' row 0 are harmless there)
+        assert width == all_idx[0].numel()
 
 
 def learning_rates(hpams: dict, niter: int):

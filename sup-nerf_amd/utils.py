@@ -13,8 +13,10 @@ Differences in mechanism, not in results:
     jitter, ``np.random.permutation`` ray subset, ``random.uniform`` symmetry coin), so a seeded run
     consumes identical random numbers.
 """
+import contextlib
 import functools
 import random
+import threading
 
 import numpy as np
 import torch
@@ -31,20 +33,36 @@ from .ops import Z_PER_OBJECT, Z_PER_RAY, Z_SHARED
 # the pose) and the resized targets (src/utils.py:447-456 redoes the same bilinear resize per call).  Values are what the uncached
 # code computes; entries are keyed by content (K, roi, grid) or by tensor identity + version (crop, mask) and live on the device.
 _CAM_CACHE, _TGT_CACHE, _CACHE_MAX = {}, {}, 32
+# The render functions are entered from several threads at once (one per GPU under nn.DataParallel, src/trainer_unified_nuscenes.py:227-229;
+# one per stream in a caller's own thread pool): reads of these dictionaries are single ``dict.get`` calls (atomic), every
+# evict-and-insert runs under this lock, and entries are immutable tuples / tensors keyed by content, so a racing reader sees either the
+# old entry or the new one -- both correct.
+_CACHE_LOCK = threading.Lock()
 
 
-def _cache_put(cache, key, value):
-    if len(cache) >= _CACHE_MAX:
-        cache.pop(next(iter(cache)))
-    cache[key] = value
+def _cache_put(cache, key, value, limit=None):
+    with _CACHE_LOCK:
+        while len(cache) >= (limit or _CACHE_MAX):
+            cache.pop(next(iter(cache)), None)
+        cache[key] = value
     return value
+
+
+def _stream_key(device):
+    """Part of every device-cache key: the stream the entry was filled on.  A tensor another thread cached a moment ago on ITS stream may
+    not be written yet from the point of view of this thread's stream; entries are therefore per (device, stream) -- a thread on its own
+    stream fills its own (one more small launch, once)."""
+    d = torch.device(device) if not isinstance(device, torch.device) else device
+    if d.type != "cuda":
+        return (str(d), 0)
+    return (str(d), torch.cuda.current_stream(d).cuda_stream)
 
 
 def _cam_table(K, px, py, like, key=None):
     """[(px - cx)/fx, (py - cy)/fy, 1] as ``like``'s dtype on ``like``'s device (the first half of get_rays, src/utils.py:122-131)."""
     if key is not None:
         Kc = K.detach().cpu() if torch.is_tensor(K) and K.is_cuda else K          # (one host copy, not four scalar reads of a device tensor)
-        key = key + (tuple(float(v) for v in (Kc[0, 0], Kc[1, 1], Kc[0, 2], Kc[1, 2])), str(like.device), like.dtype)
+        key = key + (tuple(float(v) for v in (Kc[0, 0], Kc[1, 1], Kc[0, 2], Kc[1, 2])), _stream_key(like.device), like.dtype)
         hit = _CAM_CACHE.get(key)
         if hit is not None:
             return hit
@@ -54,8 +72,10 @@ def _cam_table(K, px, py, like, key=None):
 
 
 def _fusable_pose(c2w):
-    """The one-launch ray kernels take a single fp32 (3,4) / (4,4) pose that lives on the GPU."""
-    return torch.is_tensor(c2w) and c2w.is_cuda and c2w.dim() == 2 and c2w.shape[0] >= 3 and c2w.shape[1] == 4 and c2w.dtype == torch.float32
+    """The one-launch ray kernels take a single fp32 (3,4) pose that lives on the GPU.  A (4,4) pose takes the torch formulation: the
+    reference's sphere bounds are the norm of the WHOLE last column (``cam_pose[:, -1]``, src/utils.py:468), which for a homogeneous pose
+    includes the 1 -- the kernel computes |t| of the three translation entries only."""
+    return torch.is_tensor(c2w) and c2w.is_cuda and tuple(c2w.shape) == (3, 4) and c2w.dtype == torch.float32
 
 
 def _pixel_dirs(K, c2w, px, py, key=None):
@@ -119,16 +139,34 @@ def _linspace(start, end, steps, device):
     return torch.where(i < steps // 2, lo, hi)
 
 
-# test hook: a tensor here replaces every following jitter draw, a list is consumed one tensor per draw (parity tests inject
-# the reference's numbers)
+# Test hook: injected jitter instead of the generator draws (parity tests inject the reference's numbers).  A tensor replaces every
+# following draw, a list is consumed one tensor per draw.  ``jitter_override(...)`` is the re-entrant form: it is THREAD-LOCAL (two
+# threads rendering concurrently each see their own injection, or none) and restores on exit.  The module attribute ``JITTER_OVERRIDE`` is
+# the older process-wide form, kept for single-threaded test code; the thread-local value wins.
 JITTER_OVERRIDE = None
+_TLS = threading.local()
+_NOT_SET = object()
+
+
+@contextlib.contextmanager
+def jitter_override(value):
+    """``with utils.jitter_override(t): ...`` -- inject jitter for the calls of THIS thread inside the block."""
+    prev = getattr(_TLS, "jitter", _NOT_SET)
+    _TLS.jitter = value
+    try:
+        yield
+    finally:
+        _TLS.jitter = prev
 
 
 def _jitter_override():
-    global JITTER_OVERRIDE
-    if isinstance(JITTER_OVERRIDE, list):
-        return JITTER_OVERRIDE.pop(0) if JITTER_OVERRIDE else None
-    return JITTER_OVERRIDE
+    v = getattr(_TLS, "jitter", _NOT_SET)
+    if v is _NOT_SET:
+        v = JITTER_OVERRIDE
+    if isinstance(v, list):
+        with _CACHE_LOCK:
+            return v.pop(0) if v else None
+    return v
 
 
 def _shared_depths(near, far, n_samples, device, z_fixed=False, jitter=None):
@@ -200,18 +238,17 @@ _CONST_CACHE = {}
 
 def _const(value, n, device):
     """(n,) fp32 device tensor filled with ``value``, cached (object sizes do not change between the calls of a loop)."""
-    key = (float(value), int(n), str(device))
+    key = (float(value), int(n), _stream_key(device))
     t = _CONST_CACHE.get(key)
     if t is None:
-        if len(_CONST_CACHE) >= 256:
-            _CONST_CACHE.pop(next(iter(_CONST_CACHE)))
-        t = _CONST_CACHE[key] = torch.full((int(n),), float(value), device=device)
+        t = _cache_put(_CONST_CACHE, key, torch.full((int(n),), float(value), device=device), limit=256)
     return t
 
 
 def clear_caches():
     """Drop the cached camera tables, resized targets and per-object constants (they pin device memory)."""
-    _CAM_CACHE.clear(); _TGT_CACHE.clear(); _CONST_CACHE.clear()
+    with _CACHE_LOCK:
+        _CAM_CACHE.clear(); _TGT_CACHE.clear(); _CONST_CACHE.clear()
 
 
 def _draw_jitter(n_samples, device):
@@ -286,7 +323,7 @@ def volume_rendering_batch(sigmas, rgbs, z_vals):
 def _resize_to(img, mask_occ, im_sz, device):
     """``_resize`` + the move to ``device`` as (n,3) / (n,1) ray targets, cached per (crop, mask, size, device): the optimisers pass the
     same CPU crop in every iteration."""
-    key = (img.data_ptr(), img._version, tuple(img.shape), mask_occ.data_ptr(), mask_occ._version, tuple(mask_occ.shape), int(im_sz), str(device))
+    key = (img.data_ptr(), img._version, tuple(img.shape), mask_occ.data_ptr(), mask_occ._version, tuple(mask_occ.shape), int(im_sz), _stream_key(device))
     hit = _TGT_CACHE.get(key)
     # the cached targets are handed out as they are (a clone per call would be a launch per call): a caller that edits them in place --
     # reference-style code does, e.g. ``occ_pixels[occ_pixels < 0] = 0`` -- bumps their version counter, and the entry is rebuilt
@@ -307,7 +344,7 @@ def _pixel_targets(img, mask_occ, x_vec, y_vec, device):
         return img[y_vec, x_vec, :].to(device), mask_occ[y_vec, x_vec, :].to(device)
     xa, ya = np.asarray(x_vec), np.asarray(y_vec)
     key = ("pix", img.data_ptr(), img._version, tuple(img.shape), mask_occ.data_ptr(), mask_occ._version, tuple(mask_occ.shape),
-           xa.shape, hash(xa.tobytes()), hash(ya.tobytes()), str(device))
+           xa.shape, hash(xa.tobytes()), hash(ya.tobytes()), _stream_key(device))
     hit = _TGT_CACHE.get(key)
     if hit is not None and hit[0]() is img and hit[1]() is mask_occ and hit[2]._version == hit[4] and hit[3]._version == hit[5]:
         return hit[2], hit[3]

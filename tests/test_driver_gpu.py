@@ -318,6 +318,10 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["unit"] == "rays/s" and line["value"] > 0 and line["scaling"] == "weak"
+    # one record per rank, gathered over the communicator: which device every rank rendered on and at what rate on its own clock
+    assert [r["rank"] for r in line["ranks"]] == [0, 1] and all(r["rays_per_s"] > 0 and r["pci_bus_id"] for r in line["ranks"])
+    assert line["distinct_devices"] == min(2, torch.cuda.device_count())          # (gloo rehearsal on one card: both ranks report the same device)
+    assert line["roofline"]["traffic_measured_in_run"] is False
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3"])

@@ -109,7 +109,7 @@ def test_state_dict_names_match_reference(amd):
     m = amd.CodeNeRF(shape_blocks=3, texture_blocks=1)
     assert list(m.state_dict().keys()) == list(O.decoder_param_names(3, 1))
     m.load_state_dict(O.init_decoder_params(), strict=True)
-    s = amd.SUPNeRF(shape_blocks=3, texture_blocks=1, pose_blocks=3, regress_blocks=3)
+    s = amd.SUPNeRF(shape_blocks=3, texture_blocks=1, pose_blocks=3, regress_blocks=3, img_encoder=False)
     keys = list(s.state_dict().keys())
     assert keys[:28] == list(O.decoder_param_names(3, 1)) and "out_delta_layer.weight" in keys and "pose_layer_0.0.weight" in keys
     # pose head is stock torch
@@ -459,7 +459,7 @@ def test_m0_is_written_only_by_the_weight_ring(tmp_path):
 
 def test_reference_file_formats_round_trip(amd, tmp_path):
     """models.pth / codes+poses.pth with the reference's keys (src/trainer_unified_nuscenes.py:476-490, src/optimizer_nuscenes.py:1463-1476)."""
-    m = amd.SUPNeRF(shape_blocks=3, texture_blocks=1)
+    m = amd.SUPNeRF(shape_blocks=3, texture_blocks=1, img_encoder=False)
     g = torch.Generator().manual_seed(0)
     sc, tc = torch.randn(5, 256, generator=g), torch.randn(5, 256, generator=g)
     opt = torch.tensor([1., 0., 1., 1., 0.])
