@@ -14,6 +14,7 @@
 //     XOR-swizzled 16-byte slots -> conflict-free ds_read_b128) filled by LDS-DMA, shared by the 4 waves.
 //   * Bias / latent adds, ReLU, softplus, the 256->1 density head and the 128->3 colour head run on
 //     the VALU in the accumulator layout; the composite is a 64-lane product scan.
+#include <stdlib.h>
 #include "snr_mlp_core.hpp"
 #include "snr_host.hpp"
 
@@ -285,6 +286,15 @@ using namespace snr;
 int snr_bf16_supported_(int sb, int tb, long long points_per_obj);
 int snr_bf16_launch_fwd_(int mode, const DecoderIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
                          float* depth, float* acc, void* stream_);
+int snr_fp32_fwd16_launch_(int mode, const DecoderIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
+                           float* depth, float* acc, void* stream_);
+
+// The exact-fp32 forward runs on the two-waves-per-SIMD kernel (snr_mlp16.hip: v_mfma_f32_16x16x4_f32, 16 points per wave).  Diagnostic
+// switch for A/B timing only: SNR_FP32_FWD=32x32 in the environment selects this file's one-wave-per-SIMD kernel (32x32x2) instead.
+static bool fwd_use_32x32() {
+    static const bool v = [] { const char* e = getenv("SNR_FP32_FWD"); return e && e[0] == '3' && e[1] == '2'; }();
+    return v;
+}
 
 extern "C" {
 
@@ -311,6 +321,7 @@ int snr_decoder_fwd(const float* xyz, const float* viewdir, const float* latent,
         return snr_bf16_launch_fwd_(0, io, L, xyz, viewdir, g, nullptr, nullptr, nullptr, stream_);
     }
     if (precision != SNR_FP32) return SNR_E_ARG;
+    if (!fwd_use_32x32()) return snr_fp32_fwd16_launch_(0, io, L, xyz, viewdir, g, nullptr, nullptr, nullptr, stream_);
     const unsigned grid = (unsigned)((n_points + 127) / 128);
     decoder_fwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g, nullptr, nullptr, nullptr);
     return snr_check_launch_();
@@ -334,6 +345,7 @@ int snr_render_fwd(const snr_render_args* a, float* rgb, float* depth, float* ac
         return snr_bf16_launch_fwd_(1, io, L, nullptr, nullptr, g, rgb, depth, acc_trans, stream_);
     }
     if (a->precision != SNR_FP32) return SNR_E_ARG;
+    if (!fwd_use_32x32()) return snr_fp32_fwd16_launch_(1, io, L, nullptr, nullptr, g, rgb, depth, acc_trans, stream_);
     const unsigned grid = (unsigned)((P + 127) / 128);
     decoder_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g, rgb, depth, acc_trans);
     return snr_check_launch_();

@@ -1,0 +1,489 @@
+// Fused decoder forward for gfx950, exact fp32, TWO waves per SIMD: v_mfma_f32_16x16x4_f32 on 16 points per wave.
+//
+// Same path as snr_mlp.hip (positional encoding -> code-conditioned MLP on the fp32 MFMA pipe -> optional alpha composite, one
+// launch), same packed weight stream, same LDS map, same outputs and ReLU-bit layout.  What differs is the shape of the work:
+//
+//   * Workgroup = 8 waves = 128 consecutive sample points; wave w owns points 16 w .. 16 w + 15, TWO waves share a SIMD
+//     (__launch_bounds__(512, 2): at most 256 registers each).  The matrix pipe is per SIMD: whatever one wave does between its
+//     MFMAs -- bias into the accumulators, ReLU / latent add / ReLU bits of the previous layer, the density and colour heads, LDS
+//     waits -- runs while the partner wave's MFMAs keep the pipe busy.  With one 512-register wave per SIMD (snr_mlp.hip) that work
+//     was exposed: 7.6 % of the kernel at the layer boundaries, which five ways of hiding under the wave's OWN MFMAs did not recover
+//     (tools/_diag/experiments/README.md).
+//   * GEMMs transposed as before, Y^T = W X^T: the weight slice is the A operand, the wave's 16 points the B / C / D columns.
+//     v_mfma_f32_16x16x4_f32 (32 cycles, 64 FLOP/clk/SIMD like 32x32x2): accumulator register r of lane (n = lane & 15, g = lane >> 4)
+//     of tile T holds feature 16 T + 4 g + r of point n -- which is the B operand of the NEXT layer's k-slice {16 T + 4 g' + r : g'}
+//     when the matching A fragment (row m = lane & 15, k = 16 T + 4 g .. + 3) is fetched with ONE ds_read_b128: the accumulators of
+//     layer l are the B operands of layer l + 1 with no data movement, as in the 32x32 kernel.  That fragment is 16 consecutive bytes
+//     of the EXISTING packed image (row-major 128-byte rows, 16-byte slots XOR-swizzled by (row >> 1) & 7) and the 64 lanes' reads are
+//     bank-conflict free on it (checked for all four ds_read_b128 lane groups), so snr_pack_weights is unchanged.
+//   * Layers run k-outer over the previous layer's tiles: input tile T of layer l + 1 is made from accumulator tile T of layer l
+//     (ReLU, latent add, ReLU bits, optional activation dump) just before its 64 MFMAs; two accumulator sets (previous layer's
+//     values, current sums: 64 + 64 registers), the last k-step deposits the finished tiles in the dead previous set.
+//   * One 32 KiB weight chunk (32 k) = two input tiles = 128 MFMAs per wave; ring of two buffers, one barrier per chunk as before.
+//
+// The fma chain of an output differs from the 32x32x2 kernel's in the ORDER of the k terms (a 16x16x4 MFMA sums k = 16 T + {r, 4 + r,
+// 8 + r, 12 + r}, the 32x32x2 form k = 32 c + 8 j + {e, 4 + e}): both are exact fp32 fma chains over the same products, results agree
+// to fp32 round-off, not bit for bit.
+#include "snr_mlp_core.hpp"
+#include "snr_host.hpp"
+
+namespace snr {
+
+constexpr int PE_WAVE16 = 16 * PE_ROW;               // per-wave scratch: 16 points (8 waves x 16 = the 32x32 kernel's 4 x 32)
+constexpr int LDS_ZERO16 = LDS_TOTAL;                // 256 zero floats: the latent row of a layer without one, the head weights of a layer without a head
+constexpr int LDS_TOTAL16 = LDS_TOTAL + 256;
+static_assert(LDS_TOTAL16 * 4 <= 160 * 1024, "LDS budget");
+
+// 512 threads stage `rows` x 128 B (rows a multiple of 64): linear LDS-DMA copy, 1 KiB per wave-instruction
+__device__ __forceinline__ void chunk_dma16(const float* __restrict__ g, float* lds, int rows, int tid) {
+    const int nvec = rows * 8;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i * 512 < nvec) {
+            typedef const __attribute__((address_space(1))) void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + (size_t)(i * 512 + tid) * 4), (lptr_t)(lds + (i * 512 + wave * 64) * 4), 16, 0, 0);
+        }
+    }
+}
+
+// piece i (64 rows = 8 KiB: one 1 KiB LDS-DMA instruction per wave) of a chunk
+__device__ __forceinline__ void chunk_piece16(const float* __restrict__ g, float* lds, int i, int tid) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    __builtin_amdgcn_global_load_lds((gptr_t)(g + (size_t)(i * 512 + tid) * 4), (lptr_t)(lds + (i * 512 + wave * 64) * 4), 16, 0, 0);
+}
+
+struct Ring16 {
+    int cur;             // LDS buffer holding the chunk about to be consumed
+    int aoff[2];         // this lane's float offset of the 16-byte slot (4 dT + kg) of row m in a chunk, swizzle applied (dT = 0, 1)
+};
+
+// What happens to a finished accumulator tile of the PREVIOUS layer on its way into the current layer's B operand.
+struct Epi {
+    float lo;                 // ReLU floor: 0, or -inf for the layer without an activation
+    const float* zlds;        // LATLDS: LDS row of the latent term added after the activation (the zero row if none)
+    const float* zglb;        // !LATLDS: this lane's global latent row, or null
+    const float* wsig;        // LDS: density-head weights when the tile belongs to enc_shape's output, else the zero row
+    float* dump;              // training: this lane's row of the activation dump ([point][256] + 4 g), or null
+};
+struct EpiRegs { f32x4 z, ws; };     // what a tile's epilogue reads from LDS, requested a tile ahead
+
+__device__ __forceinline__ uint32_t spread_nibbles(uint32_t m16) {
+    // nibble of input tile dT (shifted in first = highest) -> bits 8 dT .. 8 dT + 3
+    return ((m16 >> 12) & 0xFu) | (((m16 >> 8) & 0xFu) << 8) | (((m16 >> 4) & 0xFu) << 16) | ((m16 & 0xFu) << 24);
+}
+
+template <bool LATLDS>
+__device__ __forceinline__ EpiRegs epi_load(const Epi& c, int T, int g) {
+    EpiRegs e;
+    e.z = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (LATLDS) e.z = *reinterpret_cast<const f32x4*>(c.zlds + 16 * T + 4 * g);
+    else if (c.zglb) e.z = *reinterpret_cast<const f32x4*>(c.zglb + 16 * T + 4 * g);
+    e.ws = *reinterpret_cast<const f32x4*>(c.wsig + 16 * T + 4 * g);
+    return e;
+}
+
+// one value of accumulator tile T of the previous layer -> B-operand register r of input tile T (feature 16 T + 4 g + r): ReLU (or none),
+// ReLU bit (shifted in: call with r = 3, 2, 1, 0), the density head's term, the latent add.  Five VALU instructions, placed by the caller
+// BETWEEN the MFMA groups of the tile before (see layer_from_acc).
+template <bool MASKS>
+__device__ __forceinline__ void epi_value(const f32x4& acc, f32x4& x, const Epi& c, const EpiRegs& e, int r, uint32_t& m16, float& sig_part) {
+    float hi = __builtin_inff();
+    asm volatile("" : "+v"(hi));          // (a literal +inf would be rewritten as canonicalise + v_max)
+    float v = acc[r];
+    if (MASKS) m16 = __builtin_amdgcn_alignbit(m16, __float_as_uint(0.f - v), 31);      // bit = (v > 0): the sign of 0 - v (+0 and -0 give 0)
+    v = __builtin_amdgcn_fmed3f(v, c.lo, hi);
+    sig_part = fmaf(e.ws[r], v, sig_part);               // (density head: on enc_shape's raw output, no latent follows that layer)
+    x[r] = v + e.z[r];
+    // pinned here: left alone the compiler sinks the head's fma chain (and the bit collection) to the end of the layer and spills every
+    // activation and head weight it will need there
+    asm volatile("" : "+v"(sig_part));
+    if (MASKS) asm volatile("" : "+v"(m16));
+}
+
+#define SNR16_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xc07f)       /* s_waitcnt lgkmcnt(0), as an instruction the compiler's own wait insertion sees */
+
+// 64 MFMAs of one input tile: accC[t] += W[16 t .. 16 t + 15][k-slices of the tile] * x, tiles taken in pairs so that two MFMAs on the same
+// accumulator are two issues apart (dependent latency 40 cycles > the 32-cycle issue); LAST: the finished sums go to accD (the dead previous set).
+// Fragment pipeline: (a0, a1) = the tile's first pair, REQUESTED by the caller; every pair is waited for at the top of its group -- at that
+// point only that pair is outstanding, requested a whole group (>= 256 cycles) earlier -- and the next pair (the next TILE's first pair from
+// `wnext` at the end) is requested before the group's eight MFMAs.  Left to the compiler, the request follows the MFMAs and the wait
+// (lgkmcnt(0), not a counted one) sits right behind the request: an LDS round trip exposed per group in both waves of the SIMD at once.
+struct NoBetween { __device__ __forceinline__ void operator()(int) const {} };
+template <int NT, bool LAST, class Between = NoBetween>
+__device__ __forceinline__ void tile_mma(f32x4 (&accC)[16], f32x4 (&accD)[16], const f32x4& x, const float* wrow /* chunk + aoff[dT] */,
+                                         f32x4& a0, f32x4& a1, const float* wnext, Between&& between = NoBetween()) {
+#pragma unroll
+    for (int t = 0; t < NT; t += 2) {
+        SNR16_WAIT_LDS();
+        f32x4 n0 = a0, n1 = a1;
+        if (t + 2 < NT) {
+            n0 = *reinterpret_cast<const f32x4*>(wrow + (t + 2) * 16 * KC);
+            n1 = *reinterpret_cast<const f32x4*>(wrow + (t + 3) * 16 * KC);
+        } else if (wnext) {
+            n0 = *reinterpret_cast<const f32x4*>(wnext);
+            n1 = *reinterpret_cast<const f32x4*>(wnext + 16 * KC);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (LAST && r == 3) {
+                accD[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], x[r], accC[t], 0, 0, 0);
+                accD[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], x[r], accC[t + 1], 0, 0, 0);
+            } else {
+                accC[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], x[r], accC[t], 0, 0, 0);
+                accC[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], x[r], accC[t + 1], 0, 0, 0);
+            }
+        }
+        // the group's slice of non-matrix work, in program order BEHIND its eight MFMAs: it issues while they -- and the partner wave's --
+        // occupy the matrix pipe (an in-order wave reaches its next MFMA >= 64 cycles later with two waves per SIMD)
+        between(t / 2);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = n0; a1 = n1;
+    }
+}
+
+__device__ __forceinline__ void first_pair(f32x4& a0, f32x4& a1, const float* wrow) {
+    a0 = *reinterpret_cast<const f32x4*>(wrow);
+    a1 = *reinterpret_cast<const f32x4*>(wrow + 16 * KC);
+}
+
+__device__ __forceinline__ void ring_turn(Ring16& p) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    p.cur ^= 1;
+}
+
+template <int NT>
+__device__ __forceinline__ void acc_from_bias(f32x4 (&acc)[16], const float* bias /* LDS, layer's row */, int g) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(bias + 16 * t + 4 * g);
+}
+
+// One layer whose K = 256 inputs are the previous layer's accumulators accP: NT output tiles (16: 256 rows; 8: rgb.0), chunks
+// base + 0 .. 7 of the stream.  `pre` (uniform; enc_viewdir): the layer also has a chunk of explicit operand tiles xe (the direction
+// features) -- chunk 8 of its stream, consumed FIRST, so that the last MFMA step of every layer is the same deposit into accP (with the
+// extra chunk behind the eight, the merge of the two ends of the layer cost 48 spilled registers).  On entry the layer's first chunk
+// (the direction chunk if `pre`) is in the current buffer; at its last chunk the layer requests `next_first` (next_rows rows; 0 = the
+// stream ends).  On return accP holds this layer's sums (bias included, no activation yet).
+template <int NT, bool LATLDS, bool MASKS, bool DUMP>
+__device__ __forceinline__ void layer_from_acc(f32x4 (&accP)[16], Ring16& ring, float* lds, const float* bias, const Epi& c, int g, int tid,
+                                               const float* base, bool pre, const f32x4 (&xe)[2], const float* next_first, int next_rows,
+                                               uint32_t (&mw)[4], float& sig_part) {
+    f32x4 accC[16];
+    f32x4 a0, a1;
+    constexpr int rows_mid = NT * 16;
+    constexpr int chunk_floats = rows_mid * KC;
+    if (pre) {
+        chunk_dma16(base, lds + (ring.cur ^ 1) * WBUF, rows_mid, tid);
+        const float* wb = lds + ring.cur * WBUF;
+        first_pair(a0, a1, wb + ring.aoff[0]);
+        acc_from_bias<NT>(accC, bias, g);
+        tile_mma<NT, false>(accC, accP, xe[0], wb + ring.aoff[0], a0, a1, wb + ring.aoff[1]);
+        tile_mma<NT, false>(accC, accP, xe[1], wb + ring.aoff[1], a0, a1, nullptr);
+        ring_turn(ring);
+    } else {
+        acc_from_bias<NT>(accC, bias, g);
+    }
+    // Input tile T's four operand registers are made from accP[T] while tile T - 1's MFMAs run: one value (five VALU instructions) behind
+    // every second MFMA group of that tile, its latent / head-weight rows requested behind the first group; the LDS-DMA pieces of the next
+    // chunk go out one per group as well.  Nothing but the tile's own MFMAs then stands between two tiles -- with the previous form (whole
+    // epilogue + four DMA pieces at the top of a tile) both waves of a SIMD, which run this program in lockstep, left the matrix pipe idle
+    // together.  Only the layer's first tile is made up front.
+    constexpr int NG = NT / 2;                   // MFMA groups per tile
+    EpiRegs e = epi_load<LATLDS>(c, 0, g);
+    f32x4 xa, xb;
+    uint32_t m16 = 0u;
+#pragma unroll
+    for (int r = 3; r >= 0; --r) epi_value<MASKS>(accP[0], xa, c, e, r, m16, sig_part);
+    if (DUMP) *reinterpret_cast<f32x4*>(c.dump) = xa;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        const float* src = (ch < 7) ? base + (ch + 1) * chunk_floats : next_first;
+        const int rows = (ch < 7) ? rows_mid : next_rows;
+        float* const dst = lds + (ring.cur ^ 1) * WBUF;
+        const float* wb = lds + ring.cur * WBUF;
+        first_pair(a0, a1, wb + ring.aoff[0]);
+        // first tile of the chunk (T = 2 ch) on xa; between its groups: the next chunk's DMA pieces and tile 2 ch + 1's operand
+        tile_mma<NT, false>(accC, accP, xa, wb + ring.aoff[0], a0, a1, wb + ring.aoff[1], [&](int gi) {
+            if (gi == 0) e = epi_load<LATLDS>(c, 2 * ch + 1, g);
+            if ((gi & 1) == 0 && (gi >> 1) * 64 < rows) chunk_piece16(src, dst, gi >> 1, tid);
+#pragma unroll
+            for (int k = (gi * 4) / NG; k < ((gi + 1) * 4) / NG; ++k) epi_value<MASKS>(accP[2 * ch + 1], xb, c, e, 3 - k, m16, sig_part);
+            if (DUMP && gi == NG - 1) *reinterpret_cast<f32x4*>(c.dump + 16 * (2 * ch + 1)) = xb;
+        });
+        if (ch & 1) { mw[ch >> 1] = m16; m16 = 0u; }
+        // second tile (T = 2 ch + 1) on xb; between its groups: tile 2 ch + 2's operand (the next chunk's first tile)
+        if (ch == 7) {
+            tile_mma<NT, true>(accC, accP, xb, wb + ring.aoff[1], a0, a1, nullptr);
+        } else {
+            tile_mma<NT, false>(accC, accP, xb, wb + ring.aoff[1], a0, a1, nullptr, [&](int gi) {
+                if (gi == 0) e = epi_load<LATLDS>(c, 2 * ch + 2, g);
+#pragma unroll
+                for (int k = (gi * 4) / NG; k < ((gi + 1) * 4) / NG; ++k) epi_value<MASKS>(accP[2 * ch + 2], xa, c, e, 3 - k, m16, sig_part);
+                if (DUMP && gi == NG - 1) *reinterpret_cast<f32x4*>(c.dump + 16 * (2 * ch + 2)) = xa;
+            });
+        }
+        ring_turn(ring);
+    }
+}
+
+// the lane's 64 ReLU bits of a layer (4 words x 16 bits: nibbles of input tiles 4 w .. 4 w + 3) -> the documented layout (snr_layout.h: per
+// 32-point tile [layer][lane (p, h)] uint4, word w bit 16 (t & 1) + 4 j + e <-> feature 32 t + 8 j + 4 h + e) and stored.  Feature 16 T + 4 g + r
+// is bit 8 (T & 3) + 4 (g >> 1) + r of word T >> 2 of lane (p, h = g & 1): lanes g and g ^ 2 (= lane ^ 32) hold the two nibble columns.
+__device__ __forceinline__ void store_masks16x4(uint4* __restrict__ dst /* tile's [64] uint4 of this layer */, const uint32_t (&mw)[4], int wave, int lane) {
+    const int n = lane & 15, g = lane >> 4;
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t mine = spread_nibbles(mw[i]) << (4 * (g >> 1));
+        w[i] = mine | (uint32_t)__shfl_xor((int)mine, 32, 64);
+    }
+    if (g < 2) dst[16 * (wave & 1) + n + 32 * g] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int MODE, bool LATLDS, bool MASKS, bool DUMP>
+__global__ void __launch_bounds__(512, 2)
+decoder_fwd16_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom gm,
+                     float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_acc) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_TOTAL16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    const long long tile128 = blockIdx.x;
+    const long long gp_raw = tile128 * 128 + wave * 16 + n;
+    const bool live = gp_raw < io.n_points;
+    const long long gp = live ? gp_raw : io.n_points - 1;
+    const long long tile32 = tile128 * 4 + (wave >> 1);
+    const bool tile_live = tile32 * 32 < io.n_points;
+    const int sb = io.sb, tb = io.tb;
+    const int n_relu = n_relu_layers(sb, tb);
+    float px, py, pz, dx, dy, dz, zc = 0.f;
+    if (MODE == 0) {
+        px = xyz[gp * 3]; py = xyz[gp * 3 + 1]; pz = xyz[gp * 3 + 2];
+        dx = viewdir[gp * 3]; dy = viewdir[gp * 3 + 1]; dz = viewdir[gp * 3 + 2];
+    } else {
+        const long long ray = gp / gm.S;
+        const SamplePoint sp = make_sample(gm, ray, (int)(gp - ray * gm.S));
+        px = sp.x; py = sp.y; pz = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc;
+    }
+    const float* bias = lds + LDS_BIAS;
+    const float* heads = bias + L.n_mfma_layers * 256;       // sigma_w (256) | sigma_b | rgb2_w (384) | rgb2_b, as in the packed stream
+    const float* zero = lds + LDS_ZERO16;
+    const float* lat_lane = io.latent + (gp / io.points_per_obj) * (long long)L.n_lat * 256;       // (!LATLDS: the lane's own object)
+    const float* lat_wg = io.latent + ((tile128 * 128) / io.points_per_obj) * (long long)L.n_lat * 256;
+
+    // ---- prologue: first weight chunk, biases + heads (+ latent rows) by LDS-DMA while the positional encodings are computed
+    Ring16 ring;
+    ring.cur = 0;
+    {
+        const int sw = (n >> 1) & 7;
+        ring.aoff[0] = n * KC + (((0 + g) ^ sw) << 2);
+        ring.aoff[1] = n * KC + (((4 + g) ^ sw) << 2);
+    }
+    // the forward stream (snr_layout.h): enc_xyz 2 chunks, then 8 per 256-wide layer (9 for enc_viewdir: the direction chunk is its ninth),
+    // rgb.0's 8 chunks of 128 rows.  A layer's FIRST consumed chunk is its chunk 0 -- enc_viewdir's is the direction chunk.
+    constexpr long long C256 = 256 * KC;
+    const int li_encshape = sb + 1, li_view = sb + 2, li_last = sb + tb + 2;
+    const float* const stream = io.packed + L.fwd;
+    auto layer_base = [&](int li) { return stream + 2 * C256 + (long long)(li - 1) * 8 * C256 + (li > li_view ? C256 : 0); };      // li = 1 .. li_last + 1
+    auto layer_first = [&](int li) { return layer_base(li) + (li == li_view ? 8 * C256 : 0); };
+    f32x4 xin[4], xd[2];
+    {
+        chunk_dma16(stream, lds, 256, tid);
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        for (int r = wave; r < L.n_mfma_layers + 3; r += 8)
+            __builtin_amdgcn_global_load_lds((gptr_t)(io.packed + L.bias + r * 256 + lane * 4), (lptr_t)(lds + LDS_BIAS + r * 256), 16, 0, 0);
+        if (LATLDS)
+            for (int r = wave; r < L.n_lat; r += 8)
+                __builtin_amdgcn_global_load_lds((gptr_t)(lat_wg + r * 256 + lane * 4), (lptr_t)(lds + LDS_LAT + r * 256), 16, 0, 0);
+        if (tid < 64) *reinterpret_cast<f32x4*>(lds + LDS_ZERO16 + 4 * tid) = f32x4{0.f, 0.f, 0.f, 0.f};
+        float* sc = lds + LDS_SCRATCH + wave * PE_WAVE16 + n * PE_ROW;
+        // 30 (frequency, axis) pairs of the xyz encoding, 8 per lane group (the fourth takes 6); 12 of the direction encoding, 3 each
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+            const int q = 8 * g + i;
+            if (q < 3 * XYZ_FREQ) {
+                float sn, cs;
+                pe_sincos(ldexpf(pick3(px, py, pz, q % 3), q / 3), &sn, &cs);
+                sc[3 + q] = sn; sc[3 + 3 * XYZ_FREQ + q] = cs;
+            }
+        }
+#pragma unroll 1
+        for (int i = 0; i < 3; ++i) {
+            const int q = 3 * g + i;
+            float sn, cs;
+            pe_sincos(ldexpf(pick3(dx, dy, dz, q % 3), q / 3), &sn, &cs);
+            sc[64 + 3 + q] = sn; sc[64 + 3 + 3 * DIR_FREQ + q] = cs;
+        }
+        if (g == 0) {
+            sc[0] = px; sc[1] = py; sc[2] = pz; sc[63] = 0.f;
+            sc[64] = dx; sc[65] = dy; sc[66] = dz;
+#pragma unroll
+            for (int f = D_DIR; f < 32; ++f) sc[64 + f] = 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // B-operand registers: register r of input tile T <- feature 16 T + 4 g + r of the lane's point
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xin[T][r] = sc[16 * T + 4 * g + r];
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xd[T][r] = sc[64 + 16 * T + 4 * g + r];
+    }
+
+    // ---- enc_xyz: 64 -> 256 from explicit operand tiles (two chunks)
+    f32x4 accP[16];
+    {
+        f32x4 accC[16];
+        f32x4 a0, a1;
+        acc_from_bias<16>(accC, bias, g);
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            chunk_dma16(ch == 0 ? stream + C256 : layer_first(1), lds + (ring.cur ^ 1) * WBUF, 256, tid);
+            const float* wb = lds + ring.cur * WBUF;
+            first_pair(a0, a1, wb + ring.aoff[0]);
+            tile_mma<16, false>(accC, accP, xin[2 * ch], wb + ring.aoff[0], a0, a1, wb + ring.aoff[1]);
+            if (ch == 1) tile_mma<16, true>(accC, accP, xin[2 * ch + 1], wb + ring.aoff[1], a0, a1, nullptr);
+            else tile_mma<16, false>(accC, accP, xin[2 * ch + 1], wb + ring.aoff[1], a0, a1, nullptr);
+            ring_turn(ring);
+        }
+    }
+
+    // ---- the 256-wide middle layers (shape blocks, enc_shape, enc_viewdir, texture blocks): layer li consumes layer li - 1's sums
+    uint32_t mw[4] = {0u, 0u, 0u, 0u};
+    float sig_part = 0.f, o_sigma = 0.f;
+    // training dumps: a lane past the end holds the LAST point (gp is clamped), i.e. the same values as that point's own lane: its stores
+    // repeat that lane's bytes at that lane's address, so no per-lane predicate (= no divergent branch per tile) is needed
+    float* const dump_lane = DUMP ? io.act + gp * 256 + 4 * g : nullptr;
+    auto epi_of = [&](int lp) {          // the epilogue applied to the OUTPUT of layer lp on its way into layer lp + 1
+        const int la = latent_after(lp, sb, tb);
+        Epi c;
+        c.lo = (lp != li_encshape) ? 0.f : -__builtin_inff();
+        c.zlds = (la >= 0) ? lds + LDS_LAT + la * 256 : zero;
+        c.zglb = (la >= 0) ? lat_lane + la * 256 : nullptr;
+        c.wsig = (lp == li_encshape) ? heads : zero;
+        c.dump = DUMP ? dump_lane + (long long)lp * io.n_points * 256 : nullptr;
+        return c;
+    };
+    auto after_layer_input = [&](int lp) {      // ReLU bits of layer lp (collected while it was consumed) and the density head
+        if (MASKS && lp != li_encshape && tile_live) store_masks16x4(io.masks + (tile32 * n_relu + relu_slot(lp, sb)) * 64, mw, wave, lane);
+        if (lp == li_encshape) {
+            // density head: softplus(w_sigma . y + b) (src/model_supnerf.py:257); the lane groups hold a quarter of the features each
+            float s = sig_part;
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const float pre = s + heads[L.sigma_b - L.sigma_w];
+            o_sigma = pre > 20.f ? pre : log1pf(expf(pre));
+        }
+    };
+#pragma unroll 1
+    for (int li = 1; li <= li_last; ++li) {
+        const int lp = li - 1;
+        const Epi c = epi_of(lp);
+        if (lp == li_encshape) sig_part = 0.f;
+        layer_from_acc<16, LATLDS, MASKS, DUMP>(accP, ring, lds, bias + li * 256, c, g, tid, layer_base(li), li == li_view, xd, layer_first(li + 1),
+                                                (li == li_last) ? 128 : 256, mw, sig_part);
+        after_layer_input(lp);
+    }
+    {   // rgb.0: 256 -> 128
+        const Epi c = epi_of(li_last);
+        if (li_last == li_encshape) sig_part = 0.f;
+        layer_from_acc<8, LATLDS, MASKS, DUMP>(accP, ring, lds, bias + (li_last + 1) * 256, c, g, tid, layer_base(li_last + 1), false, xd, nullptr, 0, mw, sig_part);
+        after_layer_input(li_last);
+    }
+
+    // ---- rgb.0's output (accP tiles 0..7): ReLU + bits, then rgb.2 (128 -> 3) on the VALU
+    float o_r, o_g, o_b;
+    {
+        const float* w2 = heads + (L.rgb2_w - L.sigma_w);
+        float pr = 0.f, pg = 0.f, pb = 0.f;
+        uint32_t m16 = 0u, mr[4] = {0u, 0u, 0u, 0u};
+        float* const dmp = DUMP ? dump_lane + (long long)(li_last + 1) * io.n_points * 256 : nullptr;
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+            const f32x4 wr = *reinterpret_cast<const f32x4*>(w2 + 16 * T + 4 * g);
+            const f32x4 wg = *reinterpret_cast<const f32x4*>(w2 + 128 + 16 * T + 4 * g);
+            const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + 16 * T + 4 * g);
+            f32x4 xv;
+#pragma unroll
+            for (int r = 3; r >= 0; --r) {
+                float v = accP[T][r];
+                m16 = __builtin_amdgcn_alignbit(m16, __float_as_uint(0.f - v), 31);
+                v = fmaxf(v, 0.f);
+                xv[r] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pr = fmaf(wr[r], xv[r], pr); pg = fmaf(wg[r], xv[r], pg); pb = fmaf(wb[r], xv[r], pb); }
+            if (DUMP) *reinterpret_cast<f32x4*>(dmp + 16 * T) = xv;
+            if ((T & 3) == 3) { mr[T >> 2] = m16; m16 = 0u; }
+        }
+        if (MASKS && tile_live) store_masks16x4(io.masks + (tile32 * n_relu + (n_relu - 1)) * 64, mr, wave, lane);
+        pr += __shfl_xor(pr, 16, 64); pr += __shfl_xor(pr, 32, 64);
+        pg += __shfl_xor(pg, 16, 64); pg += __shfl_xor(pg, 32, 64);
+        pb += __shfl_xor(pb, 16, 64); pb += __shfl_xor(pb, 32, 64);
+        const float* b2 = heads + (L.rgb2_b - L.sigma_w);
+        o_r = pr + b2[0]; o_g = pg + b2[1]; o_b = pb + b2[2];
+    }
+
+    if (live && g == 0) {
+        if (io.sigmas) io.sigmas[gp] = o_sigma;
+        if (io.rgbs) { io.rgbs[gp * 3] = o_r; io.rgbs[gp * 3 + 1] = o_g; io.rgbs[gp * 3 + 2] = o_b; }
+    }
+    if (MODE == 1) {
+        float* comp = lds + LDS_COMP;
+        if (g == 0) {
+            float* c = comp + (wave * 16 + n) * COMP_STRIDE;
+            c[0] = o_sigma; c[1] = o_r; c[2] = o_g; c[3] = o_b; c[4] = zc;
+        }
+        __syncthreads();
+        const int S = gm.S;
+        const int rays_here = 128 / S;           // host guarantees 128 % S == 0
+        const bool white = gm.flags & SNR_WHITE_BKGD;
+        for (int r = wave; r < rays_here; r += 8) {
+            const long long ray = tile128 * rays_here + r;
+            if (ray >= gm.n_rays) break;
+            const float* c0 = comp + r * S * COMP_STRIDE;
+            RayOut o = composite_ray_fwd(S, lane, white, [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
+                const float* c = c0 + k * COMP_STRIDE;
+                s_ = c[0]; r_ = c[1]; g_ = c[2]; b_ = c[3]; z_ = c[4];
+                zn_ = (k < S - 1) ? c[COMP_STRIDE + 4] : 0.f;
+            });
+            if (lane == 0) {
+                out_rgb[ray * 3] = o.r; out_rgb[ray * 3 + 1] = o.g; out_rgb[ray * 3 + 2] = o.b;
+                out_depth[ray] = o.depth; out_acc[ray] = o.acc;
+            }
+        }
+    }
+}
+
+}  // namespace snr
+
+using namespace snr;
+
+// mode 0: explicit points; mode 1: fused render.  The workgroup's latent rows are staged in LDS when its 128 points belong to ONE object
+// (points per object a multiple of 128) and the table has at most LDS_LAT_ROWS rows: every shipped configuration.
+int snr_fp32_fwd16_launch_(int mode, const DecoderIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
+                           float* depth, float* acc, void* stream_) {
+    const unsigned grid = (unsigned)((io.n_points + 127) / 128);
+    const bool latlds = (io.points_per_obj % 128) == 0 && L.n_lat <= LDS_LAT_ROWS;
+    hipStream_t st = (hipStream_t)stream_;
+    const bool masks = io.masks != nullptr;
+    if (io.act && (mode != 0 || !masks)) return SNR_E_ARG;          // (training dumps: points mode, with the ReLU bits)
+#define SNR_LAUNCH16(M, LL, MK, DP) decoder_fwd16_kernel<M, LL, MK, DP><<<grid, 512, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc)
+    if (mode == 0) {
+        if (io.act) { if (latlds) SNR_LAUNCH16(0, true, true, true); else SNR_LAUNCH16(0, false, true, true); }
+        else if (latlds) { if (masks) SNR_LAUNCH16(0, true, true, false); else SNR_LAUNCH16(0, true, false, false); }
+        else { if (masks) SNR_LAUNCH16(0, false, true, false); else SNR_LAUNCH16(0, false, false, false); }
+    } else {
+        if (latlds) { if (masks) SNR_LAUNCH16(1, true, true, false); else SNR_LAUNCH16(1, true, false, false); }
+        else { if (masks) SNR_LAUNCH16(1, false, true, false); else SNR_LAUNCH16(1, false, false, false); }
+    }
+#undef SNR_LAUNCH16
+    return snr_check_launch_();
+}

@@ -25,6 +25,18 @@ from . import ops
 from ._lib import SnrError
 
 
+def _leaf(module, name):
+    """``module.<name>`` for a parameter WITHOUT ``nn.Module.__getattr__``'s chain of dictionary probes: ``_parameters[name]`` -- or, in a
+    replica made by ``torch.nn.parallel.replicate`` (what ``nn.DataParallel`` runs, src/trainer_unified_nuscenes.py:227-229), the plain
+    attribute of the same name: replicas carry their (non-leaf, broadcast) parameter copies in ``__dict__``, not in ``_parameters``."""
+    p = module._parameters.get(name)
+    if p is None:
+        p = module.__dict__.get(name)
+        if p is None:
+            p = getattr(module, name)
+    return p
+
+
 # One lock for the two per-module weight caches (packed stream, stacked latent layers): the decoder is entered from one thread per GPU under
 # nn.DataParallel (src/trainer_unified_nuscenes.py:227-229) and a lock on the module itself would not survive ``replicate`` / deepcopy.
 _CACHE_LOCK = threading.RLock()
@@ -90,7 +102,7 @@ class _DecoderBase(nn.Module):
         *path, leaf = name.split(".")
         for part in path:
             m = m._modules[part]
-        return m._parameters[leaf]
+        return _leaf(m, leaf)
 
     def _per_point_params(self):
         return {n: self._param(n) for n in ops.per_point_tensor_names(self.shape_blocks, self.texture_blocks)}
@@ -181,7 +193,7 @@ class _DecoderBase(nn.Module):
         """(W_lat (512, n_lat*256), b_lat, W_next (n_lat*256, n_lat*256) block diagonal, b_next), rebuilt when a weight changed.
         Row block 0 of W_lat multiplies the shape code, row block 1 the texture code; every latent layer owns one column block."""
         lat, nxt = self._latent_params()
-        ps = [q for l in lat + nxt for q in (l._parameters["weight"], l._parameters["bias"])]
+        ps = [q for l in lat + nxt for q in (_leaf(l, "weight"), _leaf(l, "bias"))]
         dev = ps[0].device
         key = tuple((q.data_ptr(), q._version) for q in ps) + (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
         with _CACHE_LOCK:
