@@ -329,8 +329,10 @@ __device__ __forceinline__ void epi16(const f32x4& acc, FOp& o, const Epi16& c, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float a = acc[e];           // bias already inside
-        if (MASKS) mbits = __builtin_amdgcn_alignbit(mbits, __builtin_bit_cast(uint32_t, a), 31);
         const float y = __builtin_amdgcn_fmed3f(a, lo_bound, 65504.f);
+        // the saved bit is "inactive" = (y == 0) = top bit of (bits(y) - 1) for the ReLU's y >= 0: a pre-activation of exactly +0.0 is
+        // inactive like torch.relu's derivative at 0 (the sign bit of `a` alone, round 3, called +0.0 active: dead units with zero bias)
+        if (MASKS) mbits = __builtin_amdgcn_alignbit(mbits, __builtin_bit_cast(uint32_t, y) - 1u, 31);
         xv[e] = ZADD ? y + z[e] : y;
         if (DUMP) dv[e] = xv[e];
     }
@@ -352,8 +354,8 @@ __device__ __forceinline__ void epi16(const f32x4& acc, FOp& o, const Epi16& c, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float a = acc[e];           // bias already inside
-        if (MASKS) mbits = __builtin_amdgcn_alignbit(mbits, __builtin_bit_cast(uint32_t, a), 31);
         const float y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, a), c.floor));
+        if (MASKS) mbits = __builtin_amdgcn_alignbit(mbits, __builtin_bit_cast(uint32_t, y) - 1u, 31);      // inactive = (y == 0), see the fp16 branch
         const float xv = ZADD ? y + z[e] : y;
         split_store_f(xv, o, 4 * HALF + e);
         if (DUMP) dv[e] = xv;
@@ -698,8 +700,8 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = accA[cb][t][e];
-                    if (MASKS) mk[2 * cb] = __builtin_amdgcn_alignbit(mk[2 * cb], __builtin_bit_cast(uint32_t, v), 31);
                     v = fmaxf(v, 0.f);
+                    if (MASKS) mk[2 * cb] = __builtin_amdgcn_alignbit(mk[2 * cb], __builtin_bit_cast(uint32_t, v) - 1u, 31);     // inactive = (relu(v) == 0): +0.0 too
                     dv[e] = v;
                     pr[cb] = fmaf(wr[e], v, pr[cb]); pg[cb] = fmaf(wg[e], v, pg[cb]); pb[cb] = fmaf(wb[e], v, pb[cb]);
                 }

@@ -14,7 +14,6 @@
 //     XOR-swizzled 16-byte slots -> conflict-free ds_read_b128) filled by LDS-DMA, shared by the 4 waves.
 //   * Bias / latent adds, ReLU, softplus, the 256->1 density head and the 128->3 colour head run on
 //     the VALU in the accumulator layout; the composite is a 64-lane product scan.
-#include <stdlib.h>
 #include "snr_mlp_core.hpp"
 #include "snr_host.hpp"
 
@@ -32,7 +31,7 @@ namespace snr {
 // lane's point p = lane & 31 (both half-waves hold the same point).  Outputs sigma, r, g, b valid in
 // every lane.  All four waves of the workgroup must call it together (block-wide barriers inside).
 // -------------------------------------------------------------------------------------------
-template <bool STAGED>      // STAGED (the points decoder, which is what trains): activation dumps through LDS, whole cache lines per store
+template <bool STAGED, bool MASKS>      // MASKS: the launch saves the ReLU bits (io.masks).  STAGED (the points decoder, which is what trains): activation dumps through LDS, whole cache lines per store
 __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const Layout& L, float* lds, long long gp /*clamped point id*/, bool live,
                                                      long long tile32, float x, float y, float z, float dx, float dy, float dz,
                                                      float& o_sigma, float& o_r, float& o_g, float& o_b) {
@@ -119,9 +118,9 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     step<8, 8>(acc, in[1], pipe, lds, 256, tid);
     {
         const int la = latent_after(0, sb, tb);
-        if (lat_in_lds && la >= 0) epilogue<8, 8>(acc, in, true, lds + LDS_LAT + la * 256, h, mask);
-        else epilogue<8, 8>(acc, in, true, la >= 0 ? lat + la * 256 : nullptr, h, mask);
-        if (io.masks && tile_live) io.masks[(tile32 * n_relu + 0) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
+        if (lat_in_lds && la >= 0) epilogue<8, 8, MASKS>(acc, in, true, lds + LDS_LAT + la * 256, h, mask);
+        else epilogue<8, 8, MASKS>(acc, in, true, la >= 0 ? lat + la * 256 : nullptr, h, mask);
+        if (MASKS && tile_live) io.masks[(tile32 * n_relu + 0) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
         if constexpr (STAGED) { if (io.act && tile_live) dump_operand_staged<8>(in, io.act + ((long long)0 * io.n_points + tile32 * 32) * 256, dump_rows, dump_scr, lane); }
         else if (io.act && live) dump_operand<8>(in, io.act + ((long long)0 * io.n_points + gp) * 256, h);
     }
@@ -146,9 +145,9 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
         if (is_view) step<8, 8>(acc, in[8], pipe, lds, rows_after, tid);
         const bool relu = (li != li_encshape);
         const int la = latent_after(li, sb, tb);
-        if (lat_in_lds && la >= 0) epilogue<8, 8>(acc, in, relu, lds + LDS_LAT + la * 256, h, mask);
-        else epilogue<8, 8>(acc, in, relu, la >= 0 ? lat + la * 256 : nullptr, h, mask);
-        if (relu && io.masks && tile_live)
+        if (lat_in_lds && la >= 0) epilogue<8, 8, MASKS>(acc, in, relu, lds + LDS_LAT + la * 256, h, mask);
+        else epilogue<8, 8, MASKS>(acc, in, relu, la >= 0 ? lat + la * 256 : nullptr, h, mask);
+        if (MASKS && relu && tile_live)
             io.masks[(tile32 * n_relu + relu_slot(li, sb)) * 64 + lane] = make_uint4(mask[0], mask[1], mask[2], mask[3]);
         if constexpr (STAGED) { if (io.act && tile_live) dump_operand_staged<8>(in, io.act + ((long long)li * io.n_points + tile32 * 32) * 256, dump_rows, dump_scr, lane); }
         else if (io.act && live) dump_operand<8>(in, io.act + ((long long)li * io.n_points + gp) * 256, h);
@@ -182,8 +181,8 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
     step<4, 8>(acc, in[6], pipe, lds, 128, tid);
     step<4, 8>(acc, in[7], pipe, lds, 0, tid);
     SNR32_STAMP(9);      // rgb.0's chunks
-    epilogue<4, 8>(acc, in, true, nullptr, h, mask);
-    if (io.masks && tile_live) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mask[0], mask[1], 0u, 0u);
+    epilogue<4, 8, MASKS>(acc, in, true, nullptr, h, mask);
+    if (MASKS && tile_live) io.masks[(tile32 * n_relu + (n_relu - 1)) * 64 + lane] = make_uint4(mask[0], mask[1], 0u, 0u);
     if constexpr (STAGED) { if (io.act && tile_live) dump_operand_staged<4>(in, io.act + ((long long)(li_last + 1) * io.n_points + tile32 * 32) * 256, dump_rows, dump_scr, lane); }
     else if (io.act && live) dump_operand<4>(in, io.act + ((long long)(li_last + 1) * io.n_points + gp) * 256, h);
     {
@@ -214,7 +213,7 @@ __device__ __forceinline__ void decoder_forward_tile(const DecoderIO& io, const 
 // kernels
 // ===========================================================================================
 // MODE 0: explicit points (SUPNeRF.forward drop-in).  MODE 1: fused render (sampling + composite).
-template <int MODE>
+template <int MODE, bool MASKS>
 __global__ void __launch_bounds__(256, 1)
 decoder_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom g,
                    float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_acc) {
@@ -238,7 +237,7 @@ decoder_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const 
     unsigned long long st_c0 = 0, st_r0 = 0;
     if (tid == 0) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c0), "=s"(st_r0) :: "memory");
 #endif
-    decoder_forward_tile<MODE == 0>(io, L, lds, gp, live, tile128 * 4 + wave, x, y, z, dx, dy, dz, sg, cr, cg, cb);
+    decoder_forward_tile<MODE == 0, MASKS>(io, L, lds, gp, live, tile128 * 4 + wave, x, y, z, dx, dy, dz, sg, cr, cg, cb);
 #ifdef SNR_STAMPS
     if (tid == 0 && io.sigmas) {
         unsigned long long c1, r1;
@@ -286,16 +285,6 @@ using namespace snr;
 int snr_bf16_supported_(int sb, int tb, long long points_per_obj);
 int snr_bf16_launch_fwd_(int mode, const DecoderIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
                          float* depth, float* acc, void* stream_);
-int snr_fp32_fwd16_launch_(int mode, const DecoderIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
-                           float* depth, float* acc, void* stream_);
-
-// The exact-fp32 forward runs on the two-waves-per-SIMD kernel (snr_mlp16.hip: v_mfma_f32_16x16x4_f32, 16 points per wave).  Diagnostic
-// switch for A/B timing only: SNR_FP32_FWD=32x32 in the environment selects this file's one-wave-per-SIMD kernel (32x32x2) instead.
-static bool fwd_use_32x32() {
-    static const bool v = [] { const char* e = getenv("SNR_FP32_FWD"); return e && e[0] == '3' && e[1] == '2'; }();
-    return v;
-}
-
 extern "C" {
 
 int snr_precision_supported(int precision, int sb, int tb, int64_t points_per_obj) {
@@ -321,9 +310,9 @@ int snr_decoder_fwd(const float* xyz, const float* viewdir, const float* latent,
         return snr_bf16_launch_fwd_(0, io, L, xyz, viewdir, g, nullptr, nullptr, nullptr, stream_);
     }
     if (precision != SNR_FP32) return SNR_E_ARG;
-    if (!fwd_use_32x32()) return snr_fp32_fwd16_launch_(0, io, L, xyz, viewdir, g, nullptr, nullptr, nullptr, stream_);
     const unsigned grid = (unsigned)((n_points + 127) / 128);
-    decoder_fwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g, nullptr, nullptr, nullptr);
+    if (relu_masks) decoder_fwd_kernel<0, true><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g, nullptr, nullptr, nullptr);
+    else decoder_fwd_kernel<0, false><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g, nullptr, nullptr, nullptr);
     return snr_check_launch_();
 }
 
@@ -345,9 +334,9 @@ int snr_render_fwd(const snr_render_args* a, float* rgb, float* depth, float* ac
         return snr_bf16_launch_fwd_(1, io, L, nullptr, nullptr, g, rgb, depth, acc_trans, stream_);
     }
     if (a->precision != SNR_FP32) return SNR_E_ARG;
-    if (!fwd_use_32x32()) return snr_fp32_fwd16_launch_(1, io, L, nullptr, nullptr, g, rgb, depth, acc_trans, stream_);
     const unsigned grid = (unsigned)((P + 127) / 128);
-    decoder_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g, rgb, depth, acc_trans);
+    if (relu_masks) decoder_fwd_kernel<1, true><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g, rgb, depth, acc_trans);
+    else decoder_fwd_kernel<1, false><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g, rgb, depth, acc_trans);
     return snr_check_launch_();
 }
 

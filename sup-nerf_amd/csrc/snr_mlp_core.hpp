@@ -114,9 +114,14 @@ __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NA], const float* __
 // matrix pipe idle (hiding it does not pay: tools/_diag/experiments/README.md), so it is kept to 4-5 VALU instructions per value: the ReLU bit
 // is the sign of (0 - v), shifted in by one v_alignbit (highest element first, so element r lands on bit r); the max is one v_med3 against an
 // opaque +inf (a constant would be rewritten as canonicalise + v_max); without ReLU the floor is -inf and the bits are not stored.
-template <int NT, int NA>
-__device__ __forceinline__ void epilogue(const f32x16 (&acc)[NA], float (&in)[9][16], bool relu, const float* __restrict__ zlat, int h,
-                                         uint32_t (&mask)[4]) {
+// MASKS false (round 4: a forward that saves no ReLU bits -- inference, evaluation renders, the bench headline): the two instructions per
+// value that collect the bit are not issued.  On this chip that is not just issue slots: the fp32 MFMA executes on the vector FP32 ALUs
+// (MI355X_MICROARCH.md: "runs at the f32 VECTOR rate"), so every VALU instruction takes its cycles away from the matrix work whether or not
+// it is "hidden" (tools/_diag/f32_waves_bench.hip, tools/_diag/experiments/README.md).
+// ZADD false (a layer that no latent term follows: three of the eight boundaries of the shipped decoder): the add is not issued either.
+template <int NT, int NA, bool MASKS, bool ZADD>
+__device__ __forceinline__ void epilogue_impl(const f32x16 (&acc)[NA], float (&in)[9][16], bool relu, const float* __restrict__ zlat, int h,
+                                              uint32_t (&mask)[4]) {
     const float lo = relu ? 0.f : -__builtin_inff();
     float hi = __builtin_inff();
     asm volatile("" : "+v"(hi));
@@ -125,13 +130,13 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NA], float (&in)[9]
     // (the latent values of tile t+1 are requested before tile t's arithmetic, order pinned: see acc_init_bias)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 zc[4] = {zero4, zero4, zero4, zero4}, zn[4] = {zero4, zero4, zero4, zero4};
-    if (zlat) {
+    if (ZADD) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) zc[j] = *reinterpret_cast<const f32x4*>(zlat + 8 * j + 4 * h);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        if (zlat && t + 1 < NT) {
+        if (ZADD && t + 1 < NT) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) zn[j] = *reinterpret_cast<const f32x4*>(zlat + 32 * (t + 1) + 8 * j + 4 * h);
         }
@@ -142,9 +147,9 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NA], float (&in)[9]
 #pragma unroll
             for (int e = 3; e >= 0; --e) {
                 float v = acc[t][4 * j + e];
-                m16 = __builtin_amdgcn_alignbit(m16, __float_as_uint(0.f - v), 31);
+                if (MASKS) m16 = __builtin_amdgcn_alignbit(m16, __float_as_uint(0.f - v), 31);
                 v = __builtin_amdgcn_fmed3f(v, lo, hi);
-                in[t][4 * j + e] = v + zc[j][e];
+                in[t][4 * j + e] = ZADD ? v + zc[j][e] : v;
             }
         }
         mask[t >> 1] = (t & 1) ? (mask[t >> 1] | (m16 << 16)) : m16;
@@ -152,6 +157,13 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NA], float (&in)[9]
 #pragma unroll
         for (int j = 0; j < 4; ++j) zc[j] = zn[j];
     }
+}
+
+template <int NT, int NA, bool MASKS = true>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[NA], float (&in)[9][16], bool relu, const float* __restrict__ zlat, int h,
+                                         uint32_t (&mask)[4]) {
+    if (zlat) epilogue_impl<NT, NA, MASKS, true>(acc, in, relu, zlat, h, mask);          // (uniform)
+    else epilogue_impl<NT, NA, MASKS, false>(acc, in, relu, zlat, h, mask);
 }
 
 // which latent term (index into the (B,NLAT,256) table) is added after MFMA layer li; -1 = none

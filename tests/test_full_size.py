@@ -359,7 +359,15 @@ def _trace_bands():
 
 def test_100_iteration_traces_against_float64_oracle_loops(amd, dev, oracle_params):
     """100 iterations of the loop (16 x 16 rays x 64 samples) on both kernel families for the 8 objects of trace_bands.npz, against the
-    float64 oracle loops committed there; bands derived from the fp32 oracle loops of the same file (see above)."""
+    float64 oracle loops committed there; bands derived from the fp32 oracle loops of the same file (see above).
+
+    FROZEN (round 4): this is a SANITY ENVELOPE, not an acceptance criterion.  A 100-iteration Adam trace is chaotic -- fp32 rounding alone
+    moves it by 0.064 dB / 0.018 rad / 0.32 m over 32 rolls of the reference's own arithmetic -- so a band of 2 x that (0.64 m on the
+    translation) cannot tell a correct kernel from a subtly wrong one; it only catches a loop that goes somewhere else entirely.
+    ``trace_bands.npz`` and the band rule stay as they are: they were widened once after a failure (round 3) and must not grow again.
+    What carries the weight for new kernels: the mask-matched gradient tests at 2e-4 (this file: config 2 / config 3 / family B, same
+    piecewise-linear function on both sides), the first five iterations here (identical numbers before Adam amplifies anything) and the
+    N-step outcome distance of tests/test_driver_gpu.py::test_training_outcome_fp32_and_bf16x3_track_the_oracle."""
     D = amd.driver
     z, objs, dev32 = _trace_bands()
     band, typical = 2.0 * dev32.max(axis=0), 2.0 * np.median(dev32, axis=0)

@@ -395,3 +395,46 @@ def test_split_forward_saturates_beyond_the_fp16_range(amd, dev, oracle_params):
         print(f"[split forward, first-layer activations x {scale:g}] max relative difference from the fp32 kernels {err:.2e}")
         if expect_close:
             assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_relu_bit_of_an_exactly_zero_preactivation_is_inactive(amd, dev, oracle_params, precision):
+    """torch.relu has derivative 0 at 0 (the reference's autograd, src/model_supnerf.py:251-263).  Hidden units whose pre-activation is
+    EXACTLY +0.0 for every point -- zero weight row, zero bias: dead or pruned units -- must be saved as inactive, and no gradient may flow
+    through them (round 3's split forward took the sign bit of the pre-activation and called +0.0 active)."""
+    from relu_bits import decode_relu_bits
+    params = {k: v.clone() for k, v in oracle_params.items()}
+    dead = [3, 64, 255]
+    for name in ("shape_layer_2.0", "texture_layer_1.0", "encoding_xyz.0"):
+        params[name + ".weight"][dead] = 0.0
+        params[name + ".bias"][dead] = 0.0
+    params["rgb.0.weight"][[5, 77]] = 0.0
+    params["rgb.0.bias"][[5, 77]] = 0.0
+    m = amd.CodeNeRF(3, 1); m.load_state_dict(params); m = m.to(dev)
+    g = torch.Generator().manual_seed(2)
+    P = 256
+    xyz = (torch.rand(P, 3, generator=g) - 0.5).to(dev)
+    vd = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
+    lat = torch.zeros(1, 4, 256, device=dev)                  # (no latent term: the dead units' inputs stay exactly zero)
+    sig, rgb, masks = amd.ops.decoder_fwd(xyz, vd, lat, m.packed_weights(), 3, 1, save_masks=True, precision=precision)
+    layers = decode_relu_bits(masks, P, 3, 1)                 # enc_xyz, shape 1..3, enc_viewdir, texture 1, rgb.0
+    assert not bool(layers[0][:, dead].any()) and not bool(layers[2][:, dead].any()) and not bool(layers[5][:, dead].any())
+    assert not bool(layers[6][:, [5, 77]].any())
+    assert bool(layers[0].any()) and bool(layers[2].any())    # (the live units are a mix)
+    # the backward applies the saved pattern: with the bits above, the kernel's d_xyz is the oracle's autograd on the SAME piecewise-linear
+    # function (every ReLU differentiated with the saved 0/1 pattern; latent terms zero so that the dead units' inputs stay exactly zero)
+    d_lat, d_xyz, d_dir = amd.ops.decoder_bwd(xyz, vd, lat, m.packed_weights(), masks, sig, torch.ones_like(sig), torch.ones_like(rgb), 3, 1,
+                                              precision=precision)
+    from oracle import supnerf_oracle as O
+    xyz_c = xyz.cpu().requires_grad_()
+    pc = {k: v for k, v in params.items()}
+    sc = torch.zeros(1, 256); tc = torch.zeros(1, 256)
+    with O.given_relu_masks(layers):
+        for j in (1, 2, 3):               # (the oracle takes codes: zero latent layers give the zero latent terms the kernel was given)
+            pc[f"shape_latent_layer_{j}.0.weight"] = torch.zeros_like(pc[f"shape_latent_layer_{j}.0.weight"]); pc[f"shape_latent_layer_{j}.0.bias"] = torch.zeros(256)
+        pc["texture_latent_layer_1.0.weight"] = torch.zeros_like(pc["texture_latent_layer_1.0.weight"]); pc["texture_latent_layer_1.0.bias"] = torch.zeros(256)
+        s_ref, c_ref = O.decoder_forward(pc, xyz_c[:, None, :], vd.cpu()[:, None, :], sc, tc)
+        (s_ref.sum() + c_ref.sum()).backward()
+    ref = xyz_c.grad
+    err = float((d_xyz.cpu() - ref).abs().max() / ref.abs().max())
+    assert err < (2e-4 if precision == "fp32" else 5e-4), err

@@ -24,36 +24,49 @@
 // The fma chain of an output differs from the 32x32x2 kernel's in the ORDER of the k terms (a 16x16x4 MFMA sums k = 16 T + {r, 4 + r,
 // 8 + r, 12 + r}, the 32x32x2 form k = 32 c + 8 j + {e, 4 + e}): both are exact fp32 fma chains over the same products, results agree
 // to fp32 round-off, not bit for bit.
+#include <stdlib.h>
 #include "snr_mlp_core.hpp"
 #include "snr_host.hpp"
 
 namespace snr {
 
-constexpr int PE_WAVE16 = 16 * PE_ROW;               // per-wave scratch: 16 points (8 waves x 16 = the 32x32 kernel's 4 x 32)
-constexpr int LDS_ZERO16 = LDS_TOTAL;                // 256 zero floats: the latent row of a layer without one, the head weights of a layer without a head
-constexpr int LDS_TOTAL16 = LDS_TOTAL + 256;
-static_assert(LDS_TOTAL16 * 4 <= 160 * 1024, "LDS budget");
+constexpr int PE_WAVE16 = 16 * PE_ROW;               // per-wave positional-encoding scratch: 16 points
+constexpr int WBUF16 = 256 * KC;                     // floats per ring buffer: the forward stream's largest chunk, 256 rows x 32 (32 KiB)
 
-// 512 threads stage `rows` x 128 B (rows a multiple of 64): linear LDS-DMA copy, 1 KiB per wave-instruction
-__device__ __forceinline__ void chunk_dma16(const float* __restrict__ g, float* lds, int rows, int tid) {
-    const int nvec = rows * 8;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i * 512 < nvec) {
-            typedef const __attribute__((address_space(1))) void* gptr_t;
-            typedef __attribute__((address_space(3))) void* lptr_t;
-            __builtin_amdgcn_global_load_lds((gptr_t)(g + (size_t)(i * 512 + tid) * 4), (lptr_t)(lds + (i * 512 + wave * 64) * 4), 16, 0, 0);
-        }
-    }
+// LDS map (float offsets; the kernel declares no static LDS, the host computes the map per launch and passes the byte size as the
+// launch's dynamic LDS).  WAVES = 8 (one 512-thread workgroup per CU): [ring 0 | ring 1 | scratch | composite | bias + heads | latent | zero].
+// WAVES = 4 (TWO 256-thread workgroups per CU, 80 KiB each at most): the scratch (needed until the operand registers are read) lies over
+// ring buffer 1 (first written by the DMA of chunk 1, behind a barrier) and the composite scratch (needed after the last chunk) over ring
+// buffer 0; the bias and latent blocks are sized by the decoder's own layer count.
+struct Lds16 { int ring1, scratch, comp, bias, lat, zero, total; };
+inline Lds16 make_lds16(int waves, int n_mfma_layers, int n_lat) {
+    Lds16 o;
+    o.ring1 = WBUF16;
+    int p = 2 * WBUF16;
+    if (waves == 8) { o.scratch = p; p += 8 * PE_WAVE16; o.comp = p; p += 128 * COMP_STRIDE; }
+    else { o.scratch = o.ring1; o.comp = 0; }
+    p = (p + 3) & ~3;
+    o.bias = p; p += (n_mfma_layers + 3) * 256;
+    o.lat = p; p += (n_lat <= LDS_LAT_ROWS ? n_lat : 0) * 256;
+    o.zero = p; p += 256;
+    o.total = p;
+    return o;
 }
 
-// piece i (64 rows = 8 KiB: one 1 KiB LDS-DMA instruction per wave) of a chunk
+// piece i of a chunk: WAVES x 64 threads copy WAVES KiB (8 WAVES rows x 128 B), one 1 KiB LDS-DMA instruction per wave
+template <int WAVES>
 __device__ __forceinline__ void chunk_piece16(const float* __restrict__ g, float* lds, int i, int tid) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    __builtin_amdgcn_global_load_lds((gptr_t)(g + (size_t)(i * 512 + tid) * 4), (lptr_t)(lds + (i * 512 + wave * 64) * 4), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(g + (size_t)(i * WAVES * 64 + tid) * 4), (lptr_t)(lds + (i * WAVES * 64 + wave * 64) * 4), 16, 0, 0);
+}
+// a whole chunk of `rows` x 128 B at once (prologue and enc_xyz; inside the 256-wide layers the pieces go out between MFMA groups)
+template <int WAVES>
+__device__ __forceinline__ void chunk_dma16(const float* __restrict__ g, float* lds, int rows, int tid) {
+#pragma unroll
+    for (int i = 0; i < 64 / WAVES; ++i)
+        if (i * 8 * WAVES < rows) chunk_piece16<WAVES>(g, lds, i, tid);
 }
 
 struct Ring16 {
@@ -169,7 +182,7 @@ __device__ __forceinline__ void acc_from_bias(f32x4 (&acc)[16], const float* bia
 // extra chunk behind the eight, the merge of the two ends of the layer cost 48 spilled registers).  On entry the layer's first chunk
 // (the direction chunk if `pre`) is in the current buffer; at its last chunk the layer requests `next_first` (next_rows rows; 0 = the
 // stream ends).  On return accP holds this layer's sums (bias included, no activation yet).
-template <int NT, bool LATLDS, bool MASKS, bool DUMP>
+template <int NT, int WAVES, bool LATLDS, bool MASKS, bool DUMP>
 __device__ __forceinline__ void layer_from_acc(f32x4 (&accP)[16], Ring16& ring, float* lds, const float* bias, const Epi& c, int g, int tid,
                                                const float* base, bool pre, const f32x4 (&xe)[2], const float* next_first, int next_rows,
                                                uint32_t (&mw)[4], float& sig_part) {
@@ -178,8 +191,8 @@ __device__ __forceinline__ void layer_from_acc(f32x4 (&accP)[16], Ring16& ring, 
     constexpr int rows_mid = NT * 16;
     constexpr int chunk_floats = rows_mid * KC;
     if (pre) {
-        chunk_dma16(base, lds + (ring.cur ^ 1) * WBUF, rows_mid, tid);
-        const float* wb = lds + ring.cur * WBUF;
+        chunk_dma16<WAVES>(base, lds + (ring.cur ^ 1) * WBUF16, rows_mid, tid);
+        const float* wb = lds + ring.cur * WBUF16;
         first_pair(a0, a1, wb + ring.aoff[0]);
         acc_from_bias<NT>(accC, bias, g);
         tile_mma<NT, false>(accC, accP, xe[0], wb + ring.aoff[0], a0, a1, wb + ring.aoff[1]);
@@ -204,13 +217,14 @@ __device__ __forceinline__ void layer_from_acc(f32x4 (&accP)[16], Ring16& ring, 
     for (int ch = 0; ch < 8; ++ch) {
         const float* src = (ch < 7) ? base + (ch + 1) * chunk_floats : next_first;
         const int rows = (ch < 7) ? rows_mid : next_rows;
-        float* const dst = lds + (ring.cur ^ 1) * WBUF;
-        const float* wb = lds + ring.cur * WBUF;
+        float* const dst = lds + (ring.cur ^ 1) * WBUF16;
+        const float* wb = lds + ring.cur * WBUF16;
         first_pair(a0, a1, wb + ring.aoff[0]);
         // first tile of the chunk (T = 2 ch) on xa; between its groups: the next chunk's DMA pieces and tile 2 ch + 1's operand
         tile_mma<NT, false>(accC, accP, xa, wb + ring.aoff[0], a0, a1, wb + ring.aoff[1], [&](int gi) {
             if (gi == 0) e = epi_load<LATLDS>(c, 2 * ch + 1, g);
-            if ((gi & 1) == 0 && (gi >> 1) * 64 < rows) chunk_piece16(src, dst, gi >> 1, tid);
+            constexpr int PSTEP = (WAVES == 8) ? 2 : 1;      // a piece covers 8 WAVES rows: 4 (8 waves) or 8 (4 waves) pieces per 256-row chunk
+            if (gi % PSTEP == 0 && (gi / PSTEP) * 8 * WAVES < rows) chunk_piece16<WAVES>(src, dst, gi / PSTEP, tid);
 #pragma unroll
             for (int k = (gi * 4) / NG; k < ((gi + 1) * 4) / NG; ++k) epi_value<MASKS>(accP[2 * ch + 1], xb, c, e, 3 - k, m16, sig_part);
             if (DUMP && gi == NG - 1) *reinterpret_cast<f32x4*>(c.dump + 16 * (2 * ch + 1)) = xb;
@@ -245,17 +259,18 @@ __device__ __forceinline__ void store_masks16x4(uint4* __restrict__ dst /* tile'
     if (g < 2) dst[16 * (wave & 1) + n + 32 * g] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <int MODE, bool LATLDS, bool MASKS, bool DUMP>
-__global__ void __launch_bounds__(512, 2)
-decoder_fwd16_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom gm,
+template <int MODE, int WAVES, bool LATLDS, bool MASKS, bool DUMP>
+__global__ void __launch_bounds__(WAVES * 64, 2)
+decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom gm,
                      float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_acc) {
-    __shared__ __attribute__((aligned(16))) float lds[LDS_TOTAL16];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int WGP = WAVES * 16;                      // points per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
-    const long long tile128 = blockIdx.x;
-    const long long gp_raw = tile128 * 128 + wave * 16 + n;
+    const long long tile_wg = blockIdx.x;
+    const long long gp_raw = tile_wg * WGP + wave * 16 + n;
     const bool live = gp_raw < io.n_points;
     const long long gp = live ? gp_raw : io.n_points - 1;
-    const long long tile32 = tile128 * 4 + (wave >> 1);
+    const long long tile32 = tile_wg * (WAVES / 2) + (wave >> 1);
     const bool tile_live = tile32 * 32 < io.n_points;
     const int sb = io.sb, tb = io.tb;
     const int n_relu = n_relu_layers(sb, tb);
@@ -268,11 +283,11 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, cons
         const SamplePoint sp = make_sample(gm, ray, (int)(gp - ray * gm.S));
         px = sp.x; py = sp.y; pz = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc;
     }
-    const float* bias = lds + LDS_BIAS;
+    const float* bias = lds + lo.bias;
     const float* heads = bias + L.n_mfma_layers * 256;       // sigma_w (256) | sigma_b | rgb2_w (384) | rgb2_b, as in the packed stream
-    const float* zero = lds + LDS_ZERO16;
+    const float* zero = lds + lo.zero;
     const float* lat_lane = io.latent + (gp / io.points_per_obj) * (long long)L.n_lat * 256;       // (!LATLDS: the lane's own object)
-    const float* lat_wg = io.latent + ((tile128 * 128) / io.points_per_obj) * (long long)L.n_lat * 256;
+    const float* lat_wg = io.latent + ((tile_wg * WGP) / io.points_per_obj) * (long long)L.n_lat * 256;
 
     // ---- prologue: first weight chunk, biases + heads (+ latent rows) by LDS-DMA while the positional encodings are computed
     Ring16 ring;
@@ -291,16 +306,16 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, cons
     auto layer_first = [&](int li) { return layer_base(li) + (li == li_view ? 8 * C256 : 0); };
     f32x4 xin[4], xd[2];
     {
-        chunk_dma16(stream, lds, 256, tid);
+        chunk_dma16<WAVES>(stream, lds, 256, tid);
         typedef const __attribute__((address_space(1))) void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
-        for (int r = wave; r < L.n_mfma_layers + 3; r += 8)
-            __builtin_amdgcn_global_load_lds((gptr_t)(io.packed + L.bias + r * 256 + lane * 4), (lptr_t)(lds + LDS_BIAS + r * 256), 16, 0, 0);
+        for (int r = wave; r < L.n_mfma_layers + 3; r += WAVES)
+            __builtin_amdgcn_global_load_lds((gptr_t)(io.packed + L.bias + r * 256 + lane * 4), (lptr_t)(lds + lo.bias + r * 256), 16, 0, 0);
         if (LATLDS)
-            for (int r = wave; r < L.n_lat; r += 8)
-                __builtin_amdgcn_global_load_lds((gptr_t)(lat_wg + r * 256 + lane * 4), (lptr_t)(lds + LDS_LAT + r * 256), 16, 0, 0);
-        if (tid < 64) *reinterpret_cast<f32x4*>(lds + LDS_ZERO16 + 4 * tid) = f32x4{0.f, 0.f, 0.f, 0.f};
-        float* sc = lds + LDS_SCRATCH + wave * PE_WAVE16 + n * PE_ROW;
+            for (int r = wave; r < L.n_lat; r += WAVES)
+                __builtin_amdgcn_global_load_lds((gptr_t)(lat_wg + r * 256 + lane * 4), (lptr_t)(lds + lo.lat + r * 256), 16, 0, 0);
+        if (tid < 64) *reinterpret_cast<f32x4*>(lds + lo.zero + 4 * tid) = f32x4{0.f, 0.f, 0.f, 0.f};
+        float* sc = lds + lo.scratch + wave * PE_WAVE16 + n * PE_ROW;
         // 30 (frequency, axis) pairs of the xyz encoding, 8 per lane group (the fourth takes 6); 12 of the direction encoding, 3 each
 #pragma unroll 1
         for (int i = 0; i < 8; ++i) {
@@ -335,6 +350,7 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, cons
         for (int T = 0; T < 2; ++T)
 #pragma unroll
             for (int r = 0; r < 4; ++r) xd[T][r] = sc[64 + 16 * T + 4 * g + r];
+        if (WAVES == 4) __syncthreads();      // the scratch lies over ring buffer 1: every wave has read its operands before any wave requests chunk 1
     }
 
     // ---- enc_xyz: 64 -> 256 from explicit operand tiles (two chunks)
@@ -345,8 +361,8 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, cons
         acc_from_bias<16>(accC, bias, g);
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            chunk_dma16(ch == 0 ? stream + C256 : layer_first(1), lds + (ring.cur ^ 1) * WBUF, 256, tid);
-            const float* wb = lds + ring.cur * WBUF;
+            chunk_dma16<WAVES>(ch == 0 ? stream + C256 : layer_first(1), lds + (ring.cur ^ 1) * WBUF16, 256, tid);
+            const float* wb = lds + ring.cur * WBUF16;
             first_pair(a0, a1, wb + ring.aoff[0]);
             tile_mma<16, false>(accC, accP, xin[2 * ch], wb + ring.aoff[0], a0, a1, wb + ring.aoff[1]);
             if (ch == 1) tile_mma<16, true>(accC, accP, xin[2 * ch + 1], wb + ring.aoff[1], a0, a1, nullptr);
@@ -365,7 +381,7 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, cons
         const int la = latent_after(lp, sb, tb);
         Epi c;
         c.lo = (lp != li_encshape) ? 0.f : -__builtin_inff();
-        c.zlds = (la >= 0) ? lds + LDS_LAT + la * 256 : zero;
+        c.zlds = (la >= 0) ? lds + lo.lat + la * 256 : zero;
         c.zglb = (la >= 0) ? lat_lane + la * 256 : nullptr;
         c.wsig = (lp == li_encshape) ? heads : zero;
         c.dump = DUMP ? dump_lane + (long long)lp * io.n_points * 256 : nullptr;
@@ -387,14 +403,14 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, cons
         const int lp = li - 1;
         const Epi c = epi_of(lp);
         if (lp == li_encshape) sig_part = 0.f;
-        layer_from_acc<16, LATLDS, MASKS, DUMP>(accP, ring, lds, bias + li * 256, c, g, tid, layer_base(li), li == li_view, xd, layer_first(li + 1),
+        layer_from_acc<16, WAVES, LATLDS, MASKS, DUMP>(accP, ring, lds, bias + li * 256, c, g, tid, layer_base(li), li == li_view, xd, layer_first(li + 1),
                                                 (li == li_last) ? 128 : 256, mw, sig_part);
         after_layer_input(lp);
     }
     {   // rgb.0: 256 -> 128
         const Epi c = epi_of(li_last);
         if (li_last == li_encshape) sig_part = 0.f;
-        layer_from_acc<8, LATLDS, MASKS, DUMP>(accP, ring, lds, bias + (li_last + 1) * 256, c, g, tid, layer_base(li_last + 1), false, xd, nullptr, 0, mw, sig_part);
+        layer_from_acc<8, WAVES, LATLDS, MASKS, DUMP>(accP, ring, lds, bias + (li_last + 1) * 256, c, g, tid, layer_base(li_last + 1), false, xd, nullptr, 0, mw, sig_part);
         after_layer_input(li_last);
     }
 
@@ -436,17 +452,17 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, cons
         if (io.rgbs) { io.rgbs[gp * 3] = o_r; io.rgbs[gp * 3 + 1] = o_g; io.rgbs[gp * 3 + 2] = o_b; }
     }
     if (MODE == 1) {
-        float* comp = lds + LDS_COMP;
+        float* comp = lds + lo.comp;             // (WAVES = 4: over ring buffer 0 -- every wave is past the last chunk's barrier)
         if (g == 0) {
             float* c = comp + (wave * 16 + n) * COMP_STRIDE;
             c[0] = o_sigma; c[1] = o_r; c[2] = o_g; c[3] = o_b; c[4] = zc;
         }
         __syncthreads();
         const int S = gm.S;
-        const int rays_here = 128 / S;           // host guarantees 128 % S == 0
+        const int rays_here = WGP / S;           // host guarantees WGP % S == 0
         const bool white = gm.flags & SNR_WHITE_BKGD;
-        for (int r = wave; r < rays_here; r += 8) {
-            const long long ray = tile128 * rays_here + r;
+        for (int r = wave; r < rays_here; r += WAVES) {
+            const long long ray = tile_wg * rays_here + r;
             if (ray >= gm.n_rays) break;
             const float* c0 = comp + r * S * COMP_STRIDE;
             RayOut o = composite_ray_fwd(S, lane, white, [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
@@ -466,24 +482,58 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, cons
 
 using namespace snr;
 
-// mode 0: explicit points; mode 1: fused render.  The workgroup's latent rows are staged in LDS when its 128 points belong to ONE object
-// (points per object a multiple of 128) and the table has at most LDS_LAT_ROWS rows: every shipped configuration.
+// mode 0: explicit points; mode 1: fused render.  Two shapes of the same kernel:
+//   WAVES = 4 -- 64 points per 256-thread workgroup, TWO workgroups per CU (each at most 80 KiB of LDS: its own two-buffer weight ring, the
+//     decoder's biases / heads, latent rows).  The two waves of a SIMD then belong to DIFFERENT workgroups: they share no barrier, drift
+//     out of phase, and whatever one is doing at a chunk rendezvous or a layer start the other's MFMAs fill the matrix pipe.  Costs twice the
+//     L2 -> LDS weight traffic per point (8 B/clk/CU).  Taken whenever it fits: the ray (render mode) inside 64 points, LDS <= 80 KiB.
+//   WAVES = 8 -- 128 points per 512-thread workgroup, one per CU; both waves of a SIMD run the same program between the same barriers.
+// The workgroup's latent rows are staged in LDS when its points belong to ONE object and the table has at most LDS_LAT_ROWS rows.
+static int fwd16_waves_override() {
+    static const int v = [] { const char* e = getenv("SNR_FP32_WAVES"); return e ? atoi(e) : 0; }();      // diagnostic: 4 or 8
+    return v;
+}
+
+template <int MODE, int WAVES, bool LATLDS, bool MASKS, bool DUMP>
+static int launch16(const DecoderIO& io, const Layout& L, const Lds16& lo, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
+                    float* depth, float* acc, hipStream_t st) {
+    auto kern = decoder_fwd16_kernel<MODE, WAVES, LATLDS, MASKS, DUMP>;
+    static bool attr_set = false;          // (dynamic LDS beyond the default cap must be granted once per kernel)
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SNR_E_LAUNCH;
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)((io.n_points + WAVES * 16 - 1) / (WAVES * 16));
+    kern<<<grid, WAVES * 64, (size_t)lo.total * 4, st>>>(io, L, lo, xyz, viewdir, g, rgb, depth, acc);
+    return snr_check_launch_();
+}
+
+template <int WAVES>
+static int launch16_w(int mode, const DecoderIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
+                      float* depth, float* acc, hipStream_t st) {
+    const bool latlds = (io.points_per_obj % (WAVES * 16)) == 0 && L.n_lat <= LDS_LAT_ROWS;
+    const bool masks = io.masks != nullptr;
+    const Lds16 lo = make_lds16(WAVES, L.n_mfma_layers, latlds ? L.n_lat : LDS_LAT_ROWS + 1);
+#define SNR_L16(M, LL, MK, DP) launch16<M, WAVES, LL, MK, DP>(io, L, lo, xyz, viewdir, g, rgb, depth, acc, st)
+    if (mode == 0) {
+        if (io.act) return latlds ? SNR_L16(0, true, true, true) : SNR_L16(0, false, true, true);
+        if (latlds) return masks ? SNR_L16(0, true, true, false) : SNR_L16(0, true, false, false);
+        return masks ? SNR_L16(0, false, true, false) : SNR_L16(0, false, false, false);
+    }
+    if (latlds) return masks ? SNR_L16(1, true, true, false) : SNR_L16(1, true, false, false);
+    return masks ? SNR_L16(1, false, true, false) : SNR_L16(1, false, false, false);
+#undef SNR_L16
+}
+
 int snr_fp32_fwd16_launch_(int mode, const DecoderIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
                            float* depth, float* acc, void* stream_) {
-    const unsigned grid = (unsigned)((io.n_points + 127) / 128);
-    const bool latlds = (io.points_per_obj % 128) == 0 && L.n_lat <= LDS_LAT_ROWS;
     hipStream_t st = (hipStream_t)stream_;
-    const bool masks = io.masks != nullptr;
-    if (io.act && (mode != 0 || !masks)) return SNR_E_ARG;          // (training dumps: points mode, with the ReLU bits)
-#define SNR_LAUNCH16(M, LL, MK, DP) decoder_fwd16_kernel<M, LL, MK, DP><<<grid, 512, 0, st>>>(io, L, xyz, viewdir, g, rgb, depth, acc)
-    if (mode == 0) {
-        if (io.act) { if (latlds) SNR_LAUNCH16(0, true, true, true); else SNR_LAUNCH16(0, false, true, true); }
-        else if (latlds) { if (masks) SNR_LAUNCH16(0, true, true, false); else SNR_LAUNCH16(0, true, false, false); }
-        else { if (masks) SNR_LAUNCH16(0, false, true, false); else SNR_LAUNCH16(0, false, false, false); }
-    } else {
-        if (latlds) { if (masks) SNR_LAUNCH16(1, true, true, false); else SNR_LAUNCH16(1, true, false, false); }
-        else { if (masks) SNR_LAUNCH16(1, false, true, false); else SNR_LAUNCH16(1, false, false, false); }
-    }
-#undef SNR_LAUNCH16
-    return snr_check_launch_();
+    if (io.act && (mode != 0 || !io.masks)) return SNR_E_ARG;          // (training dumps: points mode, with the ReLU bits)
+    const bool lat4 = (io.points_per_obj % 64) == 0 && L.n_lat <= LDS_LAT_ROWS;
+    const Lds16 lo4 = make_lds16(4, L.n_mfma_layers, lat4 ? L.n_lat : LDS_LAT_ROWS + 1);
+    bool four = lo4.total * 4 <= 80 * 1024 && (mode == 0 || (g.S <= 64 && 64 % g.S == 0));
+    if (fwd16_waves_override() == 8) four = false;
+    if (fwd16_waves_override() == 4 && !(mode == 0 || (g.S <= 64 && 64 % g.S == 0))) four = false;
+    else if (fwd16_waves_override() == 4) four = true;
+    return four ? launch16_w<4>(mode, io, L, xyz, viewdir, g, rgb, depth, acc, st) : launch16_w<8>(mode, io, L, xyz, viewdir, g, rgb, depth, acc, st);
 }
