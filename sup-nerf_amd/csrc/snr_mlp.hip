@@ -285,6 +285,12 @@ using namespace snr;
 int snr_bf16_supported_(int sb, int tb, long long points_per_obj);
 int snr_bf16_launch_fwd_(int mode, const DecoderIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
                          float* depth, float* acc, void* stream_);
+// The exact-fp32 forward runs on the two-waves-per-SIMD kernel of snr_mlp16.hip (v_mfma_f32_16x16x4_f32, 16 points per wave: round 4).  This
+// file's one-wave-per-SIMD kernel (v_mfma_f32_32x32x2_f32, rounds 1-3) still serves the TRAINING forward of the exact-fp32 step (activation
+// dumps staged through LDS) and, with -DSNR_FWD32, every fp32 forward for A/B timing (tools/build_variant.sh).
+int snr_fp32_fwd16_launch_(int mode, const DecoderIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
+                           float* depth, float* acc, void* stream_);
+
 extern "C" {
 
 int snr_precision_supported(int precision, int sb, int tb, int64_t points_per_obj) {
@@ -310,6 +316,10 @@ int snr_decoder_fwd(const float* xyz, const float* viewdir, const float* latent,
         return snr_bf16_launch_fwd_(0, io, L, xyz, viewdir, g, nullptr, nullptr, nullptr, stream_);
     }
     if (precision != SNR_FP32) return SNR_E_ARG;
+#ifndef SNR_FWD32
+    // (training dumps stay on this file's kernel: its LDS-staged dump stores write whole cache lines, 13.9 against 14.2 ms per fp32 step)
+    if (!activations) return snr_fp32_fwd16_launch_(0, io, L, xyz, viewdir, g, nullptr, nullptr, nullptr, stream_);
+#endif
     const unsigned grid = (unsigned)((n_points + 127) / 128);
     if (relu_masks) decoder_fwd_kernel<0, true><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g, nullptr, nullptr, nullptr);
     else decoder_fwd_kernel<0, false><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g, nullptr, nullptr, nullptr);
@@ -334,6 +344,9 @@ int snr_render_fwd(const snr_render_args* a, float* rgb, float* depth, float* ac
         return snr_bf16_launch_fwd_(1, io, L, nullptr, nullptr, g, rgb, depth, acc_trans, stream_);
     }
     if (a->precision != SNR_FP32) return SNR_E_ARG;
+#ifndef SNR_FWD32
+    return snr_fp32_fwd16_launch_(1, io, L, nullptr, nullptr, g, rgb, depth, acc_trans, stream_);
+#endif
     const unsigned grid = (unsigned)((P + 127) / 128);
     if (relu_masks) decoder_fwd_kernel<1, true><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g, rgb, depth, acc_trans);
     else decoder_fwd_kernel<1, false><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g, rgb, depth, acc_trans);

@@ -53,20 +53,52 @@ inline Lds16 make_lds16(int waves, int n_mfma_layers, int n_lat) {
     return o;
 }
 
-// piece i of a chunk: WAVES x 64 threads copy WAVES KiB (8 WAVES rows x 128 B), one 1 KiB LDS-DMA instruction per wave
+// LDS-DMA of the weight ring through inline asm with a SCALAR base (global_load_lds_dwordx4 voff, s[base:base+1] offset:imm; M0 = the LDS
+// address): wave w copies the contiguous slice w of a chunk (rows x 128 B / WAVES bytes: 4 or 8 pieces of 1 KiB for 256 rows), the
+// per-lane VGPR offset (lane x 16 + 4096) is made once per kernel and the piece is selected by the immediate, which moves the global and
+// the LDS address together (-4096 .. +3072).  The builtin form computes a 64-bit per-lane address on the VALU for every piece -- and on
+// this chip VALU instructions compete with the fp32 MFMAs for the ALUs.  EVERY LDS-DMA of the kernel takes this form: the compiler must
+// never have a use of M0 of its own (it would assume M0 survives an asm statement).  Completion is counted by hand (ring_turn: vmcnt(0)).
+template <int K>
+__device__ __forceinline__ void dma_piece_imm(unsigned voff, const void* sbase, unsigned m0v) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" :: "v"(voff), "s"(sbase), "s"(m0v), "n"(1024 * K - 4096) : "memory");
+}
+__device__ __forceinline__ void dma_piece(int k, unsigned voff, const void* sbase, unsigned m0v) {      // k is a constant after unrolling
+    switch (k) {
+        case 0: dma_piece_imm<0>(voff, sbase, m0v); break;
+        case 1: dma_piece_imm<1>(voff, sbase, m0v); break;
+        case 2: dma_piece_imm<2>(voff, sbase, m0v); break;
+        case 3: dma_piece_imm<3>(voff, sbase, m0v); break;
+        case 4: dma_piece_imm<4>(voff, sbase, m0v); break;
+        case 5: dma_piece_imm<5>(voff, sbase, m0v); break;
+        case 6: dma_piece_imm<6>(voff, sbase, m0v); break;
+        default: dma_piece_imm<7>(voff, sbase, m0v); break;
+    }
+}
+struct Dma16 {
+    unsigned voff;       // lane * 16 + 4096
+    unsigned lds0;       // LDS byte address of lds[0] (uniform)
+    int wave;            // uniform
+};
+// piece i of this wave's slice of a chunk of `rows` rows: bytes [wave * SL + i KiB, + 1 KiB), SL = rows * 128 / WAVES
 template <int WAVES>
-__device__ __forceinline__ void chunk_piece16(const float* __restrict__ g, float* lds, int i, int tid) {
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    __builtin_amdgcn_global_load_lds((gptr_t)(g + (size_t)(i * WAVES * 64 + tid) * 4), (lptr_t)(lds + (i * WAVES * 64 + wave * 64) * 4), 16, 0, 0);
+__device__ __forceinline__ void chunk_piece16(const Dma16& d, const float* __restrict__ g, const float* lds_dst, const float* lds_base, int rows, int i) {
+    const unsigned sl = (unsigned)(rows * 128 / WAVES) * (unsigned)d.wave;
+    const char* sbase = reinterpret_cast<const char*>(g) + sl;
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(d.lds0 + (unsigned)((lds_dst - lds_base) * 4) + sl + 4096u);
+    dma_piece(i, d.voff, sbase, m0v);
 }
 // a whole chunk of `rows` x 128 B at once (prologue and enc_xyz; inside the 256-wide layers the pieces go out between MFMA groups)
 template <int WAVES>
-__device__ __forceinline__ void chunk_dma16(const float* __restrict__ g, float* lds, int rows, int tid) {
+__device__ __forceinline__ void chunk_dma16(const Dma16& d, const float* __restrict__ g, const float* lds_dst, const float* lds_base, int rows) {
 #pragma unroll
-    for (int i = 0; i < 64 / WAVES; ++i)
-        if (i * 8 * WAVES < rows) chunk_piece16<WAVES>(g, lds, i, tid);
+    for (int i = 0; i < 32 / WAVES; ++i)
+        if (i * 8 * WAVES < rows) chunk_piece16<WAVES>(d, g, lds_dst, lds_base, rows, i);
+}
+// one 1 KiB row (biases, heads, latent rows) by ONE wave
+__device__ __forceinline__ void row_dma16(const Dma16& d, const float* __restrict__ g, const float* lds_dst, const float* lds_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(d.lds0 + (unsigned)((lds_dst - lds_base) * 4) + 4096u);
+    dma_piece_imm<0>(d.voff, g, m0v);
 }
 
 struct Ring16 {
@@ -79,10 +111,10 @@ struct Epi {
     float lo;                 // ReLU floor: 0, or -inf for the layer without an activation
     const float* zlds;        // LATLDS: LDS row of the latent term added after the activation (the zero row if none)
     const float* zglb;        // !LATLDS: this lane's global latent row, or null
-    const float* wsig;        // LDS: density-head weights when the tile belongs to enc_shape's output, else the zero row
+    float hi;                 // +inf, opaque (made once per kernel): the upper bound of the ReLU's v_med3
     float* dump;              // training: this lane's row of the activation dump ([point][256] + 4 g), or null
 };
-struct EpiRegs { f32x4 z, ws; };     // what a tile's epilogue reads from LDS, requested a tile ahead
+struct EpiRegs { f32x4 z; };          // what a tile's epilogue reads from LDS, requested a tile ahead
 
 __device__ __forceinline__ uint32_t spread_nibbles(uint32_t m16) {
     // nibble of input tile dT (shifted in first = highest) -> bits 8 dT .. 8 dT + 3
@@ -95,7 +127,6 @@ __device__ __forceinline__ EpiRegs epi_load(const Epi& c, int T, int g) {
     e.z = f32x4{0.f, 0.f, 0.f, 0.f};
     if (LATLDS) e.z = *reinterpret_cast<const f32x4*>(c.zlds + 16 * T + 4 * g);
     else if (c.zglb) e.z = *reinterpret_cast<const f32x4*>(c.zglb + 16 * T + 4 * g);
-    e.ws = *reinterpret_cast<const f32x4*>(c.wsig + 16 * T + 4 * g);
     return e;
 }
 
@@ -103,18 +134,12 @@ __device__ __forceinline__ EpiRegs epi_load(const Epi& c, int T, int g) {
 // ReLU bit (shifted in: call with r = 3, 2, 1, 0), the density head's term, the latent add.  Five VALU instructions, placed by the caller
 // BETWEEN the MFMA groups of the tile before (see layer_from_acc).
 template <bool MASKS>
-__device__ __forceinline__ void epi_value(const f32x4& acc, f32x4& x, const Epi& c, const EpiRegs& e, int r, uint32_t& m16, float& sig_part) {
-    float hi = __builtin_inff();
-    asm volatile("" : "+v"(hi));          // (a literal +inf would be rewritten as canonicalise + v_max)
+__device__ __forceinline__ void epi_value(const f32x4& acc, f32x4& x, const Epi& c, const EpiRegs& e, int r, uint32_t& m16) {
     float v = acc[r];
     if (MASKS) m16 = __builtin_amdgcn_alignbit(m16, __float_as_uint(0.f - v), 31);      // bit = (v > 0): the sign of 0 - v (+0 and -0 give 0)
-    v = __builtin_amdgcn_fmed3f(v, c.lo, hi);
-    sig_part = fmaf(e.ws[r], v, sig_part);               // (density head: on enc_shape's raw output, no latent follows that layer)
+    v = __builtin_amdgcn_fmed3f(v, c.lo, c.hi);
     x[r] = v + e.z[r];
-    // pinned here: left alone the compiler sinks the head's fma chain (and the bit collection) to the end of the layer and spills every
-    // activation and head weight it will need there
-    asm volatile("" : "+v"(sig_part));
-    if (MASKS) asm volatile("" : "+v"(m16));
+    if (MASKS) asm volatile("" : "+v"(m16));      // (pinned: left alone the compiler sinks the bit collection to the end of the layer)
 }
 
 #define SNR16_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xc07f)       /* s_waitcnt lgkmcnt(0), as an instruction the compiler's own wait insertion sees */
@@ -183,15 +208,15 @@ __device__ __forceinline__ void acc_from_bias(f32x4 (&acc)[16], const float* bia
 // (the direction chunk if `pre`) is in the current buffer; at its last chunk the layer requests `next_first` (next_rows rows; 0 = the
 // stream ends).  On return accP holds this layer's sums (bias included, no activation yet).
 template <int NT, int WAVES, bool LATLDS, bool MASKS, bool DUMP>
-__device__ __forceinline__ void layer_from_acc(f32x4 (&accP)[16], Ring16& ring, float* lds, const float* bias, const Epi& c, int g, int tid,
+__device__ __forceinline__ void layer_from_acc(f32x4 (&accP)[16], Ring16& ring, float* lds, const float* bias, const Epi& c, int g, const Dma16& dm,
                                                const float* base, bool pre, const f32x4 (&xe)[2], const float* next_first, int next_rows,
-                                               uint32_t (&mw)[4], float& sig_part) {
+                                               uint32_t (&mw)[4]) {
     f32x4 accC[16];
     f32x4 a0, a1;
     constexpr int rows_mid = NT * 16;
     constexpr int chunk_floats = rows_mid * KC;
     if (pre) {
-        chunk_dma16<WAVES>(base, lds + (ring.cur ^ 1) * WBUF16, rows_mid, tid);
+        chunk_dma16<WAVES>(dm, base, lds + (ring.cur ^ 1) * WBUF16, lds, rows_mid);
         const float* wb = lds + ring.cur * WBUF16;
         first_pair(a0, a1, wb + ring.aoff[0]);
         acc_from_bias<NT>(accC, bias, g);
@@ -211,7 +236,7 @@ __device__ __forceinline__ void layer_from_acc(f32x4 (&accP)[16], Ring16& ring, 
     f32x4 xa, xb;
     uint32_t m16 = 0u;
 #pragma unroll
-    for (int r = 3; r >= 0; --r) epi_value<MASKS>(accP[0], xa, c, e, r, m16, sig_part);
+    for (int r = 3; r >= 0; --r) epi_value<MASKS>(accP[0], xa, c, e, r, m16);
     if (DUMP) *reinterpret_cast<f32x4*>(c.dump) = xa;
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
@@ -224,9 +249,9 @@ __device__ __forceinline__ void layer_from_acc(f32x4 (&accP)[16], Ring16& ring, 
         tile_mma<NT, false>(accC, accP, xa, wb + ring.aoff[0], a0, a1, wb + ring.aoff[1], [&](int gi) {
             if (gi == 0) e = epi_load<LATLDS>(c, 2 * ch + 1, g);
             constexpr int PSTEP = (WAVES == 8) ? 2 : 1;      // a piece covers 8 WAVES rows: 4 (8 waves) or 8 (4 waves) pieces per 256-row chunk
-            if (gi % PSTEP == 0 && (gi / PSTEP) * 8 * WAVES < rows) chunk_piece16<WAVES>(src, dst, gi / PSTEP, tid);
+            if (gi % PSTEP == 0 && (gi / PSTEP) * 8 * WAVES < rows) chunk_piece16<WAVES>(dm, src, dst, lds, rows, gi / PSTEP);
 #pragma unroll
-            for (int k = (gi * 4) / NG; k < ((gi + 1) * 4) / NG; ++k) epi_value<MASKS>(accP[2 * ch + 1], xb, c, e, 3 - k, m16, sig_part);
+            for (int k = (gi * 4) / NG; k < ((gi + 1) * 4) / NG; ++k) epi_value<MASKS>(accP[2 * ch + 1], xb, c, e, 3 - k, m16);
             if (DUMP && gi == NG - 1) *reinterpret_cast<f32x4*>(c.dump + 16 * (2 * ch + 1)) = xb;
         });
         if (ch & 1) { mw[ch >> 1] = m16; m16 = 0u; }
@@ -237,7 +262,7 @@ __device__ __forceinline__ void layer_from_acc(f32x4 (&accP)[16], Ring16& ring, 
             tile_mma<NT, false>(accC, accP, xb, wb + ring.aoff[1], a0, a1, nullptr, [&](int gi) {
                 if (gi == 0) e = epi_load<LATLDS>(c, 2 * ch + 2, g);
 #pragma unroll
-                for (int k = (gi * 4) / NG; k < ((gi + 1) * 4) / NG; ++k) epi_value<MASKS>(accP[2 * ch + 2], xa, c, e, 3 - k, m16, sig_part);
+                for (int k = (gi * 4) / NG; k < ((gi + 1) * 4) / NG; ++k) epi_value<MASKS>(accP[2 * ch + 2], xa, c, e, 3 - k, m16);
                 if (DUMP && gi == NG - 1) *reinterpret_cast<f32x4*>(c.dump + 16 * (2 * ch + 2)) = xa;
             });
         }
@@ -292,6 +317,10 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
     // ---- prologue: first weight chunk, biases + heads (+ latent rows) by LDS-DMA while the positional encodings are computed
     Ring16 ring;
     ring.cur = 0;
+    Dma16 dm;
+    dm.voff = lane * 16u + 4096u;
+    dm.lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds);
+    dm.wave = __builtin_amdgcn_readfirstlane(wave);
     {
         const int sw = (n >> 1) & 7;
         ring.aoff[0] = n * KC + (((0 + g) ^ sw) << 2);
@@ -306,14 +335,10 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
     auto layer_first = [&](int li) { return layer_base(li) + (li == li_view ? 8 * C256 : 0); };
     f32x4 xin[4], xd[2];
     {
-        chunk_dma16<WAVES>(stream, lds, 256, tid);
-        typedef const __attribute__((address_space(1))) void* gptr_t;
-        typedef __attribute__((address_space(3))) void* lptr_t;
-        for (int r = wave; r < L.n_mfma_layers + 3; r += WAVES)
-            __builtin_amdgcn_global_load_lds((gptr_t)(io.packed + L.bias + r * 256 + lane * 4), (lptr_t)(lds + lo.bias + r * 256), 16, 0, 0);
+        chunk_dma16<WAVES>(dm, stream, lds, lds, 256);
+        for (int r = dm.wave; r < L.n_mfma_layers + 3; r += WAVES) row_dma16(dm, io.packed + L.bias + r * 256, lds + lo.bias + r * 256, lds);
         if (LATLDS)
-            for (int r = wave; r < L.n_lat; r += WAVES)
-                __builtin_amdgcn_global_load_lds((gptr_t)(lat_wg + r * 256 + lane * 4), (lptr_t)(lds + lo.lat + r * 256), 16, 0, 0);
+            for (int r = dm.wave; r < L.n_lat; r += WAVES) row_dma16(dm, lat_wg + r * 256, lds + lo.lat + r * 256, lds);
         if (tid < 64) *reinterpret_cast<f32x4*>(lds + lo.zero + 4 * tid) = f32x4{0.f, 0.f, 0.f, 0.f};
         float* sc = lds + lo.scratch + wave * PE_WAVE16 + n * PE_ROW;
         // 30 (frequency, axis) pairs of the xyz encoding, 8 per lane group (the fourth takes 6); 12 of the direction encoding, 3 each
@@ -361,7 +386,7 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
         acc_from_bias<16>(accC, bias, g);
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            chunk_dma16<WAVES>(ch == 0 ? stream + C256 : layer_first(1), lds + (ring.cur ^ 1) * WBUF16, 256, tid);
+            chunk_dma16<WAVES>(dm, ch == 0 ? stream + C256 : layer_first(1), lds + (ring.cur ^ 1) * WBUF16, lds, 256);
             const float* wb = lds + ring.cur * WBUF16;
             first_pair(a0, a1, wb + ring.aoff[0]);
             tile_mma<16, false>(accC, accP, xin[2 * ch], wb + ring.aoff[0], a0, a1, wb + ring.aoff[1]);
@@ -373,7 +398,9 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
 
     // ---- the 256-wide middle layers (shape blocks, enc_shape, enc_viewdir, texture blocks): layer li consumes layer li - 1's sums
     uint32_t mw[4] = {0u, 0u, 0u, 0u};
-    float sig_part = 0.f, o_sigma = 0.f;
+    float o_sigma = 0.f;
+    float pos_inf = __builtin_inff();
+    asm volatile("" : "+v"(pos_inf));          // (opaque: a literal +inf in v_med3 would be rewritten as canonicalise + v_max, per value)
     // training dumps: a lane past the end holds the LAST point (gp is clamped), i.e. the same values as that point's own lane: its stores
     // repeat that lane's bytes at that lane's address, so no per-lane predicate (= no divergent branch per tile) is needed
     float* const dump_lane = DUMP ? io.act + gp * 256 + 4 * g : nullptr;
@@ -383,34 +410,40 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
         c.lo = (lp != li_encshape) ? 0.f : -__builtin_inff();
         c.zlds = (la >= 0) ? lds + lo.lat + la * 256 : zero;
         c.zglb = (la >= 0) ? lat_lane + la * 256 : nullptr;
-        c.wsig = (lp == li_encshape) ? heads : zero;
+        c.hi = pos_inf;
         c.dump = DUMP ? dump_lane + (long long)lp * io.n_points * 256 : nullptr;
         return c;
     };
-    auto after_layer_input = [&](int lp) {      // ReLU bits of layer lp (collected while it was consumed) and the density head
+    auto after_layer_input = [&](int lp) {      // ReLU bits of layer lp, collected while it was consumed
         if (MASKS && lp != li_encshape && tile_live) store_masks16x4(io.masks + (tile32 * n_relu + relu_slot(lp, sb)) * 64, mw, wave, lane);
-        if (lp == li_encshape) {
-            // density head: softplus(w_sigma . y + b) (src/model_supnerf.py:257); the lane groups hold a quarter of the features each
-            float s = sig_part;
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            const float pre = s + heads[L.sigma_b - L.sigma_w];
-            o_sigma = pre > 20.f ? pre : log1pf(expf(pre));
-        }
     };
 #pragma unroll 1
     for (int li = 1; li <= li_last; ++li) {
         const int lp = li - 1;
         const Epi c = epi_of(lp);
-        if (lp == li_encshape) sig_part = 0.f;
-        layer_from_acc<16, WAVES, LATLDS, MASKS, DUMP>(accP, ring, lds, bias + li * 256, c, g, tid, layer_base(li), li == li_view, xd, layer_first(li + 1),
-                                                (li == li_last) ? 128 : 256, mw, sig_part);
+        if (li == li_view) {
+            // density head on enc_shape's finished sums (accP, no activation, no latent): softplus(w_sigma . y + b), src/model_supnerf.py:257.
+            // One pass of 64 fma here instead of an fma + a head-weight fetch in EVERY layer's per-value epilogue: on this chip a VALU
+            // instruction is not hidden by fp32 MFMAs, it competes with them for the same ALUs.  The lane groups hold a quarter of the features.
+            float s = 0.f;
+#pragma unroll
+            for (int T = 0; T < 16; ++T) {
+                const f32x4 ws = *reinterpret_cast<const f32x4*>(heads + 16 * T + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s = fmaf(ws[r], accP[T][r], s);
+            }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const float pre = s + heads[L.sigma_b - L.sigma_w];
+            o_sigma = pre > 20.f ? pre : log1pf(expf(pre));
+        }
+        layer_from_acc<16, WAVES, LATLDS, MASKS, DUMP>(accP, ring, lds, bias + li * 256, c, g, dm, layer_base(li), li == li_view, xd, layer_first(li + 1),
+                                                       (li == li_last) ? 128 : 256, mw);
         after_layer_input(lp);
     }
     {   // rgb.0: 256 -> 128
         const Epi c = epi_of(li_last);
-        if (li_last == li_encshape) sig_part = 0.f;
-        layer_from_acc<8, WAVES, LATLDS, MASKS, DUMP>(accP, ring, lds, bias + (li_last + 1) * 256, c, g, tid, layer_base(li_last + 1), false, xd, nullptr, 0, mw, sig_part);
+        layer_from_acc<8, WAVES, LATLDS, MASKS, DUMP>(accP, ring, lds, bias + (li_last + 1) * 256, c, g, dm, layer_base(li_last + 1), false, xd, nullptr, 0, mw);
         after_layer_input(li_last);
     }
 
@@ -490,8 +523,12 @@ using namespace snr;
 //   WAVES = 8 -- 128 points per 512-thread workgroup, one per CU; both waves of a SIMD run the same program between the same barriers.
 // The workgroup's latent rows are staged in LDS when its points belong to ONE object and the table has at most LDS_LAT_ROWS rows.
 static int fwd16_waves_override() {
+#ifdef SNR16_FORCE_WAVES
+    return SNR16_FORCE_WAVES;
+#else
     static const int v = [] { const char* e = getenv("SNR_FP32_WAVES"); return e ? atoi(e) : 0; }();      // diagnostic: 4 or 8
     return v;
+#endif
 }
 
 template <int MODE, int WAVES, bool LATLDS, bool MASKS, bool DUMP>
@@ -516,7 +553,6 @@ static int launch16_w(int mode, const DecoderIO& io, const Layout& L, const floa
     const Lds16 lo = make_lds16(WAVES, L.n_mfma_layers, latlds ? L.n_lat : LDS_LAT_ROWS + 1);
 #define SNR_L16(M, LL, MK, DP) launch16<M, WAVES, LL, MK, DP>(io, L, lo, xyz, viewdir, g, rgb, depth, acc, st)
     if (mode == 0) {
-        if (io.act) return latlds ? SNR_L16(0, true, true, true) : SNR_L16(0, false, true, true);
         if (latlds) return masks ? SNR_L16(0, true, true, false) : SNR_L16(0, true, false, false);
         return masks ? SNR_L16(0, false, true, false) : SNR_L16(0, false, false, false);
     }
@@ -528,7 +564,7 @@ static int launch16_w(int mode, const DecoderIO& io, const Layout& L, const floa
 int snr_fp32_fwd16_launch_(int mode, const DecoderIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, float* rgb,
                            float* depth, float* acc, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    if (io.act && (mode != 0 || !io.masks)) return SNR_E_ARG;          // (training dumps: points mode, with the ReLU bits)
+    if (io.act) return SNR_E_UNSUPPORTED;          // (training dumps: snr_mlp.hip's kernel, whose dump stores are staged through LDS)
     const bool lat4 = (io.points_per_obj % 64) == 0 && L.n_lat <= LDS_LAT_ROWS;
     const Lds16 lo4 = make_lds16(4, L.n_mfma_layers, lat4 ? L.n_lat : LDS_LAT_ROWS + 1);
     bool four = lo4.total * 4 <= 80 * 1024 && (mode == 0 || (g.S <= 64 && 64 % g.S == 0));

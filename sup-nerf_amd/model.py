@@ -136,7 +136,7 @@ class _DecoderBase(nn.Module):
         call of a weight version runs the same batch once more in exact fp32 (``probe(precision)`` -> outputs; 1.75 ms at 4096 x 64),
         compares, counts clamped weights, and on disagreement beyond ops.RANGE_TOL downgrades the model to fp32 with a warning.  One host
         read per weight version; nothing in the steady state.  Training (weights change every step) and DataParallel replicas (re-made
-        every step) re-check on calls 1, 2, 4, 8, ... and every 1024th."""
+        every step) re-check on calls 1, 16, 256 and every 1024th (weights drift slowly; a probe costs one exact-fp32 forward + a host read)."""
         sb, tb = self.shape_blocks, self.texture_blocks
         if requested not in (None, "auto"):
             f, b = ops.precision_pair(requested, sb, tb, points_per_obj)
@@ -153,7 +153,7 @@ class _DecoderBase(nn.Module):
             g["calls"] += 1
             n = g["calls"]
             if train or getattr(self, "_is_replica", False):
-                due = g["verdict"] is None or (n & (n - 1)) == 0 or n % 1024 == 0
+                due = g["verdict"] is None or n in (16, 256) or n % 1024 == 0
             else:
                 due = g["key"] != self._packed_key or g["verdict"] is None
             if due:

@@ -64,6 +64,15 @@ def setup(name):
     good.snr_render_fwd(C.byref(a32), rgb32.data_ptr(), depth32.data_ptr(), acc32.data_ptr(), None, None, None, st())
     f0(); torch.cuda.synchronize()
     err = f"rgb {float((rgb - rgb32).abs().max()):.1e} depth {float((depth - depth32).abs().max()):.1e} vs fp32"
+    if name != "shipped" and int(os.environ.get("SNR_AB_PRECISION", "1")) == 0:
+        # the variant's saved ReLU bits against the shipped kernel's (same layout; bits of units within rounding of zero may differ)
+        m_v = masks.clone(); s_v = sig.clone()
+        a_g = type(a_shipped)(); C.memmove(C.byref(a_g), C.byref(a_shipped), C.sizeof(a_shipped))
+        good.snr_render_fwd(C.byref(a_g), rgb32.data_ptr(), depth32.data_ptr(), acc32.data_ptr(), sig.data_ptr(), rgbs.data_ptr(), masks.data_ptr(), st())
+        torch.cuda.synchronize()
+        x = (m_v ^ masks); nbits = int(sum(((x >> k) & 1).sum() for k in range(8)))
+        err += f"; ReLU bits differing from the shipped kernel's: {nbits} of {masks.numel() * 8} ({nbits / (masks.numel() * 8):.2e}); sigma {float((s_v - sig).abs().max()):.1e}"
+        f1(); torch.cuda.synchronize()
     return f0, f1, b, err, ws
 names = list(dict.fromkeys(sys.argv[1:]))
 for n in names: libs[n] = setup(n)
