@@ -445,8 +445,11 @@ def _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, 
             lat = model.latent_terms(shapecode, texturecode)
             cfg.latent_bias = cfg_l.latent_bias = model.latent_biases(lat)
             if it == 0:         # which arithmetic the loop runs in: "auto" is decided (and range-checked) once, on the first iteration's batch
-                prec = model._auto_precision(model.precision, n * S, lambda p_: ops.render_probe(rays_o.detach(), viewdir.detach(), z, c["diag"], None,
-                                                                                                 lat.detach(), packed, cfg, p_))
+                def probe(p_):      # (one object of the batch: the decoder is the same for all of them)
+                    c1 = ops.copy.copy(cfg)
+                    c1.latent_bias = None if cfg.latent_bias is None else cfg.latent_bias[:1]
+                    return ops.render_probe(rays_o.detach()[:n], viewdir.detach()[:n], z[:1], c["diag"][:1], None, lat.detach()[:1], packed, c1, p_)
+                prec = model._auto_precision(model.precision, n * S, probe)
                 cfg.precision = prec
                 cfg_l.precision = prec if (prec != "bf16x3" or ops.split_supported(sb, tb, n_l * S)) else "fp32"
             rgb, depth, acc = ops.FusedRender.apply(rays_o, viewdir, z, c["diag"], None, lat, packed, cfg)
