@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsupnerf_hip.so")
 STAMP = os.path.join(HERE, ".libsupnerf_hip.stamp")
-SOURCES = ["snr_aux.hip", "snr_loss.hip", "snr_loop.hip", "snr_wgrad.hip", "snr_mlp.hip", "snr_mlp16.hip", "snr_mlp_bwd.hip", "snr_bf16.hip"]
+SOURCES = ["snr_aux.hip", "snr_loss.hip", "snr_loop.hip", "snr_wgrad.hip", "snr_mlp.hip", "snr_mlp16.hip", "snr_mlp16_bwd.hip", "snr_mlp_bwd.hip", "snr_bf16.hip"]
 HEADERS = ["snr_layout.h", "snr_device.hpp", "snr_host.hpp", "snr_mlp_core.hpp", "snr_mlp16_core.hpp", os.path.join("..", "..", "include", "supnerf_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

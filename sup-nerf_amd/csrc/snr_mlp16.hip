@@ -154,6 +154,24 @@ __device__ __forceinline__ void store_masks16x4(uint4* __restrict__ dst /* tile'
     if (g < 2) dst[16 * (wave & 1) + n + 32 * g] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+#ifdef SNR_STAMPS   /* diagnostic build (tools/build_diag.sh): lane 0 of every wave writes s_memtime at phase boundaries into the sigmas buffer, 8 per
+                       16-point wave tile (tools/_diag/stamps16.py prints them); the renders of such a build are valid, the saved sigmas are not */
+#define SNR16_STAMP(i) do { if (io.sigmas && lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        reinterpret_cast<unsigned long long*>(io.sigmas)[(tile_wg * WAVES + wave) * 8 + (i)] = t_; } } while (0)
+/* slot 6 takes the wave's place on the chip instead: HW_ID (wave, SIMD, CU, SE) | XCC_ID << 32 */
+#define SNR16_STAMP_HWID(i) do { if (io.sigmas && lane == 0) { unsigned a_, b_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(a_), "=s"(b_)); \
+        reinterpret_cast<unsigned long long*>(io.sigmas)[(tile_wg * WAVES + wave) * 8 + (i)] = (unsigned long long)a_ | ((unsigned long long)b_ << 32); } } while (0)
+#else
+#define SNR16_STAMP(i) do {} while (0)
+#define SNR16_STAMP_HWID(i) do {} while (0)
+#endif
+
+#ifdef SNR16_NO_PRIO
+#define SNR16_PRIO(p) do {} while (0)
+#else
+#define SNR16_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
+
 template <int MODE, int WAVES, bool LATLDS, bool MASKS, bool DUMP>
 __global__ void __launch_bounds__(WAVES * 64, 2)
 decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom gm,
@@ -169,6 +187,12 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
     const bool tile_live = tile32 * 32 < io.n_points;
     const int sb = io.sb, tb = io.tb;
     const int n_relu = n_relu_layers(sb, tb);
+    SNR16_STAMP(0);
+    // The prologue and the tail are VALU work; the SIMD's other wave (another workgroup, out of phase) is mid-stream, issuing MFMAs back to back,
+    // and at equal priority its ready MFMA wins the ALUs nearly every time: the prologue then takes 69 000 cycles instead of 9 000 and the matrix
+    // pipe is fed by one wave (0.87 of its rate) for that long.  With priority the prologue is over in a fraction of that and two waves share
+    // the pipe again (tools/_diag/stamps16.py).
+    SNR16_PRIO(3);
     float px, py, pz, dx, dy, dz, zc = 0.f;
     if (MODE == 0) {
         px = xyz[gp * 3]; py = xyz[gp * 3 + 1]; pz = xyz[gp * 3 + 2];
@@ -248,6 +272,8 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
         if (WAVES == 4) __syncthreads();      // the scratch lies over ring buffer 1: every wave has read its operands before any wave requests chunk 1
     }
 
+    SNR16_PRIO(0);
+    SNR16_STAMP(1);
     // ---- enc_xyz: 64 -> 256 from explicit operand tiles (two chunks)
     f32x4 accP[16];
     {
@@ -266,6 +292,7 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
         }
     }
 
+    SNR16_STAMP(2);
     // ---- the 256-wide middle layers (shape blocks, enc_shape, enc_viewdir, texture blocks): layer li consumes layer li - 1's sums
     uint32_t mw[4] = {0u, 0u, 0u, 0u};
     float o_sigma = 0.f;
@@ -292,6 +319,7 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
         const int lp = li - 1;
         const Epi c = epi_of(lp);
         if (li == li_view) {
+            SNR16_STAMP(3);
             // density head on enc_shape's finished sums (accP, no activation, no latent): softplus(w_sigma . y + b), src/model_supnerf.py:257.
             // One pass of 64 fma here instead of an fma + a head-weight fetch in EVERY layer's per-value epilogue: on this chip a VALU
             // instruction is not hidden by fp32 MFMAs, it competes with them for the same ALUs.  The lane groups hold a quarter of the features.
@@ -311,12 +339,15 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
                                                        (li == li_last) ? 128 : 256, mw);
         after_layer_input(lp);
     }
+    SNR16_STAMP(4);
     {   // rgb.0: 256 -> 128
         const Epi c = epi_of(li_last);
         layer_from_acc<8, WAVES, LATLDS, MASKS, DUMP>(accP, ring, lds, bias + (li_last + 1) * 256, c, g, dm, layer_base(li_last + 1), false, xd, nullptr, 0, mw);
         after_layer_input(li_last);
     }
 
+    SNR16_STAMP(5);
+    SNR16_PRIO(3);
     // ---- rgb.0's output (accP tiles 0..7): ReLU + bits, then rgb.2 (128 -> 3) on the VALU
     float o_r, o_g, o_b;
     {
@@ -350,8 +381,11 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
         o_r = pr + b2[0]; o_g = pg + b2[1]; o_b = pb + b2[2];
     }
 
+    SNR16_STAMP_HWID(6);
+#ifndef SNR_STAMPS
+    if (live && g == 0 && io.sigmas) io.sigmas[gp] = o_sigma;
+#endif
     if (live && g == 0) {
-        if (io.sigmas) io.sigmas[gp] = o_sigma;
         if (io.rgbs) { io.rgbs[gp * 3] = o_r; io.rgbs[gp * 3 + 1] = o_g; io.rgbs[gp * 3 + 2] = o_b; }
     }
     if (MODE == 1) {
@@ -379,6 +413,7 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
             }
         }
     }
+    SNR16_STAMP(7);
 }
 
 }  // namespace snr

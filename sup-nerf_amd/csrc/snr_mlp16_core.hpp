@@ -91,9 +91,14 @@ struct Ring16 {
 // `wnext` at the end) is requested before the group's eight MFMAs.  Left to the compiler, the request follows the MFMAs and the wait
 // (lgkmcnt(0), not a counted one) sits right behind the request: an LDS round trip exposed per group in both waves of the SIMD at once.
 struct NoBetween { __device__ __forceinline__ void operator()(int) const {} };
-template <int NT, bool LAST, class Between = NoBetween, int NA = 16, int ND = 16>
+// FLAGS: bit 0 (LAST): the finished sums go to accD; bit 1 (ZERO): the sums start from zero -- every tile's first MFMA takes the constant 0 as
+// its C operand, no zeroed register set.
+constexpr int TM_LAST = 1, TM_ZERO = 2;
+template <int NT, int FLAGS, class Between = NoBetween, int NA = 16, int ND = 16>
 __device__ __forceinline__ void tile_mma(f32x4 (&accC)[NA], f32x4 (&accD)[ND], const f32x4& x, const float* wrow /* chunk + aoff[dT] */,
                                          f32x4& a0, f32x4& a1, const float* wnext, Between&& between = NoBetween()) {
+    constexpr bool LAST = FLAGS & TM_LAST, ZERO = FLAGS & TM_ZERO;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; t += 2) {
         SNR16_WAIT_LDS();
@@ -112,8 +117,8 @@ __device__ __forceinline__ void tile_mma(f32x4 (&accC)[NA], f32x4 (&accD)[ND], c
                 accD[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], x[r], accC[t], 0, 0, 0);
                 accD[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], x[r], accC[t + 1], 0, 0, 0);
             } else {
-                accC[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], x[r], accC[t], 0, 0, 0);
-                accC[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], x[r], accC[t + 1], 0, 0, 0);
+                accC[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], x[r], (ZERO && r == 0) ? zero4 : accC[t], 0, 0, 0);
+                accC[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], x[r], (ZERO && r == 0) ? zero4 : accC[t + 1], 0, 0, 0);
             }
         }
         // the group's slice of non-matrix work, in program order BEHIND its eight MFMAs: it issues while they -- and the partner wave's --

@@ -348,14 +348,31 @@ int snr_launch_reduce_latent_(const float* partial, float* scratch, long long ti
 long long snr_reduce_scratch_floats_(long long tiles_per_obj, int n_lat, long long n_obj);
 int snr_bf16_supported_(int sb, int tb, long long points_per_obj);
 int snr_bf16_launch_bwd_(int mode, const BwdIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, void* stream_);
+// snr_mlp16_bwd.hip: the exact-fp32 backward with two waves per SIMD (16-point wave tiles)
+int snr_fp32_bwd16_supported_(int mode, const BwdIO& io, const RayGeom& g);
+int snr_fp32_bwd16_launch_(int mode, const BwdIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, void* stream_);
 
-// workspace = per-wave-tile partial latent gradients [tiles32][n_lat][256] + the reduction tree's scratch
+// workspace = per-wave-tile partial latent gradients [tiles][n_lat][256] + the reduction tree's scratch; sized for the smallest wave tile
+// any kernel uses (16 points: snr_mlp16_bwd.hip; the others write one row per 32 points)
 static size_t bwd_ws_bytes(int64_t n_points, int64_t points_per_obj, int sb, int tb) {
-    const int64_t tiles = (n_points + 31) / 32;
+    const int64_t tiles = (n_points + 15) / 16;
     const int64_t ppo = points_per_obj > 0 ? points_per_obj : n_points;
     const int64_t n_obj = ppo > 0 ? (n_points + ppo - 1) / ppo : 1;
-    const int64_t tree = snr_reduce_scratch_floats_((ppo + 31) / 32, sb + tb, n_obj);
+    const int64_t tree = snr_reduce_scratch_floats_((ppo + 15) / 16, sb + tb, n_obj);
     return (size_t)((tiles * (int64_t)(sb + tb) * 256 + tree) * sizeof(float) + 256);
+}
+
+// the exact-fp32 backward: the two-waves-per-SIMD kernel where it applies (no training dumps, a ray inside 64 points), else the
+// one-wave 32x32x2 kernel of rounds 1-3 (-DSNR_BWD32: always, for A/B timing).  *tile = points per partial row.
+static int launch_fp32_bwd(int mode, const BwdIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, void* stream_, int* tile) {
+#ifndef SNR_BWD32
+    if (snr_fp32_bwd16_supported_(mode, io, g)) { *tile = 16; return snr_fp32_bwd16_launch_(mode, io, L, xyz, viewdir, g, stream_); }
+#endif
+    *tile = 32;
+    const unsigned grid = (unsigned)((io.n_points + 127) / 128);
+    if (mode == 0) decoder_bwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
+    else decoder_bwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g);
+    return snr_check_launch_();
 }
 
 extern "C" {
@@ -383,18 +400,16 @@ int snr_decoder_bwd(const float* xyz, const float* viewdir, const float* latent,
     io.gdump = layer_grads;
     RayGeom g{};
     const Layout L = make_layout(sb, tb);
-    int rc;
+    int rc, tile = 32;
     if (precision == SNR_BF16X3) {
         if (!snr_bf16_supported_(sb, tb, points_per_obj)) return SNR_E_UNSUPPORTED;
         rc = snr_bf16_launch_bwd_(0, io, L, xyz, viewdir, g, stream_);
     } else if (precision == SNR_FP32) {
-        const unsigned grid = (unsigned)((n_points + 127) / 128);
-        decoder_bwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
-        rc = snr_check_launch_();
+        rc = launch_fp32_bwd(0, io, L, xyz, viewdir, g, stream_, &tile);
     } else return SNR_E_ARG;
     if (rc != SNR_OK) return rc;
     if (want_lat)
-        return snr_launch_reduce_latent_(io.partial, io.partial + ((n_points + 31) / 32) * (int64_t)(sb + tb) * 256, points_per_obj / 32, sb + tb,
+        return snr_launch_reduce_latent_(io.partial, io.partial + ((n_points + tile - 1) / tile) * (int64_t)(sb + tb) * 256, points_per_obj / tile, sb + tb,
                                          n_points / points_per_obj, d_latent, stream_);
     return SNR_OK;
 }
@@ -431,17 +446,16 @@ int snr_render_bwd(const snr_render_args* a, const float* sigmas, const float* r
     io.partial = want_lat ? (float*)workspace : nullptr;
     io.d_rays_o = d_rays_o; io.d_rays_d = d_rays_d; io.d_t = d_t;
     const Layout L = make_layout(sb, tb);
+    int tile = 32;
     if (a->precision == SNR_BF16X3) {
         if (!snr_bf16_supported_(sb, tb, ppo)) return SNR_E_UNSUPPORTED;
         rc = snr_bf16_launch_bwd_(1, io, L, nullptr, nullptr, g, stream_);
     } else if (a->precision == SNR_FP32) {
-        const unsigned grid = (unsigned)((P + 127) / 128);
-        decoder_bwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, nullptr, nullptr, g);
-        rc = snr_check_launch_();
+        rc = launch_fp32_bwd(1, io, L, nullptr, nullptr, g, stream_, &tile);
     } else return SNR_E_ARG;
     if (rc != SNR_OK) return rc;
     if (want_lat)
-        return snr_launch_reduce_latent_(io.partial, io.partial + ((P + 31) / 32) * (long long)(sb + tb) * 256, ppo / 32, sb + tb,
+        return snr_launch_reduce_latent_(io.partial, io.partial + ((P + tile - 1) / tile) * (long long)(sb + tb) * 256, ppo / tile, sb + tb,
                                          a->n_rays / a->rays_per_obj, d_latent, stream_);
     return SNR_OK;
 }

@@ -438,3 +438,23 @@ def test_relu_bit_of_an_exactly_zero_preactivation_is_inactive(amd, dev, oracle_
     ref = xyz_c.grad
     err = float((d_xyz.cpu() - ref).abs().max() / ref.abs().max())
     assert err < (2e-4 if precision == "fp32" else 5e-4), err
+
+
+@pytest.mark.parametrize("P,B", [(4096, 2), (1984, 1), (96, 3)])
+def test_fp32_backward_kernels_agree(amd, dev, packed, P, B):
+    """The exact-fp32 backward has two kernels: two waves per SIMD on 16x16x4 tiles (snr_mlp16_bwd.hip: the optimiser's backward) and one wave
+    per SIMD on 32x32x2 tiles (snr_mlp_bwd.hip: taken when the training dumps are asked for).  Same products, same saved ReLU bits; the sums
+    differ in association only (16- against 32-point partial rows, four against two lane groups in the encoding gradient)."""
+    pk, _ = packed
+    ops = amd.ops
+    g = torch.Generator().manual_seed(P)
+    xyz = (torch.rand(P, 3, generator=g) * 2 - 1).to(dev); vd = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
+    lat = (torch.randn(B, 4, 256, generator=g) * 0.3).to(dev)
+    sig, rgb, masks = ops.decoder_fwd(xyz, vd, lat, pk, 3, 1, save_masks=True, precision="fp32")
+    d_sig = torch.randn(P, generator=g).to(dev); d_rgb = torch.randn(P, 3, generator=g).to(dev)
+    new = ops.decoder_bwd(xyz, vd, lat, pk, masks, sig, d_sig, d_rgb, 3, 1, precision="fp32")
+    dumps = torch.empty(3 + 1 + 4, P, 256, device=dev)          # [layer][P][256], as DecoderTrain.backward allocates them
+    old = ops.decoder_bwd(xyz, vd, lat, pk, masks, sig, d_sig, d_rgb, 3, 1, precision="fp32", layer_grads=dumps)
+    for a, b, name in zip(new, old, ("d_latent", "d_xyz", "d_viewdir")):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-6 * scale, name

@@ -73,13 +73,17 @@ def setup(name):
         x = (m_v ^ masks); nbits = int(sum(((x >> k) & 1).sum() for k in range(8)))
         err += f"; ReLU bits differing from the shipped kernel's: {nbits} of {masks.numel() * 8} ({nbits / (masks.numel() * 8):.2e}); sigma {float((s_v - sig).abs().max()):.1e}"
         f1(); torch.cuda.synchronize()
-    return f0, f1, b, err, ws
+    b(); torch.cuda.synchronize()
+    return f0, f1, b, err, ws, (d_lat.clone(), d_o.clone(), d_d.clone())
 names = list(dict.fromkeys(sys.argv[1:]))
 for n in names: libs[n] = setup(n)
 res = {n: [[], [], []] for n in names}
 for rnd in range(int(os.environ.get("SNR_AB_ROUNDS", "5"))):          # interleaved rounds: clock drift hits every variant alike
     for n in names:
         for k in range(3): res[n][k].append(timed(libs[n][k], 20))
+for n in names[1:]:          # backward outputs against the first name's
+    ref, got = libs[names[0]][5], libs[n][5]
+    print(n, "backward vs", names[0], " ".join(f"{k} {float((g_ - r_).abs().max() / r_.abs().max()):.1e}" for k, r_, g_ in zip(("d_latent", "d_rays_o", "d_rays_d"), ref, got)), flush=True)
 for n in names:
     r = res[n]
     print(f"{n:14s} fwd {min(r[0]):.4f} (med {sorted(r[0])[len(r[0]) // 2]:.4f})   fwd+bits {min(r[1]):.4f} (med {sorted(r[1])[len(r[1]) // 2]:.4f})   "

@@ -6,5 +6,5 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 out=tools/_diag/libsupnerf_stamps_${name}.so
 hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -shared -DSNR_STAMPS "$@" \
-    sup-nerf_amd/csrc/snr_aux.hip sup-nerf_amd/csrc/snr_mlp.hip sup-nerf_amd/csrc/snr_mlp_bwd.hip sup-nerf_amd/csrc/snr_bf16.hip -o $out
+    -Isup-nerf_amd/csrc sup-nerf_amd/csrc/snr_aux.hip sup-nerf_amd/csrc/snr_mlp.hip sup-nerf_amd/csrc/snr_mlp16.hip sup-nerf_amd/csrc/snr_mlp16_bwd.hip sup-nerf_amd/csrc/snr_mlp_bwd.hip sup-nerf_amd/csrc/snr_bf16.hip -o $out
 echo $out
