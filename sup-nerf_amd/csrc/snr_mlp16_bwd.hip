@@ -11,8 +11,8 @@
 //   * fp32 MFMAs execute on the vector ALUs: non-matrix instructions are not hidden, so the boundary work is kept small --
 //     the density head's term is one 64-fma pass before enc_shape^T, the latent-term gradient a DPP reduce-scatter over the wave's 16
 //     points (128 VALU per latent layer).
-//   * Latent-gradient partials: one row per 16-point wave tile ([tiles16][n_lat][256]; the 32x32x2 kernel writes one per 32 points), summed
-//     by the same deterministic tree kernel.
+//   * Latent-gradient partials: one row per 64-point workgroup ([tiles64][n_lat][256]; the 32x32x2 kernel writes one per 32 points): the four
+//     waves' rows meet in LDS behind the next chunk rendezvous; summed by the same deterministic tree kernel.
 // Not here: the training dumps (layer_grads) -- the exact-fp32 training backward stays on snr_mlp_bwd.hip's kernel.
 #include "snr_mlp16_core.hpp"
 #include "snr_host.hpp"
@@ -20,9 +20,9 @@
 namespace snr {
 
 constexpr int WBUFB = K_VIEW_PAD * KC;              // floats per ring buffer of the backward stream: 288 rows x 32 (36 KiB)
-// LDS map of the backward (floats): [ring 0 | ring 1 | sigma_w 256 | part 64]; the composite scratch (start of the kernel) lies over ring
+// LDS map of the backward (floats): [ring 0 | ring 1 | sigma_w 256 | part 64 | latent-gradient rows 4 x 256]; the composite scratch (start of the kernel) lies over ring
 // buffer 1, the positional-encoding scratch (end of the kernel) over ring buffer 0
-constexpr int LB_RING1 = WBUFB, LB_SIGW = 2 * WBUFB, LB_PART = LB_SIGW + 256, LB_TOTAL = LB_PART + 64;
+constexpr int LB_RING1 = WBUFB, LB_SIGW = 2 * WBUFB, LB_PART = LB_SIGW + 256, LB_RED = LB_PART + 64, LB_TOTAL = LB_RED + 4 * 256;
 static_assert(LB_TOTAL * 4 <= 80 * 1024, "two workgroups per CU");
 static_assert(4 * PE_WAVE16 <= WBUFB && 64 * COMP_STRIDE <= WBUFB, "scratch aliases");
 
@@ -56,9 +56,11 @@ __device__ __forceinline__ float masked(float v, const uint32_t (&mw)[4], int T,
 // One transposed layer.  NT output tiles (16: 256 rows; 18: enc_viewdir^T, 288 rows; 4: enc_xyz^T), NCH chunks of 32 k (8; 4 for rgb.0^T).
 // FROM_ACC: the operand tiles are accP's, masked by mw (all ones: no activation); else the explicit tiles xin[2 NCH].
 // On entry the layer's first chunk is in the current buffer; at its last chunk it requests `next_first` (next_rows rows; 0 = none).
-template <int NT, int NCH, bool FROM_ACC>
+// after_first_turn(): called behind the layer's first chunk rendezvous (the workgroup's latent-gradient rows of the layer before are complete then).
+struct Nothing { __device__ __forceinline__ void operator()() const {} };
+template <int NT, int NCH, bool FROM_ACC, class After = Nothing>
 __device__ __forceinline__ void layer_b(f32x4 (&accP)[18], const f32x4* xin, RingB& ring, float* lds, const uint32_t (&mw)[4], const Dma16& dm,
-                                        const float* base, const float* next_first, int next_rows) {
+                                        const float* base, const float* next_first, int next_rows, After&& after_first_turn = Nothing()) {
     f32x4 accC[18];
     f32x4 a0, a1;
     constexpr int rows = NT * 16, chunk_floats = rows * KC, NG = NT / 2;
@@ -100,12 +102,15 @@ __device__ __forceinline__ void layer_b(f32x4 (&accP)[18], const f32x4* xin, Rin
             });
         }
         ring_turn_b(ring);
+        if (ch == 0) after_first_turn();
     }
 }
 
 // enc_xyz^T (256 -> 64 features: 4 output tiles, 8 chunks of 64 rows): four chunks at a time (one 32 KiB piece of the stream = one ring
 // buffer), so the layer has two ring turns instead of eight -- a 64-row chunk is 32 MFMAs per wave, less than the latency of its own DMA.
-__device__ __forceinline__ void layer_xyz_b(f32x4 (&accP)[18], RingB& ring, float* lds, const uint32_t (&mw)[4], const Dma16& dm, const float* base) {
+template <class After>
+__device__ __forceinline__ void layer_xyz_b(f32x4 (&accP)[18], RingB& ring, float* lds, const uint32_t (&mw)[4], const Dma16& dm, const float* base,
+                                            After&& after_first_turn) {
     f32x4 accC[4];
     f32x4 a0, a1, xa, xb;
     constexpr int CH = K_XYZ_PAD * KC;          // floats per chunk
@@ -141,6 +146,7 @@ __device__ __forceinline__ void layer_xyz_b(f32x4 (&accP)[18], RingB& ring, floa
             else tile_mma<4, 0>(accC, accP, xb, wc + ring.aoff[1], a0, a1, wn, mask_a);
         }
         ring_turn_b(ring);
+        if (sc == 0) after_first_turn();
     }
 }
 
@@ -149,20 +155,22 @@ __device__ __forceinline__ void layer_xyz_b(f32x4 (&accP)[18], RingB& ring, floa
 // bit 2 (row_half_mirror) and T | T + 4 -- the two halves of a pair sum different register sets (bank_mask), so every step halves the live
 // registers --, C and D are plain sums inside a quad.  Lane i of a row ends with the sums of tiles 8 b3 + 4 b2 + {0..3}, i.e. features
 // 16 T + 4 g + r; one lane per quad stores them: 128 VALU instructions instead of 256 for four row sums per value.  asm volatile keeps the
-// statements in order (every DPP read >= 2 instructions behind the write of its source).
+// statements in order (every DPP read >= 2 instructions behind the write of its source).  The wave's 256 sums go to its row of the workgroup's
+// LDS block; behind the next chunk rendezvous the four rows are added in wave order and ONE row per 64-point workgroup goes to the workspace
+// (flush_latent_rows): a quarter of the partial rows of a store per wave, and one level less in the reduction tree.
 #define SNR_DPP_SELF(R, CTRL, BANK) asm volatile("v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:" BANK : "+v"(R))
 #define SNR_DPP_FROM(R0, R1, CTRL, BANK) asm volatile("v_add_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:" BANK : "+v"(R0) : "v"(R1))
-__device__ __forceinline__ void reduce16_store(const f32x4 (&acc)[18], float* __restrict__ dst /* 256 floats of this wave tile and latent layer */, int lane) {
+__device__ __forceinline__ void reduce16_store(const f32x4 (&acc)[18], float* dst /* the wave's 256-float row in LDS */, int lane, bool tile_live) {
     const int i = lane & 15, g = lane >> 4;
-    float v[16][4];
-#pragma unroll
-    for (int T = 0; T < 16; ++T)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v[T][r] = acc[T][r]; asm volatile("" : "+v"(v[T][r])); }
+    // step A writes fresh registers (the accumulators stay: they are the next layer's operands): the two halves of a row write complementary banks
+    float v[8][4];
 #pragma unroll
     for (int T = 0; T < 8; ++T)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { SNR_DPP_SELF(v[T][r], "row_mirror", "0x3"); SNR_DPP_FROM(v[T][r], v[T + 8][r], "row_mirror", "0xc"); }
+        for (int r = 0; r < 4; ++r) {
+            asm volatile("v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0x3" : "=&v"(v[T][r]) : "v"(acc[T][r]));
+            asm volatile("v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc" : "+v"(v[T][r]) : "v"(acc[T + 8][r]));
+        }
 #pragma unroll
     for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -178,8 +186,13 @@ __device__ __forceinline__ void reduce16_store(const f32x4 (&acc)[18], float* __
     if ((i & 3) == 0) {
         const int T0 = 8 * ((i >> 3) & 1) + 4 * ((i >> 2) & 1);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(dst + 16 * (T0 + t) + 4 * g) = f32x4{v[t][0], v[t][1], v[t][2], v[t][3]};
+        for (int t = 0; t < 4; ++t)       // (a wave tile past the end of the launch holds copies of the last point: it contributes zeros)
+            *reinterpret_cast<f32x4*>(dst + 16 * (T0 + t) + 4 * g) = tile_live ? f32x4{v[t][0], v[t][1], v[t][2], v[t][3]} : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+}
+__device__ __forceinline__ void flush_latent_rows(const float* red /* lds + LB_RED */, float* __restrict__ dst /* the workgroup's 256 floats */, int tid) {
+    const float s = ((red[tid] + red[256 + tid]) + red[512 + tid]) + red[768 + tid];
+    dst[tid] = s;
 }
 
 // Tail of the render-mode backward for 16 points per wave (all 256 threads; 64 consecutive sample points, S divides 64; the four lane groups
@@ -398,6 +411,11 @@ decoder_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const fl
 #endif
     // ---- 256-wide layers in reverse: texture .., enc_viewdir, enc_shape, shape ..
     f32x4 gdir[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    int la_pending = -1;               // latent layer whose four wave rows wait in LDS for the next rendezvous
+    auto flush = [&]() {
+        if (la_pending >= 0) flush_latent_rows(lds + LB_RED, io.partial + (tile64 * L.n_lat + la_pending) * 256, tid);
+        la_pending = -1;
+    };
 #pragma unroll 1
     for (int li = li_last; li >= 1; --li) {
         const bool relu = (li != li_encshape);
@@ -416,11 +434,11 @@ decoder_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const fl
         load_bits(li - 1 >= 1 ? relu_slot(li - 1, sb) : 0, mw_next);
         const float* base = layer_base(li);
         const float* nxt = (li - 1 >= 1) ? layer_base(li - 1) : layer_base(0);
-        if (li == li_view) layer_b<18, 8, true>(accP, nullptr, ring, lds, mw, dm, base, nxt, rows_of(li - 1));
-        else layer_b<16, 8, true>(accP, nullptr, ring, lds, mw, dm, base, nxt, rows_of(li - 1));
+        if (li == li_view) layer_b<18, 8, true>(accP, nullptr, ring, lds, mw, dm, base, nxt, rows_of(li - 1), flush);
+        else layer_b<16, 8, true>(accP, nullptr, ring, lds, mw, dm, base, nxt, rows_of(li - 1), flush);
         // accP = gradient wrt the INPUT of layer li = previous output + latent term
         const int la = latent_after(li - 1, sb, tb);
-        if (la >= 0 && io.partial && tile_live) reduce16_store(accP, io.partial + (tile16 * L.n_lat + la) * 256, lane);
+        if (la >= 0 && io.partial) { reduce16_store(accP, lds + LB_RED + wave * 256, lane, tile_live); la_pending = la; }
         if (li == li_view) { gdir[0] = accP[16]; gdir[1] = accP[17];
 #ifndef SNR16_TAILSTAMPS
             SNR16_BSTAMP(4);
@@ -430,7 +448,7 @@ decoder_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const fl
     SNR16_BSTAMP(5);
 
     // ---- enc_xyz^T : 256 -> 64 positional-encoding features
-    layer_xyz_b(accP, ring, lds, mw_next, dm, layer_base(0));
+    layer_xyz_b(accP, ring, lds, mw_next, dm, layer_base(0), flush);
 
     SNR16_BSTAMP(6);
     SNR16_PRIO(3);
@@ -498,11 +516,11 @@ decoder_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const fl
 
 using namespace snr;
 
-// supported: the fused render needs a ray inside 64 points; the latent gradient whole 16-point wave tiles per object
+// supported: the fused render needs a ray inside 64 points; the latent gradient whole 64-point workgroups per object
 int snr_fp32_bwd16_supported_(int mode, const BwdIO& io, const RayGeom& g) {
     if (io.gdump) return 0;
     if (mode == 1 && !(g.S <= 64 && 64 % g.S == 0)) return 0;
-    if (io.partial && (io.points_per_obj % 16) != 0) return 0;
+    if (io.partial && (io.points_per_obj % 64) != 0) return 0;
     return 1;
 }
 int snr_fp32_bwd16_launch_(int mode, const BwdIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, void* stream_) {

@@ -352,13 +352,13 @@ int snr_bf16_launch_bwd_(int mode, const BwdIO& io, const Layout& L, const float
 int snr_fp32_bwd16_supported_(int mode, const BwdIO& io, const RayGeom& g);
 int snr_fp32_bwd16_launch_(int mode, const BwdIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, void* stream_);
 
-// workspace = per-wave-tile partial latent gradients [tiles][n_lat][256] + the reduction tree's scratch; sized for the smallest wave tile
-// any kernel uses (16 points: snr_mlp16_bwd.hip; the others write one row per 32 points)
+// workspace = partial latent gradients [tiles][n_lat][256] + the reduction tree's scratch; sized for the smallest tile any kernel
+// writes a row for (32 points: a wave tile of the 32x32 kernels; snr_mlp16_bwd.hip writes one row per 64-point workgroup)
 static size_t bwd_ws_bytes(int64_t n_points, int64_t points_per_obj, int sb, int tb) {
-    const int64_t tiles = (n_points + 15) / 16;
+    const int64_t tiles = (n_points + 31) / 32;
     const int64_t ppo = points_per_obj > 0 ? points_per_obj : n_points;
     const int64_t n_obj = ppo > 0 ? (n_points + ppo - 1) / ppo : 1;
-    const int64_t tree = snr_reduce_scratch_floats_((ppo + 15) / 16, sb + tb, n_obj);
+    const int64_t tree = snr_reduce_scratch_floats_((ppo + 31) / 32, sb + tb, n_obj);
     return (size_t)((tiles * (int64_t)(sb + tb) * 256 + tree) * sizeof(float) + 256);
 }
 
@@ -366,7 +366,7 @@ static size_t bwd_ws_bytes(int64_t n_points, int64_t points_per_obj, int sb, int
 // one-wave 32x32x2 kernel of rounds 1-3 (-DSNR_BWD32: always, for A/B timing).  *tile = points per partial row.
 static int launch_fp32_bwd(int mode, const BwdIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, void* stream_, int* tile) {
 #ifndef SNR_BWD32
-    if (snr_fp32_bwd16_supported_(mode, io, g)) { *tile = 16; return snr_fp32_bwd16_launch_(mode, io, L, xyz, viewdir, g, stream_); }
+    if (snr_fp32_bwd16_supported_(mode, io, g)) { *tile = 64; return snr_fp32_bwd16_launch_(mode, io, L, xyz, viewdir, g, stream_); }
 #endif
     *tile = 32;
     const unsigned grid = (unsigned)((io.n_points + 127) / 128);
