@@ -266,6 +266,21 @@ __device__ __forceinline__ void pin(FOp& o) { asm volatile("" : "+v"(o.hi), "+v"
         if (SNR_IL16_VALU) __builtin_amdgcn_sched_group_barrier(0x002, SNR_IL16_VALU, 0);\
     }
 
+// the backward's groups (bf16_bwd16_kernel) take the same form of request; measured (tools/ab_time.py, two boxes, interleaved rounds, ms):
+// 1:1 0.5879 / 0.6029, 1:0 0.5882, 1:2 0.6036, 2:3 0.5926, 3:3 0.5960 / 0.6109, 1:3 0.5992, 2:2 0.6127, 3:2 0.6154, 4:4 0.6191, 1:4 0.6016,
+// 2:1 0.6024, 3:4 0.6209, 6:6 0.6250; the 32x32x16 kernel of rounds 1-3 on the same boxes: 0.6031 / 0.6198
+#ifndef SNR_IL16B_MFMA
+#define SNR_IL16B_MFMA 1
+#endif
+#ifndef SNR_IL16B_VALU
+#define SNR_IL16B_VALU 1
+#endif
+#define SNR_INTERLEAVE16B(N_MFMA)                                                        \
+    _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA) / SNR_IL16B_MFMA; ++g_) {           \
+        __builtin_amdgcn_sched_group_barrier(0x008, SNR_IL16B_MFMA, 0);                  \
+        if (SNR_IL16B_VALU) __builtin_amdgcn_sched_group_barrier(0x002, SNR_IL16B_VALU, 0);\
+    }
+
 struct Frag16 { fwdx8 hi[4], lo[4]; };        // A fragments of four 16-row tiles (one group): 8 KiB of the chunk, contiguous
 __device__ __forceinline__ void load16(Frag16& f, const char* wq /* chunk + group offset + lane*16 */) {
 #pragma unroll
@@ -1157,11 +1172,450 @@ bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* 
     SNR_BSTAMP(14);
 }
 
+// ------------------------------------------------------------------------------------------ backward on v_mfma_f32_16x16x32_bf16
+// Round 4: the backward chain on the shape the forward took in round 3 (the chip holds a higher clock on it in MFMA-dense loops, see the
+// forward's header).  Same structure as bf16_bwd_kernel above -- G_in = W^T G_out per layer, the finished sums of a layer are the next
+// layer's B operands, all eight operand steps of a layer stay in registers (enc_viewdir^T's direction tiles multiply them afterwards),
+// the previous layer's ReLU mask + hi/lo split spread under the MFMAs, bf16 pieces (gradients need the exponent range) -- on tiles of
+// 16 features x 16 points: the wave's 32 points are two column blocks c; register r of lane (n = lane & 15, g = lane >> 4) of tile T of
+// block c = feature 16 T + 4 g + r of point 16 c + n; operand step S (32 k) = tiles 2S, 2S+1.  Chunk = one k32-step of the 16 output
+// tiles (32 KiB, four groups of four tiles); the transposed stream is packed for this shape (pack_bf16_kernel, transpose == 2).
+// -DSNR_BWD_BF32 builds the 32x32x16 kernel of rounds 1-3 instead (A/B timing).
+struct Frag16B { bf16x8 hi[4], lo[4]; };
+__device__ __forceinline__ void load16b(Frag16B& f, const char* wq /* chunk + group offset + lane*16 */) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f.hi[t] = *reinterpret_cast<const bf16x8*>(wq + (2 * t) * 1024);
+        f.lo[t] = *reinterpret_cast<const bf16x8*>(wq + (2 * t + 1) * 1024);
+    }
+}
+#define SNR_MFMA16B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+// 24 MFMAs of one group.  ZERO: the layer's first step, the sums start from the constant 0; TO_P: its last, they go to the dead previous set.
+template <int T0, bool ZERO, bool TO_P>
+__device__ __forceinline__ void mma16b(f32x4 (&accC)[2][16], f32x4 (&accP)[2][16], const XOp (&x)[2], const Frag16B& f) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 a = SNR_MFMA16B(f.hi[t], x[c].hi, ZERO ? zero4 : accC[c][T0 + t]);
+            a = SNR_MFMA16B(f.hi[t], x[c].lo, a);
+            a = SNR_MFMA16B(f.lo[t], x[c].hi, a);
+            if (TO_P) accP[c][T0 + t] = a; else accC[c][T0 + t] = a;
+        }
+}
+// one whole k32-step of 16 tiles straight from a chunk (rgb.0^T: its operands come from the colour head, nothing to hide under it)
+template <bool ZERO>
+__device__ __forceinline__ void step_mma16b(f32x4 (&acc)[2][16], const XOp (&x)[2], const char* ws) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + (2 * t) * 1024);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ws + (2 * t + 1) * 1024);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 a = SNR_MFMA16B(ah, x[c].hi, ZERO ? zero4 : acc[c][t]);
+            a = SNR_MFMA16B(ah, x[c].lo, a);
+            acc[c][t] = SNR_MFMA16B(al, x[c].hi, a);
+        }
+    }
+}
+
+// Latent-term gradient of one layer in this layout: the two column blocks are added, then the reduce-scatter over the 16 point lanes of a
+// DPP row (A: row_mirror, tiles T | T + 8; B: row_half_mirror, T | T + 4; C, D: quad sums): lane i of row g ends with the sums of tiles
+// 8 b3 + 4 b2 + {0..3}, features 16 T + 4 g + r; one lane per quad parks them in LDS.  192 VALU instructions (the 32x32 form: 416).
+__device__ __forceinline__ void reduce_tiles16_dpp(const f32x4 (&acc)[2][16], float* __restrict__ out /*LDS, 256*/, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    float s[16][4], v[8][4];
+#pragma unroll
+    for (int T = 0; T < 16; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[T][r] = acc[0][T][r] + acc[1][T][r]; asm volatile("" : "+v"(s[T][r])); }
+#pragma unroll
+    for (int T = 0; T < 8; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            asm volatile("v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0x3" : "=&v"(v[T][r]) : "v"(s[T][r]));
+            asm volatile("v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc" : "+v"(v[T][r]) : "v"(s[T + 8][r]));
+        }
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { SNR_DPP_SELF(v[T][r], "row_half_mirror", "0x5"); SNR_DPP_FROM(v[T][r], v[T + 4][r], "row_half_mirror", "0xa"); }
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) SNR_DPP_SELF(v[T][r], "quad_perm:[1,0,3,2]", "0xf");
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) SNR_DPP_SELF(v[T][r], "quad_perm:[2,3,0,1]", "0xf");
+    if ((i & 3) == 0) {
+        const int T0 = 8 * ((i >> 3) & 1) + 4 * ((i >> 2) & 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(out + 16 * (T0 + t) + 4 * g) = f32x4{v[t][0], v[t][1], v[t][2], v[t][3]};
+    }
+}
+
+struct BwdEpi16 {
+    uint32_t m[4];        // ReLU bits of the layer for the lane's two points: bit 8 (T & 3) + 4 c + r of word T >> 2 (all ones: no activation)
+    const float* wsig;    // LDS: density-head weights (only below enc_shape: null otherwise)
+    float dpre[2];        // d loss / d (pre-softplus density) of the lane's two points
+    float* dzl;           // LDS: where this wave parks the layer's latent-term gradient (256 floats), or null
+    float* dump[2];       // DUMP (training): the lane's rows of the pre-activation gradient dump, [point][256] + 4 g, or null
+};
+// four values (features 16 T + 4 g .. +3 of point 16 c + n) -> elements 4 HALF .. +3 of an operand step, the saved ReLU bit applied
+template <int HALF, bool DUMP>
+__device__ __forceinline__ void bwd_conv16(const f32x4& acc, XOp& o, const BwdEpi16& c, int T, int cblk) {
+    f32x4 dv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int keep = __builtin_amdgcn_sbfe((int)c.m[T >> 2], 8 * (T & 3) + 4 * cblk + e, 1);
+        const float a = acc[e];           // (a copy first: __builtin_bit_cast on the vector-element lvalue itself reads element 0)
+        const float v = __uint_as_float(__float_as_uint(a) & (uint32_t)keep);
+        split_store(v, o, 4 * HALF + e);
+        if (DUMP) dv[e] = v;
+    }
+    if (DUMP) { if (c.dump[cblk]) *reinterpret_cast<f32x4*>(c.dump[cblk] + 16 * T) = dv; }
+    if (HALF == 1) pin(o);
+}
+
+// One transposed layer: NT16 output tiles (16: a 256-row layer, one k32-step per chunk; 4: enc_xyz^T, four steps per chunk, the stream's
+// last layer) from the 16 tiles of accP; the operand steps are made from accP one step ahead of their use and ALL kept (x[8][2]); the sums
+// build up in a local set and the last step deposits them in accP.  `ninth` (enc_viewdir^T): the two direction tiles follow from one more
+// chunk ([step][tile 2][plane][lane]) against the kept operand steps.
+template <int NT16, bool DUMP>
+__device__ __forceinline__ void layer_bwd16(f32x4 (&accP)[2][16], f32x4 (&accD)[2][2], XOp (&x)[8][2], Ring& ring, char* lds, const BwdEpi16& c,
+                                            bool ninth, int lane) {
+    f32x4 accC[2][16];
+    const int g = lane >> 4;
+    const unsigned voff = lane * 16u + 4096u;
+    constexpr int GPS = NT16 / 4;                     // groups per step
+    constexpr int NG = 8 * GPS;                       // groups of the layer
+    constexpr bool TAIL = (NT16 != 16);               // enc_xyz^T: the stream ends with this layer
+    constexpr int NCH = NG / 4;                       // chunks of this layer
+    if (c.dzl) reduce_tiles16_dpp(accP, c.dzl, lane);
+    if (c.wsig) {       // below enc_shape the density head adds d_pre * w_sigma (one pass on the finished tiles)
+#pragma unroll
+        for (int T = 0; T < 16; ++T) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(c.wsig + 16 * T + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { accP[0][T][e] = fmaf(c.dpre[0], wv[e], accP[0][T][e]); accP[1][T][e] = fmaf(c.dpre[1], wv[e], accP[1][T][e]); }
+        }
+    }
+    bwd_conv16<0, DUMP>(accP[0][0], x[0][0], c, 0, 0); bwd_conv16<1, DUMP>(accP[0][1], x[0][0], c, 1, 0);
+    bwd_conv16<0, DUMP>(accP[1][0], x[0][1], c, 0, 1); bwd_conv16<1, DUMP>(accP[1][1], x[0][1], c, 1, 1);
+    Frag16B fa, fb;
+    const char* w = ring_acquire<TAIL && NCH == 1>(ring, lds) + lane * 16;
+    load16b(fa, w);
+    if constexpr (!TAIL || 2 < NCH) ring_pieces<0, 2>(ring, voff);
+    // group G: step S = G / GPS, tiles 4 (G % GPS); position Q = G % 4 in its chunk W = G / 4
+#define SNR_GROUP16B(G, FCUR, FNXT)                                                                                        \
+    {                                                                                                                      \
+        constexpr int S_ = (G) / GPS, T0_ = 4 * ((G) % GPS), Q_ = (G) % 4, W_ = (G) / 4;                                   \
+        if constexpr (Q_ != 3) load16b(FNXT, w + (Q_ + 1) * 8192);                                                         \
+        else if constexpr ((G) + 1 < NG) { w = ring_acquire<TAIL && W_ + 1 == NCH - 1>(ring, lds) + lane * 16; load16b(FNXT, w); } \
+        mma16b<T0_, S_ == 0, S_ == 7>(accC, accP, x[S_], FCUR);                                                            \
+        if constexpr (Q_ != 3) { if constexpr (!TAIL || W_ + 2 < NCH) ring_pieces<2 * Q_ + 2, 2>(ring, voff); }            \
+        else if constexpr ((G) + 1 < NG) { if constexpr (!TAIL || W_ + 3 < NCH) ring_pieces<0, 2>(ring, voff); }           \
+        if constexpr (S_ != 7) {                                                                                           \
+            /* operand step S+1: four tile conversions (c0 h0, c0 h1, c1 h0, c1 h1) over the GPS groups of step S */      \
+            constexpr int E0_ = ((G) % GPS) * (4 / GPS);                                                                   \
+            _Pragma("unroll") for (int e_ = E0_; e_ < E0_ + 4 / GPS; ++e_) {                                               \
+                const int cb_ = e_ >> 1, hf_ = e_ & 1, T_ = 2 * (S_ + 1) + hf_;                                            \
+                if (hf_ == 0) bwd_conv16<0, DUMP>(accP[cb_][T_], x[S_ + 1][cb_], c, T_, cb_);                              \
+                else bwd_conv16<1, DUMP>(accP[cb_][T_], x[S_ + 1][cb_], c, T_, cb_);                                       \
+            }                                                                                                              \
+        }                                                                                                                  \
+        SNR_INTERLEAVE16B(24)                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }
+#define SNR_GROUP16B_PAIR(G) SNR_GROUP16B(G, fa, fb) SNR_GROUP16B((G) + 1, fb, fa)
+    SNR_GROUP16B_PAIR(0) SNR_GROUP16B_PAIR(2) SNR_GROUP16B_PAIR(4) SNR_GROUP16B_PAIR(6)
+    if constexpr (NG == 32) {
+        SNR_GROUP16B_PAIR(8) SNR_GROUP16B_PAIR(10) SNR_GROUP16B_PAIR(12) SNR_GROUP16B_PAIR(14)
+        SNR_GROUP16B_PAIR(16) SNR_GROUP16B_PAIR(18) SNR_GROUP16B_PAIR(20) SNR_GROUP16B_PAIR(22)
+        SNR_GROUP16B_PAIR(24) SNR_GROUP16B_PAIR(26) SNR_GROUP16B_PAIR(28) SNR_GROUP16B_PAIR(30)
+    }
+#undef SNR_GROUP16B_PAIR
+#undef SNR_GROUP16B
+    if (NT16 == 16 && ninth) {
+        w = ring_acquire(ring, lds) + lane * 16;
+        ring_pieces<0, 8>(ring, voff);
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(w + s2 * 4096 + t * 2048);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(w + s2 * 4096 + t * 2048 + 1024);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    f32x4 a = SNR_MFMA16B(ah, x[s2][cb].hi, accD[cb][t]);
+                    a = SNR_MFMA16B(ah, x[s2][cb].lo, a);
+                    accD[cb][t] = SNR_MFMA16B(al, x[s2][cb].hi, a);
+                }
+            }
+    }
+}
+
+template <int MODE, bool DUMP = false>      // DUMP (training): io.gdump receives the gradient wrt every MFMA layer's pre-activation
+__global__ void __launch_bounds__(256, 1)
+bf16_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom g) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5, n16 = lane & 15, gq = lane >> 4;
+    const long long tile128 = blockIdx.x;
+    const long long tile32 = tile128 * 4 + wave;
+    const long long gp_raw = tile128 * 128 + wave * 32 + p;
+    const bool live = gp_raw < io.n_points;
+    const long long gp = live ? gp_raw : io.n_points - 1;
+    const int sb = io.sb, tb = io.tb;
+    const int n_relu = n_relu_layers(sb, tb);
+    const int li_encshape = sb + 1, li_view = sb + 2, li_last = sb + tb + 2;
+    float* vec = reinterpret_cast<float*>(lds + OFF_VEC);
+
+    // ---- everything that needs an ordinary global load happens before the DMA ring starts
+    vec[VEC_SIGW + tid] = io.packed[L.sigma_w + tid];
+    vec[VEC_ZERO + tid] = 0.f;
+    for (int i = tid; i < 384; i += 256) vec[VEC_RGBW + i] = io.packed[L.rgb2_w + i];
+    const bool tile_live = tile32 * 32 < io.n_points;         // wave tiles past the end (last workgroup) read and store nothing
+    // ReLU bits of every ReLU layer for the lane's two points 16 c + n, features 16 T + 4 g + r: in the documented layout (snr_layout.h) they
+    // are the nibbles 2 (T & 3) + (g >> 1) of word T >> 2 of lane slot 32 (g & 1) + 16 c + n; block 0's go to the low nibble of every byte,
+    // block 1's to the high one: bit 8 (T & 3) + 4 c + r of word T >> 2
+    uint4 mk[MAX_LAYERS - 1];
+    {
+        const int sh = 4 * (gq >> 1);
+#pragma unroll
+        for (int s = 0; s < MAX_LAYERS - 1; ++s) {
+            uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+            if (s < n_relu && tile_live) {
+                const uint4* row = io.masks + (tile32 * n_relu + s) * 64 + 32 * (gq & 1) + n16;
+                a = row[0]; b = row[16];
+            }
+            mk[s].x = ((a.x >> sh) & 0x0F0F0F0Fu) | (((b.x >> sh) & 0x0F0F0F0Fu) << 4);
+            mk[s].y = ((a.y >> sh) & 0x0F0F0F0Fu) | (((b.y >> sh) & 0x0F0F0F0Fu) << 4);
+            mk[s].z = ((a.z >> sh) & 0x0F0F0F0Fu) | (((b.z >> sh) & 0x0F0F0F0Fu) << 4);
+            mk[s].w = ((a.w >> sh) & 0x0F0F0F0Fu) | (((b.w >> sh) & 0x0F0F0F0Fu) << 4);
+        }
+    }
+    float px_, py_, pz_, dx, dy, dz, tval = 0.f, zc = 0.f, uval = 0.f;
+    long long ray = 0;
+    if (MODE == 0) {
+        px_ = xyz[gp * 3]; py_ = xyz[gp * 3 + 1]; pz_ = xyz[gp * 3 + 2];
+        dx = viewdir[gp * 3]; dy = viewdir[gp * 3 + 1]; dz = viewdir[gp * 3 + 2];
+    } else {
+        ray = gp / g.S;
+        const SamplePoint sp = make_sample(g, ray, (int)(gp - ray * g.S));
+        px_ = sp.x; py_ = sp.y; pz_ = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc; tval = sp.t; uval = sp.u;
+    }
+    const float sig_gp = io.sigmas[gp];
+    float gs = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gzc = 0.f;
+    float* comp = reinterpret_cast<float*>(lds + OFF_COMP);
+    if (MODE == 0) {
+        if (live) {
+            gs = io.d_sigmas ? io.d_sigmas[gp] : 0.f;
+            if (io.d_rgbs) { gr = io.d_rgbs[gp * 3]; gg = io.d_rgbs[gp * 3 + 1]; gb = io.d_rgbs[gp * 3 + 2]; }
+        }
+    } else {
+        if (lane < 32) comp[(wave * 32 + p) * COMP_STRIDE + 5] = zc;
+        __syncthreads();
+        const int S = g.S;
+        const int rays_here = 128 / S;
+        const bool white = g.flags & SNR_WHITE_BKGD;
+        for (int r = wave; r < rays_here; r += 4) {
+            const long long rr = tile128 * rays_here + r;
+            if (rr >= g.n_rays) break;
+            float* c0 = comp + r * S * COMP_STRIDE;
+            const float* srow = io.sigmas + rr * S;
+            const float* crow = io.rgbs + rr * S * 3;
+            const float ur = io.d_rgb ? io.d_rgb[rr * 3] : 0.f, ug = io.d_rgb ? io.d_rgb[rr * 3 + 1] : 0.f,
+                        ub = io.d_rgb ? io.d_rgb[rr * 3 + 2] : 0.f;
+            const float ud = io.d_depth ? io.d_depth[rr] : 0.f, ua = io.d_acc ? io.d_acc[rr] : 0.f;
+            if (S <= 64) composite_ray_bwd<1>(S, lane, white, ur, ug, ub, ud, ua,
+                [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
+                    s_ = srow[k]; r_ = crow[3 * k]; g_ = crow[3 * k + 1]; b_ = crow[3 * k + 2];
+                    z_ = c0[k * COMP_STRIDE + 5];
+                    zn_ = (k < S - 1) ? c0[(k + 1) * COMP_STRIDE + 5] : 0.f;
+                },
+                [&](int k, float ds, float dcr, float dcg, float dcb, float dzz) {
+                    float* c = c0 + k * COMP_STRIDE;
+                    c[0] = ds; c[1] = dcr; c[2] = dcg; c[3] = dcb; c[4] = dzz;
+                });
+            else composite_ray_bwd<2>(S, lane, white, ur, ug, ub, ud, ua,
+                [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
+                    s_ = srow[k]; r_ = crow[3 * k]; g_ = crow[3 * k + 1]; b_ = crow[3 * k + 2];
+                    z_ = c0[k * COMP_STRIDE + 5];
+                    zn_ = (k < S - 1) ? c0[(k + 1) * COMP_STRIDE + 5] : 0.f;
+                },
+                [&](int k, float ds, float dcr, float dcg, float dcb, float dzz) {
+                    float* c = c0 + k * COMP_STRIDE;
+                    c[0] = ds; c[1] = dcr; c[2] = dcg; c[3] = dcb; c[4] = dzz;
+                });
+        }
+        __syncthreads();
+        if (live) {
+            const float* c = comp + (wave * 32 + p) * COMP_STRIDE;
+            gs = c[0]; gr = c[1]; gg = c[2]; gb = c[3]; gzc = c[4];
+        }
+    }
+    // the point's four upstream scalars travel to the lanes (n, g) of its column block through its row of the composite scratch (rows are
+    // private to the wave from here on: LDS operations of one wave execute in order)
+    if (lane < 32) {
+        float* c = comp + (wave * 32 + p) * COMP_STRIDE;
+        c[0] = gs * (1.f - expf(-sig_gp)); c[1] = gr; c[2] = gg; c[3] = gb;
+    }
+    float dpre2[2], gr2[2], gg2[2], gb2[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const float* c = comp + (wave * 32 + 16 * cb + n16) * COMP_STRIDE;
+        dpre2[cb] = c[0]; gr2[cb] = c[1]; gg2[cb] = c[2]; gb2[cb] = c[3];
+    }
+    __syncthreads();
+
+    Ring ring;
+    const int total_chunks = 4 + 8 * tb + 9 + 8 * (sb + 1) + 2;       // enc_viewdir^T: 8 chunks + 1 for its direction tiles
+    const unsigned voff = lane * 16u + 4096u;
+    ring_start(ring, reinterpret_cast<const char*>(io.packed + L.bf_bwd), total_chunks, lds, voff);
+
+    XOp x[8][2];
+    auto mask_words = [&](int slot, uint32_t (&m)[4]) {        // runtime slot out of the register array (static unroll)
+        m[0] = m[1] = m[2] = m[3] = 0xffffffffu;
+#pragma unroll
+        for (int s = 0; s < MAX_LAYERS - 1; ++s) if (s == slot) { m[0] = mk[s].x; m[1] = mk[s].y; m[2] = mk[s].z; m[3] = mk[s].w; }
+    };
+    // ---- colour head backward on the VALU: g_h = W2^T d_rgb masked by rgb.0's ReLU -> 4 operand steps (128 features = 8 tiles)
+    {
+        uint32_t m[4];
+        mask_words(n_relu - 1, m);
+        const float* w2 = vec + VEC_RGBW;
+        float* hdump[2] = {nullptr, nullptr};       // rgb.0's G, 128 columns
+        if (DUMP) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const long long gpd = tile128 * 128 + wave * 32 + 16 * cb + n16;
+                if (gpd < io.n_points) hdump[cb] = io.gdump + ((long long)(li_last + 1) * io.n_points + gpd) * 256 + 4 * gq;
+            }
+        }
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+            const f32x4 wr = *reinterpret_cast<const f32x4*>(w2 + 16 * T + 4 * gq);
+            const f32x4 wg = *reinterpret_cast<const f32x4*>(w2 + 128 + 16 * T + 4 * gq);
+            const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + 16 * T + 4 * gq);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                f32x4 dv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = wr[e] * gr2[cb] + wg[e] * gg2[cb] + wb[e] * gb2[cb];
+                    v = ((m[T >> 2] >> (8 * (T & 3) + 4 * cb + e)) & 1u) ? v : 0.f;
+                    dv[e] = v;
+                    split_store(v, x[T >> 1][cb], 4 * (T & 1) + e);
+                }
+                if (DUMP) { if (hdump[cb]) *reinterpret_cast<f32x4*>(hdump[cb] + 16 * T) = dv; }
+            }
+        }
+    }
+
+    f32x4 accA[2][16], accD[2][2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) accD[cb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- rgb.0^T : K = 128 (4 k32-steps, one chunk each) -> accA
+    {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const char* w = ring_acquire(ring, lds) + lane * 16;
+            ring_pieces<0, 8>(ring, voff);
+            if (s == 0) step_mma16b<true>(accA, x[s], w); else step_mma16b<false>(accA, x[s], w);
+        }
+    }
+
+    auto epi_of = [&](int l) {      // how the gradient wrt (output of layer l [+ latent]) becomes the operand of W_l^T
+        BwdEpi16 c;
+        mask_words(l == li_encshape ? -1 : relu_slot(l, sb), c.m);
+        c.wsig = (l == li_encshape) ? vec + VEC_SIGW : nullptr;
+        c.dpre[0] = (l == li_encshape) ? dpre2[0] : 0.f;
+        c.dpre[1] = (l == li_encshape) ? dpre2[1] : 0.f;
+        const int la = latent_after(l, sb, tb);
+        c.dzl = (la >= 0 && io.partial) ? reinterpret_cast<float*>(lds + OFF_LAT) + (wave * MAX_LAT + la) * 256 : nullptr;
+        c.dump[0] = c.dump[1] = nullptr;
+        if (DUMP) {      // slot l = gradient wrt the pre-activation of MFMA layer l
+            int t = threadIdx.x; asm volatile("" : "+v"(t));
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const long long gpd = tile128 * 128 + wave * 32 + 16 * cb + (t & 15);
+                if (gpd < io.n_points) c.dump[cb] = io.gdump + ((long long)l * io.n_points + gpd) * 256 + 4 * ((t & 63) >> 4);
+            }
+        }
+        return c;
+    };
+#pragma unroll 1
+    for (int li = li_last; li >= 1; --li) layer_bwd16<16, DUMP>(accA, accD, x, ring, lds, epi_of(li), li == li_view, lane);
+    // ---- enc_xyz^T : 256 -> 64 positional-encoding features (four tiles)
+    layer_bwd16<4, DUMP>(accA, accD, x, ring, lds, epi_of(0), false, lane);
+
+    // ---- the parked latent-term gradients of this wave tile -> global partials (the ring is idle now)
+    if (io.partial && tile_live) {
+        const float* dzl = reinterpret_cast<const float*>(lds + OFF_LAT) + wave * MAX_LAT * 256;
+        for (int la = 0; la < L.n_lat; ++la)
+            *reinterpret_cast<f32x4*>(io.partial + (tile32 * L.n_lat + la) * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(dzl + la * 256 + lane * 4);
+    }
+    // ---- positional-encoding backward through the scratch rows (they alias ring buffer 2; the ring retired its last DMA at the final
+    // acquire): lane (n, g) writes its share of the rows of points 16 c + n, lane (p, h) reads point p's row
+    __syncthreads();
+    float* scw = reinterpret_cast<float*>(lds + OFF_PE) + (wave * 32) * PE_ROWF;
+    float* sc = scw + p * PE_ROWF;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scw[(16 * cb + n16) * PE_ROWF + 16 * T + 4 * gq + r] = accA[cb][T][r];
+    float gx = 0.f, gy = 0.f, gz = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < 15; ++i) {
+        const int q = 15 * h + i, a = q % 3, f = q / 3;
+        float sn, cs;
+        pe_sincos(ldexpf(pick3(px_, py_, pz_, a), f), &sn, &cs);
+        const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * XYZ_FREQ + q] * sn, f);
+        gx += a == 0 ? v : 0.f; gy += a == 1 ? v : 0.f; gz += a == 2 ? v : 0.f;
+    }
+    if (h == 0) { gx += sc[0]; gy += sc[1]; gz += sc[2]; }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scw[(16 * cb + n16) * PE_ROWF + 16 * t + 4 * gq + r] = accD[cb][t][r];
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) {
+        const int q = 6 * h + i, a = q % 3, f = q / 3;
+        float sn, cs;
+        pe_sincos(ldexpf(pick3(dx, dy, dz, a), f), &sn, &cs);
+        const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * DIR_FREQ + q] * sn, f);
+        hx += a == 0 ? v : 0.f; hy += a == 1 ? v : 0.f; hz += a == 2 ? v : 0.f;
+    }
+    if (h == 0) { hx += sc[0]; hy += sc[1]; hz += sc[2]; }
+    gx = sum_halves(gx); gy = sum_halves(gy); gz = sum_halves(gz);
+    hx = sum_halves(hx); hy = sum_halves(hy); hz = sum_halves(hz);
+
+    if (MODE == 0) {
+        if (live && h == 0) {
+            if (io.d_xyz) { io.d_xyz[gp * 3] = gx; io.d_xyz[gp * 3 + 1] = gy; io.d_xyz[gp * 3 + 2] = gz; }
+            if (io.d_dir) { io.d_dir[gp * 3] = hx; io.d_dir[gp * 3 + 1] = hy; io.d_dir[gp * 3 + 2] = hz; }
+        }
+        return;
+    }
+    ray_grad_tail(g, io.d_rays_o, io.d_rays_d, io.d_t, comp, tile128, ray, gp, live, tval, uval, zc, gx, gy, gz, hx, hy, hz, gzc);
+}
+
 // ------------------------------------------------------------------------------------------ packing
 // One thread per (k-step, tile, lane, j): writes the hi and the lo element of the layer image
 //   [s][tile][plane hi/lo][lane][8].
 //   backward (transpose == 1, v_mfma_f32_32x32x16_bf16): k16-steps, 32-row tiles; value = W[k][row], row = input feature, k = output
 //     feature 16 s + 8 (j >> 2) + 4 (lane >> 5) + (j & 3) -- the order in which a 32x32 accumulator tile re-enters the MFMA as B operand;
+//   backward (transpose == 2, v_mfma_f32_16x16x32_bf16, the shipped backward): k32-steps, 16-row tiles; value = W[k][row], row = 16 tile +
+//     (lane & 15) = input feature, k = output feature 32 s + 16 (j >> 2) + 4 (lane >> 4) + (j & 3);
 //   forward (transpose == 0, v_mfma_f32_16x16x32_bf16): k32-steps, 16-row tiles; value = W[row][k], row = 16 tile + (lane & 15) = output
 //     feature, k = input feature 32 s + 16 (j >> 2) + 4 (lane >> 4) + (j & 3) -- the order in which the 16x16 accumulator tiles 2s, 2s+1
 //     re-enter; k_off shifts k (enc_viewdir's direction step: features 256 .. 282 as one step of their own).
@@ -1178,6 +1632,10 @@ __global__ void pack_bf16_kernel(const float* __restrict__ Wt, int n_out, int k_
             const int row = 16 * (tile0 + tile) + (lane & 15);
             const int k = k_off + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
             if (row < n_out && k < k_in) v = Wt[(long long)row * k_in + k];
+        } else if (transpose == 2) {      // backward on 16x16x32: 16-row tiles of input features, k32-steps over the layer's outputs
+            const int row = 16 * (tile0 + tile) + (lane & 15);
+            const int k = 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+            if (row < k_in && k < n_out) v = Wt[(long long)k * k_in + row];
         } else {
             const int row = 32 * (tile0 + tile) + (lane & 31), hh = lane >> 5;
             const int k = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
@@ -1243,6 +1701,7 @@ int snr_bf16_pack_(const float* const* W /* per-point weight tensors in MFMA-lay
         const bool is_xyz = li == 0, is_view = li == sb + 2, is_rgb0 = li == n_layers - 1;
         const int n_out = is_rgb0 ? 128 : 256;
         const int k_in = is_xyz ? D_XYZ : (is_view ? 256 + D_DIR : 256);
+#ifdef SNR_BWD_BF32      /* the 32x32x16 backward of rounds 1-3 */
         const int KS = n_out / 16;                                 // reduction over the layer's outputs
         const int n_tiles = is_xyz ? 2 : 8;                        // tiles of 32 input features
         launch(W[li], n_out, k_in, 1, n_tiles, KS, reinterpret_cast<__bf16*>(b));
@@ -1251,6 +1710,16 @@ int snr_bf16_pack_(const float* const* W /* per-point weight tensors in MFMA-lay
             launch(W[li], n_out, k_in, 1, 1, KS, reinterpret_cast<__bf16*>(b), 8);
             b += 2ll * KS * 1024;
         }
+#else
+        const int KS = n_out / 32;                                 // k32-steps over the layer's outputs
+        const int n_tiles = is_xyz ? 4 : 16;                       // tiles of 16 input features
+        launch(W[li], n_out, k_in, 2, n_tiles, KS, reinterpret_cast<__bf16*>(b));
+        b += (long long)n_tiles * 2 * KS * 1024;
+        if (is_view) {                                             // the direction features: tiles 16, 17, a chunk of their own
+            launch(W[li], n_out, k_in, 2, 2, KS, reinterpret_cast<__bf16*>(b), 16);
+            b += 2ll * 2 * KS * 1024;
+        }
+#endif
     }
     if (b - reinterpret_cast<char*>(packed + L.bf_bwd) != L.bf_bwd_bytes) return SNR_E_SHAPE;
     return snr_check_launch_();
@@ -1278,10 +1747,16 @@ int snr_bf16_launch_fwd_(int mode, const DecoderIO& io, const Layout& L, const f
 
 int snr_bf16_launch_bwd_(int mode, const BwdIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, void* stream_) {
     const unsigned grid = (unsigned)((io.n_points + 127) / 128);
+#ifdef SNR_BWD_BF32
+#define SNR_BWD_KERNEL bf::bf16_bwd_kernel
+#else
+#define SNR_BWD_KERNEL bf::bf16_bwd16_kernel
+#endif
     if (io.gdump) {
         if (mode != 0) return SNR_E_ARG;
-        bf::bf16_bwd_kernel<0, true><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
-    } else if (mode == 0) bf::bf16_bwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
-    else bf::bf16_bwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
+        SNR_BWD_KERNEL<0, true><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
+    } else if (mode == 0) SNR_BWD_KERNEL<0><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
+    else SNR_BWD_KERNEL<1><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);
+#undef SNR_BWD_KERNEL
     return snr_check_launch_();
 }
