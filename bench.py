@@ -52,7 +52,7 @@ PEAK_TFLOPS = {"fp32": 157.3,    # MI355X_MICROARCH.md "Peak FP32 (matrix)": v_m
 ISSUE_FACTOR = {"fp32": 1.0, "bf16x3": 3.0}
 DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 = split 16-bit pieces (fp32 operands as hi + lo: fp16 pieces in the forward chain, bf16 pieces in the backward chain and the weight-gradient products; 3 MFMAs per product, fp32 accumulate)"}
 FWD_KERNEL = {"fp32": "decoder_fwd16_kernel<1,4,true,false,false>", "bf16x3": "bf16_fwd_kernel<1,false,true>"}
-BWD_KERNEL = {"fp32": "decoder_bwd_kernel<1>", "bf16x3": "bf16_bwd_kernel<1>"}
+BWD_KERNEL = {"fp32": "decoder_bwd16_kernel<1>", "bf16x3": "bf16_bwd16_kernel<1>"}
 N_RAYS, N_SAMPLES, IM_SZ = 4096, 64, 64
 C3_OBJECTS = 64
 

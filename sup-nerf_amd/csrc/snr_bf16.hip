@@ -333,6 +333,11 @@ __device__ __forceinline__ void epi16(const f32x4& acc, FOp& o, const Epi16& c, 
 #ifdef SNR_EXP_NOEPI
     return;
 #endif
+#ifdef SNR_EXP_EPI0      /* timing experiment: the operand step is a raw copy of accumulator bits (one move per two values) */
+    { uint32_t (&hw0)[4] = reinterpret_cast<uint32_t (&)[4]>(o.hi); uint32_t (&lw0)[4] = reinterpret_cast<uint32_t (&)[4]>(o.lo);
+      hw0[2 * HALF] = __float_as_uint(acc[0]); hw0[2 * HALF + 1] = __float_as_uint(acc[1]); lw0[2 * HALF] = __float_as_uint(acc[2]); lw0[2 * HALF + 1] = __float_as_uint(acc[3]);
+      if (HALF == 1) pin(o); return; }
+#endif
     f32x4 z;
     if (ZADD) z = *reinterpret_cast<const f32x4*>(c.zl + 16 * T + 4 * g);
     f32x4 dv;
@@ -361,7 +366,11 @@ __device__ __forceinline__ void epi16(const f32x4& acc, FOp& o, const Epi16& c, 
         const h2 hp = __builtin_amdgcn_cvt_pkrtz(xv[2 * k], xv[2 * k + 1]);
         // the remainder x - hi as ONE v_fma_mix_f32 (f32 x 1 - f16 piece; exact) instead of v_cvt_f32_f16 + v_sub_f32: three VALU
         // instructions per value in this epilogue where bf16 pieces took four (forward -1.5 %, forward with ReLU bits -2.7 %)
+#ifdef SNR_EXP_EPI1      /* timing experiment: no low piece (ReLU + one packed conversion per two values) */
+        const h2 lp = hp;
+#else
         const h2 lp = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(xv[2 * k], one_, -(float)hp[0]), __builtin_fmaf(xv[2 * k + 1], one_, -(float)hp[1]));
+#endif
         hw[2 * HALF + k] = __builtin_bit_cast(uint32_t, hp);
         lw[2 * HALF + k] = __builtin_bit_cast(uint32_t, lp);
     }
@@ -410,6 +419,12 @@ __device__ __forceinline__ void layer16(f32x4 (&accP)[2][16], Ring& ring, char* 
     const char* w = ring_acquire(ring, lds) + lane * 16;
     load16(fa, w);
     if constexpr (!TAIL || 2 < NCH) ring_pieces<0, 2>(ring, voff);
+#ifdef SNR_EXP_EPIIND     /* timing experiment: the MFMAs do not wait for the conversions (they multiply the layer's first operand step throughout) */
+    FOp x_first[2] = {xc[0], xc[1]};
+#define SNR_MMA16_CALL(T0_, LASTS_, FCUR) mma16<T0_, LASTS_>(accC, accP, x_first, FCUR); asm volatile("" :: "v"(xc[0].hi), "v"(xc[0].lo), "v"(xc[1].hi), "v"(xc[1].lo));
+#else
+#define SNR_MMA16_CALL(T0_, LASTS_, FCUR) mma16<T0_, LASTS_>(accC, accP, xc, FCUR);
+#endif
     // group G: step S = G / GPS, tiles 4 (G % GPS); position Q = G % 4 in its chunk W = G / 4
 #define SNR_GROUP16(G, FCUR, FNXT)                                                                                         \
     {                                                                                                                      \
@@ -417,7 +432,7 @@ __device__ __forceinline__ void layer16(f32x4 (&accP)[2][16], Ring& ring, char* 
         constexpr bool LASTS_ = S_ == 7;                                                                                   \
         if constexpr (Q_ != 3) load16(FNXT, w + (Q_ + 1) * 8192);                                                          \
         else if constexpr ((G) + 1 < NG) { w = ring_acquire<TAIL && W_ + 1 == NCH - 1>(ring, lds) + lane * 16; load16(FNXT, w); } \
-        mma16<T0_, LASTS_>(accC, accP, xc, FCUR);                                                                          \
+        SNR_MMA16_CALL(T0_, LASTS_, FCUR)                                                                                  \
         if constexpr (Q_ != 3) { if constexpr (!TAIL || W_ + 2 < NCH) ring_pieces<2 * Q_ + 2, 2>(ring, voff); }            \
         else if constexpr ((G) + 1 < NG) { if constexpr (!TAIL || W_ + 3 < NCH) ring_pieces<0, 2>(ring, voff); }           \
         if constexpr (!LASTS_) {                                                                                           \
@@ -442,6 +457,7 @@ __device__ __forceinline__ void layer16(f32x4 (&accP)[2][16], Ring& ring, char* 
     }
 #undef SNR_GROUP16_PAIR
 #undef SNR_GROUP16
+#undef SNR_MMA16_CALL
 }
 
 // x | x[lane ^ 32] (the two lanes hold disjoint bits): gfx950 v_permlane32_swap, no LDS round trip
@@ -1270,7 +1286,9 @@ __device__ __forceinline__ void bwd_conv16(const f32x4& acc, XOp& o, const BwdEp
     f32x4 dv;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int keep = __builtin_amdgcn_sbfe((int)c.m[T >> 2], 8 * (T & 3) + 4 * cblk + e, 1);
+        // (through asm: from the builtin LLVM makes v_and + v_cmp + v_cndmask, three VALU instructions through VCC, out of "bit ? v : 0")
+        uint32_t keep;
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(c.m[T >> 2]), "n"(8 * (T & 3) + 4 * cblk + e));
         const float a = acc[e];           // (a copy first: __builtin_bit_cast on the vector-element lvalue itself reads element 0)
         const float v = __uint_as_float(__float_as_uint(a) & (uint32_t)keep);
         split_store(v, o, 4 * HALF + e);

@@ -8,7 +8,10 @@ import supnerf_amd as A
 from supnerf_amd import _lib, ops, synthetic as SY, utils as U
 good = _lib.lib()
 dev = torch.device("cuda:0")
-model = A.CodeNeRF(3, 1); model.load_state_dict(SY.init_decoder_params()); model = model.to(dev)
+_sd = SY.init_decoder_params()
+if os.environ.get("SNR_AB_SCALE"):        # power experiment: every decoder weight scaled (0 = all-zero operands: nothing toggles in the matrix pipe)
+    _sd = {k: v * float(os.environ["SNR_AB_SCALE"]) for k, v in _sd.items()}
+model = A.CodeNeRF(3, 1); model.load_state_dict(_sd); model = model.to(dev)
 N, S = 4096, 64
 ob = SY.synthetic_object(100)
 g = torch.Generator().manual_seed(100)

@@ -53,7 +53,7 @@ find $raw -type f | head -60 > $out/raw_files.txt
 python3 - "$raw" "$out" <<'PY'
 import csv, glob, json, os, sys
 raw, out = sys.argv[1], sys.argv[2]
-for prec, fwd_name, bwd_name in (("fp32", "decoder_fwd", "decoder_bwd"), ("bf16x3", "bf16_fwd_kernel", "bf16_bwd_kernel")):
+for prec, fwd_name, bwd_name in (("fp32", "decoder_fwd", "decoder_bwd"), ("bf16x3", "bf16_fwd_kernel", "bf16_bwd")):
     for which, kname in (("fwd", fwd_name), ("bwd", bwd_name)):
         agg = {}
         for f in glob.glob(os.path.join(raw, f"pmc_*_{prec}_{which}", "**", "*counter_collection.csv"), recursive=True):
