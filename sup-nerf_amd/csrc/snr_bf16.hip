@@ -368,11 +368,16 @@ __device__ __forceinline__ void epi16(const f32x4& acc, FOp& o, const Epi16& c, 
         // instructions per value in this epilogue where bf16 pieces took four (forward -1.5 %, forward with ReLU bits -2.7 %)
 #ifdef SNR_EXP_EPI1      /* timing experiment: no low piece (ReLU + one packed conversion per two values) */
         const h2 lp = hp;
-#else
-        const h2 lp = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(xv[2 * k], one_, -(float)hp[0]), __builtin_fmaf(xv[2 * k + 1], one_, -(float)hp[1]));
-#endif
         hw[2 * HALF + k] = __builtin_bit_cast(uint32_t, hp);
         lw[2 * HALF + k] = __builtin_bit_cast(uint32_t, lp);
+#else
+        const h2 lp = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(xv[2 * k], one_, -(float)hp[0]), __builtin_fmaf(xv[2 * k + 1], one_, -(float)hp[1]));
+        hw[2 * HALF + k] = __builtin_bit_cast(uint32_t, hp);
+        lw[2 * HALF + k] = __builtin_bit_cast(uint32_t, lp);
+        // (round 4, measured and dropped: the low piece as v_fma_mixlo_f16 / v_fma_mixhi_f16 through inline asm -- 2.5 instead of 3 VALU per value,
+        // rgb 4.7e-8 instead of 5.5e-8 from the fp32 kernel's -- ran +0.6 % / +1.6 % (forward / with ReLU bits): the solver does not place asm
+        // statements under the MFMAs, and the high half is a read-modify-write of the low half's register)
+#endif
     }
 #else
 #pragma unroll
