@@ -18,6 +18,7 @@
 //     drains the DMA queue inside the layer chain.
 // Limits of this variant (the fp32 kernels have none of them): shape_blocks + texture_blocks <= 4 and
 // whole 32-point wave tiles per object.
+#include <utility>
 #include "snr_mlp_core.hpp"
 #include "snr_host.hpp"
 
@@ -395,6 +396,92 @@ __device__ __forceinline__ void epi16(const f32x4& acc, FOp& o, const Epi16& c, 
     if (MASKS) asm volatile("" : "+v"(mbits));
 }
 
+// ---- hand-placed group of the 256-wide forward layers (round 4, VERDICT r3 #2's second lever at source level): the 24 MFMAs of a group
+// with exactly one other instruction in (nearly) every gap -- the next group's eight fragment reads on the even gaps, the conversion of one
+// accumulator tile of the previous layer (12 - 25 single-instruction statements) spread over the others, the two DMA pieces behind MFMAs 16
+// and 19 -- each gap closed by sched_barrier(0), so the compiler keeps the order as written (its own scheduling inside a gap is one or two
+// instructions).  Budget per gap (MI355X_MICROARCH.md): the MFMA holds the vector issue 8 of its 16 cycles, a VALU / LDS instruction costs
+// 4: one extra instruction per gap leaves the pipe fed.  -DSNR_NO_PLACED: the sched_group_barrier request of round 3 instead (A/B).
+struct E16State {
+    float y[4], l[4];
+    f32x4 z;
+    uint32_t hpw[2];
+    uint32_t tmp;
+    float one_, lo_bound;
+};
+template <int K, int HALF, bool MASKS, bool ZADD>
+__device__ __forceinline__ void e16_op(E16State& s, const f32x4& acc, FOp& o, const Epi16& c, int T, int g, uint32_t& mbits) {
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    constexpr int PV = 1 + 2 * (MASKS ? 1 : 0) + (ZADD ? 1 : 0);
+    constexpr int K0 = ZADD ? 1 : 0;              // op 0 of a ZADD conversion: the latent values of the tile
+    if constexpr (ZADD && K == 0) { s.z = *reinterpret_cast<const f32x4*>(c.zl + 16 * T + 4 * g); return; }
+    constexpr int kk = K - K0;
+    if constexpr (kk < 4 * PV) {
+        constexpr int e = kk / PV, sub = kk % PV;
+        if constexpr (sub == 0) { const float a = acc[e]; s.y[e] = __builtin_amdgcn_fmed3f(a, s.lo_bound, 65504.f); }
+        else if constexpr (MASKS && sub == 1) s.tmp = __builtin_bit_cast(uint32_t, s.y[e]) - 1u;
+        else if constexpr (MASKS && sub == 2) mbits = __builtin_amdgcn_alignbit(mbits, s.tmp, 31);
+        else s.y[e] = s.y[e] + s.z[e];
+    } else {
+        constexpr int k2 = kk - 4 * PV;
+        uint32_t (&hw)[4] = reinterpret_cast<uint32_t (&)[4]>(o.hi);
+        uint32_t (&lw)[4] = reinterpret_cast<uint32_t (&)[4]>(o.lo);
+        if constexpr (k2 < 2) { const h2 hp = __builtin_amdgcn_cvt_pkrtz(s.y[2 * k2], s.y[2 * k2 + 1]); s.hpw[k2] = __builtin_bit_cast(uint32_t, hp); hw[2 * HALF + k2] = s.hpw[k2]; }
+        else if constexpr (k2 < 6) { constexpr int e = k2 - 2; const h2 hp = __builtin_bit_cast(h2, s.hpw[e >> 1]); s.l[e] = __builtin_fmaf(s.y[e], s.one_, -(float)hp[e & 1]); }
+        else { constexpr int q = k2 - 6; const h2 lp = __builtin_amdgcn_cvt_pkrtz(s.l[2 * q], s.l[2 * q + 1]); lw[2 * HALF + q] = __builtin_bit_cast(uint32_t, lp); }
+    }
+}
+template <int I, int T0, bool TO_P, bool HAS_F, int PIECE0, bool HAS_E, int HALF, bool MASKS, bool ZADD>
+__device__ __forceinline__ void g16_step(f32x4 (&accC)[2][16], f32x4 (&accP)[2][16], const FOp (&x)[2], const Frag16& f, Frag16& fn, const char* wq,
+                                         const Ring& ring, unsigned voff, E16State& s, const f32x4& eacc, FOp& eo, const Epi16& c, int T, int g, uint32_t& mbits) {
+    constexpr int t = I / 6, cb = (I / 3) % 2, pr = I % 3;
+    if constexpr (pr == 0) accC[cb][T0 + t] = SNR_MFMA16(f.hi[t], x[cb].hi, accC[cb][T0 + t], 0, 0, 0);
+    else if constexpr (pr == 1) accC[cb][T0 + t] = SNR_MFMA16(f.hi[t], x[cb].lo, accC[cb][T0 + t], 0, 0, 0);
+    else if constexpr (TO_P) accP[cb][T0 + t] = SNR_MFMA16(f.lo[t], x[cb].hi, accC[cb][T0 + t], 0, 0, 0);
+    else accC[cb][T0 + t] = SNR_MFMA16(f.lo[t], x[cb].hi, accC[cb][T0 + t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);        // (the gap's instruction BEHIND its MFMA: inside one region the compiler puts a load first)
+#ifndef SNR_PL_FSTEP
+#define SNR_PL_FSTEP 2          /* a fragment read every FSTEP-th gap, from gap SNR_PL_F0 */
+#endif
+#ifndef SNR_PL_F0
+#define SNR_PL_F0 0
+#endif
+#ifndef SNR_PL_DMA0
+#define SNR_PL_DMA0 16
+#endif
+#ifndef SNR_PL_DMA1
+#define SNR_PL_DMA1 19
+#endif
+#ifndef SNR_PL_SHIFT
+#define SNR_PL_SHIFT 1
+#endif
+    if constexpr (HAS_F && I >= SNR_PL_F0 && I < SNR_PL_F0 + 8 * SNR_PL_FSTEP && ((I - SNR_PL_F0) % SNR_PL_FSTEP) == 0) {
+        constexpr int fi = (I - SNR_PL_F0) / SNR_PL_FSTEP, ft = fi / 2, pl = fi % 2;
+        if constexpr (pl == 0) fn.hi[ft] = *reinterpret_cast<const fwdx8*>(wq + (2 * ft) * 1024);
+        else fn.lo[ft] = *reinterpret_cast<const fwdx8*>(wq + (2 * ft + 1) * 1024);
+    }
+    if constexpr (PIECE0 >= 0 && I == SNR_PL_DMA0) ring_pieces<(PIECE0 >= 0 ? PIECE0 : 0), 1>(ring, voff);
+    if constexpr (PIECE0 >= 0 && I == SNR_PL_DMA1) ring_pieces<(PIECE0 >= 0 ? PIECE0 + 1 : 0), 1>(ring, voff);
+    if constexpr (HAS_E) {
+        constexpr int NE = (ZADD ? 1 : 0) + 4 * (1 + 2 * (MASKS ? 1 : 0) + (ZADD ? 1 : 0)) + 8;
+        constexpr int SHIFT = NE <= 12 ? SNR_PL_SHIFT : 0;          // twelve operations: the odd gaps (the fragment reads have the even ones)
+        // operations k with gap(k) == I, gap(k) = k * 24 / NE + SHIFT  (NE <= 25: at most two per gap)
+        constexpr int KA = ((I - SHIFT) * NE + 23) / 24;              // first k with k * 24 / NE >= I - SHIFT
+        constexpr int KB = ((I - SHIFT + 1) * NE + 23) / 24;          // first k of the next gap
+        if constexpr (I - SHIFT >= 0) {
+            if constexpr (KA < KB && KA < NE) e16_op<KA, HALF, MASKS, ZADD>(s, eacc, eo, c, T, g, mbits);
+            if constexpr (KA + 1 < KB && KA + 1 < NE) e16_op<KA + 1, HALF, MASKS, ZADD>(s, eacc, eo, c, T, g, mbits);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int T0, bool TO_P, bool HAS_F, int PIECE0, bool HAS_E, int HALF, bool MASKS, bool ZADD, int... I>
+__device__ __forceinline__ void g16_run(f32x4 (&accC)[2][16], f32x4 (&accP)[2][16], const FOp (&x)[2], const Frag16& f, Frag16& fn, const char* wq,
+                                        const Ring& ring, unsigned voff, E16State& s, const f32x4& eacc, FOp& eo, const Epi16& c, int T, int g, uint32_t& mbits,
+                                        std::integer_sequence<int, I...>) {
+    (g16_step<I, T0, TO_P, HAS_F, PIECE0, HAS_E, HALF, MASKS, ZADD>(accC, accP, x, f, fn, wq, ring, voff, s, eacc, eo, c, T, g, mbits), ...);
+}
+
 // One layer: NT16 output tiles (16: a 256-wide layer, one k32-step per 32 KiB chunk; 8: rgb.0, two steps per chunk, the stream's last
 // layer) from the 16 tiles of accP (8 operand steps), the sums building up in a local set and deposited in accP by the last step.
 // A chunk period is always four groups of four tiles (8 KiB of fragments each): the fragments of group q+1 are fetched while group q's
@@ -431,6 +518,21 @@ __device__ __forceinline__ void layer16(f32x4 (&accP)[2][16], Ring& ring, char* 
 #define SNR_MMA16_CALL(T0_, LASTS_, FCUR) mma16<T0_, LASTS_>(accC, accP, xc, FCUR);
 #endif
     // group G: step S = G / GPS, tiles 4 (G % GPS); position Q = G % 4 in its chunk W = G / 4
+#if !defined(SNR_NO_PLACED)
+#define SNR_GROUP16_PLACED(G, FCUR, FNXT)                                                                                  \
+    {                                                                                                                      \
+        constexpr int S_ = (G) / GPS, T0_ = 4 * ((G) % GPS), Q_ = (G) % 4, W_ = (G) / 4;                                   \
+        constexpr bool LASTS_ = S_ == 7;                                                                                   \
+        constexpr bool HASF_ = (Q_ != 3) || ((G) + 1 < NG);                                                                \
+        const char* wq_ = w + (Q_ + 1) * 8192;                                                                             \
+        if constexpr (Q_ == 3 && (G) + 1 < NG) { w = ring_acquire<TAIL && W_ + 1 == NCH - 1>(ring, lds) + lane * 16; wq_ = w; } \
+        constexpr int P0_ = (Q_ != 3) ? ((!TAIL || W_ + 2 < NCH) ? 2 * Q_ + 2 : -1) : (((G) + 1 < NG && (!TAIL || W_ + 3 < NCH)) ? 0 : -1); \
+        constexpr int e_ = (G) % 4, cb_ = e_ >> 1, hf_ = e_ & 1, T_ = LASTS_ ? 0 : 2 * (S_ + 1) + hf_;                      \
+        g16_run<T0_, LASTS_, HASF_, P0_, !LASTS_, hf_, MASKS, ZADD>(accC, accP, xc, FCUR, FNXT, wq_, ring, voff, es, accP[cb_][T_], xn[cb_], c, T_, g, \
+                                                                   mw[2 * cb_ + (T_ >> 3)], std::make_integer_sequence<int, 24>{}); \
+        if constexpr (!LASTS_ && ((G) % GPS) == GPS - 1) { xc[0] = xn[0]; xc[1] = xn[1]; }                                 \
+    }
+#endif
 #define SNR_GROUP16(G, FCUR, FNXT)                                                                                         \
     {                                                                                                                      \
         constexpr int S_ = (G) / GPS, T0_ = 4 * ((G) % GPS), Q_ = (G) % 4, W_ = (G) / 4;                                   \
@@ -454,11 +556,26 @@ __device__ __forceinline__ void layer16(f32x4 (&accP)[2][16], Ring& ring, char* 
         if constexpr (!LASTS_ && ((G) % GPS) == GPS - 1) { xc[0] = xn[0]; xc[1] = xn[1]; }                                 \
     }
 #define SNR_GROUP16_PAIR(G) SNR_GROUP16(G, fa, fb) SNR_GROUP16((G) + 1, fb, fa)
+#if !defined(SNR_NO_PLACED)
+#define SNR_GROUP16_PPAIR(G) SNR_GROUP16_PLACED(G, fa, fb) SNR_GROUP16_PLACED((G) + 1, fb, fa)
+    if constexpr (NT16 == 16 && !DUMP) {
+        E16State es;
+        es.one_ = 1.0f; asm("" : "+v"(es.one_));
+        es.lo_bound = c.floor == 0 ? 0.f : -65504.f;
+        SNR_GROUP16_PPAIR(0) SNR_GROUP16_PPAIR(2) SNR_GROUP16_PPAIR(4) SNR_GROUP16_PPAIR(6)
+        SNR_GROUP16_PPAIR(8) SNR_GROUP16_PPAIR(10) SNR_GROUP16_PPAIR(12) SNR_GROUP16_PPAIR(14)
+        SNR_GROUP16_PPAIR(16) SNR_GROUP16_PPAIR(18) SNR_GROUP16_PPAIR(20) SNR_GROUP16_PPAIR(22)
+        SNR_GROUP16_PPAIR(24) SNR_GROUP16_PPAIR(26) SNR_GROUP16_PPAIR(28) SNR_GROUP16_PPAIR(30)
+    } else
+#undef SNR_GROUP16_PPAIR
+#endif
+    {
     SNR_GROUP16_PAIR(0) SNR_GROUP16_PAIR(2) SNR_GROUP16_PAIR(4) SNR_GROUP16_PAIR(6)
     SNR_GROUP16_PAIR(8) SNR_GROUP16_PAIR(10) SNR_GROUP16_PAIR(12) SNR_GROUP16_PAIR(14)
     if constexpr (NG == 32) {
         SNR_GROUP16_PAIR(16) SNR_GROUP16_PAIR(18) SNR_GROUP16_PAIR(20) SNR_GROUP16_PAIR(22)
         SNR_GROUP16_PAIR(24) SNR_GROUP16_PAIR(26) SNR_GROUP16_PAIR(28) SNR_GROUP16_PAIR(30)
+    }
     }
 #undef SNR_GROUP16_PAIR
 #undef SNR_GROUP16
