@@ -201,8 +201,7 @@ __device__ __forceinline__ BoxSlab box_slab(const float (&o)[3], const float (&d
     return b;
 }
 
-__device__ __forceinline__ void box_ray(const RayGeom& g, long long ray, float (&o)[3], float (&d)[3], float (&hb)[3], float& zs) {
-    const long long obj = ray / g.rays_per_obj;
+__device__ __forceinline__ void box_ray(const RayGeom& g, long long ray, long long obj, float (&o)[3], float (&d)[3], float (&hb)[3], float& zs) {
     zs = g.z_scale[obj];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -212,8 +211,11 @@ __device__ __forceinline__ void box_ray(const RayGeom& g, long long ray, float (
     }
 }
 
-__device__ __forceinline__ float load_t(const RayGeom& g, long long ray, int s) {
-    long long obj = ray / g.rays_per_obj;
+__device__ __forceinline__ void box_ray(const RayGeom& g, long long ray, float (&o)[3], float (&d)[3], float (&hb)[3], float& zs) {
+    box_ray(g, ray, ray / g.rays_per_obj, o, d, hb, zs);
+}
+
+__device__ __forceinline__ float load_t(const RayGeom& g, long long ray, int s, long long obj) {
     long long idx = g.z_mode == SNR_Z_SHARED ? s : (g.z_mode == SNR_Z_PER_OBJECT ? obj * g.S + s : ray * g.S + s);
     return g.t_vals[idx];
 }
@@ -222,16 +224,16 @@ __device__ __forceinline__ float load_t(const RayGeom& g, long long ray, int s) 
 // (src/utils.py:165,472-495; src/renderer.py:111,441).  Composite depth is t, or the metric
 // distance |p_sampling - o| * z_scale for SNR_METRIC_Z (src/renderer.py:114).
 // SNR_Z_BOX: o is rays_o / z_scale, t comes from the ray's own box bounds and xyz_div is not applied (see the header).
-__device__ __forceinline__ SamplePoint make_sample(const RayGeom& g, long long ray, int s) {
+// (`obj` = ray / rays_per_obj: the two-waves fp32 kernels derive it without a per-lane 64-bit division, ~150 VALU instructions)
+__device__ __forceinline__ SamplePoint make_sample(const RayGeom& g, long long ray, int s, long long obj) {
     SamplePoint sp;
-    long long obj = ray / g.rays_per_obj;
     float ox, oy, oz, t;
     const float dx = g.rays_d[ray * 3 + 0], dy = g.rays_d[ray * 3 + 1], dz = g.rays_d[ray * 3 + 2];
     const bool box = g.z_mode == SNR_Z_BOX;
     sp.u = 0.f;
     if (box) {
         float o[3], d[3], hb[3], zs;
-        box_ray(g, ray, o, d, hb, zs);
+        box_ray(g, ray, obj, o, d, hb, zs);
         const BoxSlab b = box_slab(o, d, hb);
         const float near = b.hit ? b.t_near : -1.f, far = b.hit ? b.t_far : -1.f;
         const float step = 1.f / (float)g.S;            // S is a power of two: linspace(0, 1 - 1/S, S)[s] = s / S exactly
@@ -241,7 +243,7 @@ __device__ __forceinline__ SamplePoint make_sample(const RayGeom& g, long long r
         ox = o[0]; oy = o[1]; oz = o[2];
     } else {
         ox = g.rays_o[ray * 3 + 0]; oy = g.rays_o[ray * 3 + 1]; oz = g.rays_o[ray * 3 + 2];
-        t = load_t(g, ray, s);
+        t = load_t(g, ray, s, obj);
     }
     // o + d*t with separate multiply and add like the reference's broadcast ops (no fma contraction)
     float px = __fadd_rn(ox, __fmul_rn(dx, t));
@@ -270,6 +272,7 @@ __device__ __forceinline__ SamplePoint make_sample(const RayGeom& g, long long r
     sp.dz = g.m[6] * dx + g.m[7] * dy + g.m[8] * dz;
     return sp;
 }
+__device__ __forceinline__ SamplePoint make_sample(const RayGeom& g, long long ray, int s) { return make_sample(g, ray, s, ray / g.rays_per_obj); }
 
 // ------------------------------------------------------------------ positional encoding
 // Feature f of PE(v, L) (src/model_supnerf.py:155-161): f<3 -> v[f]; 3<=f<3+3L -> sin(2^i v[a]);

@@ -198,8 +198,8 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
         px = xyz[gp * 3]; py = xyz[gp * 3 + 1]; pz = xyz[gp * 3 + 2];
         dx = viewdir[gp * 3]; dy = viewdir[gp * 3 + 1]; dz = viewdir[gp * 3 + 2];
     } else {
-        const long long ray = gp / gm.S;
-        const SamplePoint sp = make_sample(gm, ray, (int)(gp - ray * gm.S));
+        const PointId id = point_id(gm, tile_wg, WGP, wave * 16 + n, live);
+        const SamplePoint sp = make_sample(gm, id.ray, id.s, id.obj);
         px = sp.x; py = sp.y; pz = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc;
     }
     const float* bias = lds + lo.bias;

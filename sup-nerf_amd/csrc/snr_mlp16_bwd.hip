@@ -198,10 +198,9 @@ __device__ __forceinline__ void flush_latent_rows(const float* red /* lds + LB_R
 // Tail of the render-mode backward for 16 points per wave (all 256 threads; 64 consecutive sample points, S divides 64; the four lane groups
 // of a point hold the same values): snr_device.hpp's ray_grad_tail for this lane layout.
 __device__ __forceinline__ void ray_grad_tail16(const RayGeom& g, float* __restrict__ d_rays_o, float* __restrict__ d_rays_d, float* __restrict__ d_t,
-                                                float* part, long long tile64, long long ray, long long gp, bool live, float tval, float u,
+                                                float* part, long long tile64, long long ray, long long obj, long long gp, bool live, float tval, float u,
                                                 float zc, float gx, float gy, float gz, float hx, float hy, float hz, float gzc) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, gg = lane >> 4;
-    const long long obj = ray / g.rays_per_obj;
     const bool box = g.z_mode == SNR_Z_BOX;
     const float sc_ = box ? g.xyz_mul : g.xyz_mul / g.xyz_div[obj];
     const float px = (g.m[0] * gx + g.m[3] * gy + g.m[6] * gz) * sc_;
@@ -320,13 +319,14 @@ decoder_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const fl
 
     // ---- this lane's point and its upstream gradient
     float x, y, z, dx, dy, dz, tval = 0.f, zc = 0.f, uval = 0.f;
-    long long ray = 0;
+    long long ray = 0, obj = 0;
     if (MODE == 0) {
         x = xyz[gp * 3]; y = xyz[gp * 3 + 1]; z = xyz[gp * 3 + 2];
         dx = viewdir[gp * 3]; dy = viewdir[gp * 3 + 1]; dz = viewdir[gp * 3 + 2];
     } else {
-        ray = gp / gm.S;
-        const SamplePoint sp = make_sample(gm, ray, (int)(gp - ray * gm.S));
+        const PointId id = point_id(gm, tile64, 64, wave * 16 + n, live);
+        ray = id.ray; obj = id.obj;
+        const SamplePoint sp = make_sample(gm, id.ray, id.s, id.obj);
         x = sp.x; y = sp.y; z = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc; tval = sp.t; uval = sp.u;
     }
     float gs = 0.f, gr = 0.f, ggr = 0.f, gb = 0.f, gzc = 0.f;
@@ -505,10 +505,10 @@ decoder_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const fl
         return;
     }
 #ifdef SNR_STAMPS
-    ray_grad_tail16(gm, io.d_rays_o, io.d_rays_d, nullptr, lds + LB_PART, tile64, ray, gp, live, tval, uval, zc, gx, gy, gz, hx, hy, hz, gzc);
+    ray_grad_tail16(gm, io.d_rays_o, io.d_rays_d, nullptr, lds + LB_PART, tile64, ray, obj, gp, live, tval, uval, zc, gx, gy, gz, hx, hy, hz, gzc);
     SNR16_BSTAMP(7);
 #else
-    ray_grad_tail16(gm, io.d_rays_o, io.d_rays_d, io.d_t, lds + LB_PART, tile64, ray, gp, live, tval, uval, zc, gx, gy, gz, hx, hy, hz, gzc);
+    ray_grad_tail16(gm, io.d_rays_o, io.d_rays_d, io.d_t, lds + LB_PART, tile64, ray, obj, gp, live, tval, uval, zc, gx, gy, gz, hx, hy, hz, gzc);
 #endif
 }
 

@@ -77,6 +77,26 @@ __device__ __forceinline__ void row_dma16(const Dma16& d, const float* __restric
     dma_piece_imm<0>(d.voff, g, m0v);
 }
 
+// (ray, sample, object) of point pl (0 .. wgp - 1) of workgroup tile_wg without per-lane 64-bit divisions (~150 VALU instructions each, and on
+// this chip every VALU instruction comes out of the fp32 MFMAs' time): in the fused render S is a power of two that divides the workgroup's
+// points, so the ray is a shift away from the workgroup's first ray, and the object follows from ONE uniform division (scalar ALU) per workgroup.
+// Lanes past the end of the launch hold its last point, like everywhere else.
+struct PointId { long long ray, obj; int s; };
+__device__ __forceinline__ PointId point_id(const RayGeom& g, long long tile_wg, int wgp, int pl, bool live) {
+    const int ls = 31 - __builtin_clz((unsigned)g.S);
+    const long long ray0 = tile_wg * (long long)(wgp >> ls);
+    const long long obj0 = ray0 / g.rays_per_obj;
+    const long long rem0 = ray0 - obj0 * g.rays_per_obj;
+    const int dr = pl >> ls;
+    const long long r = rem0 + dr;
+    PointId p;
+    p.ray = ray0 + dr;
+    p.s = pl & (g.S - 1);
+    p.obj = obj0 + (g.rays_per_obj >= wgp ? (long long)(r >= g.rays_per_obj) : (long long)((unsigned)r / (unsigned)g.rays_per_obj));
+    if (!live) { p.ray = g.n_rays - 1; p.s = g.S - 1; p.obj = (g.n_rays - 1) / g.rays_per_obj; }
+    return p;
+}
+
 struct Ring16 {
     int cur;             // LDS buffer holding the chunk about to be consumed
     int aoff[2];         // this lane's float offset of the 16-byte slot (4 dT + kg) of row m in a chunk, swizzle applied (dT = 0, 1)
