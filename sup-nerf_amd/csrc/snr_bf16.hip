@@ -320,6 +320,26 @@ __device__ __forceinline__ void step_mma16(f32x4 (&acc)[2][16], const FOp (&x)[2
     }
 }
 
+// the same with the fragments of group q + 1 requested before group q's 24 MFMAs (round 4: enc_xyz took 6.2 k cycles for 3.1 k of MFMAs with
+// every fragment requested right in front of its use)
+__device__ __forceinline__ void step_mma16_groups(f32x4 (&acc)[2][16], const FOp (&x)[2], const char* ws) {
+    Frag16 fa, fb;
+    load16(fa, ws);
+    load16(fb, ws + 8192);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16<0, false>(acc, acc, x, fa);
+    __builtin_amdgcn_sched_barrier(0);
+    load16(fa, ws + 16384);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16<4, false>(acc, acc, x, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    load16(fb, ws + 24576);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16<8, false>(acc, acc, x, fa);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16<12, false>(acc, acc, x, fb);
+}
+
 // What happens to a finished 16x16 accumulator tile of the PREVIOUS layer on its way into an operand step of the current one.
 struct Epi16 {
     int floor;            // ReLU as an integer max on the bit pattern: 0 for a ReLU layer, INT_MIN for none
@@ -633,31 +653,37 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
     float* latw = reinterpret_cast<float*>(lds + OFF_LAT) + wave * MAX_LAT * 256;
     SNR_STAMP(0);
 
-    // ---- stage the small vectors and this wave's latent terms in LDS (plain loads, before any DMA is queued)
-    {
-        // 16-byte loads, all issued before the first wait (fixed trip counts): the dword loops with run-time bounds paid one global
-        // round trip per iteration
-        const f32x4* src4 = reinterpret_cast<const f32x4*>(io.packed + L.bias);
-        f32x4* dst4 = reinterpret_cast<f32x4*>(vec + VEC_BIAS);
-        const int n4 = L.n_mfma_layers * 64;
-        f32x4 bv[MAX_LAYERS * 64 / 256];
+    // ---- the small vectors and this wave's latent terms are REQUESTED here (plain 16-byte loads, all issued before the first wait) and written
+    // to LDS behind the positional encodings (round 4: 3.5 k cycles of exposed global round trip at the top of the kernel otherwise); the
+    // first ring_acquire's barrier publishes them.  The weight ring's DMA pieces go out in between: they are younger than these loads, so a
+    // counted wait for these never waits for less than it should.
+    const f32x4* src4 = reinterpret_cast<const f32x4*>(io.packed + L.bias);
+    const int n4 = L.n_mfma_layers * 64;
+    f32x4 bv[MAX_LAYERS * 64 / 256];
 #pragma unroll
-        for (int k = 0; k < MAX_LAYERS * 64 / 256; ++k) bv[k] = src4[min(tid + 256 * k, n4 - 1)];
-        vec[VEC_SIGW + tid] = io.packed[L.sigma_w + tid];
-        for (int i = tid; i < 384; i += 256) vec[VEC_RGBW + i] = io.packed[L.rgb2_w + i];
-        if (tid < 4) vec[VEC_MISC + tid] = io.packed[L.sigma_b + tid];
-        if (tid >= 4 && tid < 8) vec[VEC_MISC + tid] = io.packed[L.rgb2_b + tid - 4];
-        vec[VEC_ZERO + tid] = 0.f;
+    for (int k = 0; k < MAX_LAYERS * 64 / 256; ++k) bv[k] = src4[min(tid + 256 * k, n4 - 1)];
+    const float st_sigw = io.packed[L.sigma_w + tid];
+    const float st_rgbw0 = io.packed[L.rgb2_w + tid], st_rgbw1 = io.packed[L.rgb2_w + 256 + (tid & 127)];
+    const float st_misc = io.packed[(tid < 4 ? L.sigma_b : L.rgb2_b - 4) + (tid & 7)];
+    f32x4 lv[MAX_LAT];
+    {
         const long long first = tile32 * 32 < io.n_points ? tile32 * 32 : io.n_points - 1;
         const f32x4* ls4 = reinterpret_cast<const f32x4*>((EBIAS ? io.latent_bias : io.latent) + (first / io.points_per_obj) * L.n_lat * 256);
-        f32x4 lv[MAX_LAT];
 #pragma unroll
         for (int la = 0; la < MAX_LAT; ++la) lv[la] = ls4[max(min(la, L.n_lat - 1), 0) * 64 + lane];   // (n_lat == 0: the caller passes one dummy row)
+    }
+    auto staged_to_lds = [&]() {
+        f32x4* dst4 = reinterpret_cast<f32x4*>(vec + VEC_BIAS);
 #pragma unroll
         for (int k = 0; k < MAX_LAYERS * 64 / 256; ++k) if (tid + 256 * k < n4) dst4[tid + 256 * k] = bv[k];
+        vec[VEC_SIGW + tid] = st_sigw;
+        vec[VEC_RGBW + tid] = st_rgbw0;
+        if (tid < 128) vec[VEC_RGBW + 256 + tid] = st_rgbw1;
+        if (tid < 8) vec[VEC_MISC + tid] = st_misc;
+        vec[VEC_ZERO + tid] = 0.f;
 #pragma unroll
         for (int la = 0; la < MAX_LAT; ++la) if (la < L.n_lat) reinterpret_cast<f32x4*>(latw)[la * 64 + lane] = lv[la];
-    }
+    };
     float px, py, pz, dx, dy, dz, zc = 0.f;
     if (MODE == 0) {
         px = xyz[gp * 3]; py = xyz[gp * 3 + 1]; pz = xyz[gp * 3 + 2];
@@ -668,7 +694,6 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         px = sp.x; py = sp.y; pz = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc;
         if (lane < 32) reinterpret_cast<float*>(lds + OFF_COMP)[(wave * 32 + p) * COMP_STRIDE + 4] = zc;
     }
-    __syncthreads();
     SNR_STAMP(1);
 
     // ---- weight ring: chunks 0,1 in flight while the positional encodings are computed (scratch = ring buffer 2)
@@ -738,6 +763,7 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         }
     }
 
+    staged_to_lds();
     f32x4 accA[2][16];
     uint32_t mw[4];
     float sig_dot[2] = {0.f, 0.f};
@@ -752,10 +778,10 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
             const f32x4 b = *reinterpret_cast<const f32x4*>(vec + VEC_BIAS + 16 * t + 4 * gq);
             accA[0][t] = b; accA[1][t] = b;
         }
-        step_mma16<16>(accA, x0[0], w);
+        step_mma16_groups(accA, x0[0], w);
         w = ring_acquire(ring, lds) + lane * 16;
         ring_pieces<0, 8>(ring, voff);
-        step_mma16<16>(accA, x0[1], w);
+        step_mma16_groups(accA, x0[1], w);
     }
 
     SNR_STAMP(3);
@@ -1359,6 +1385,26 @@ __device__ __forceinline__ void step_mma16b(f32x4 (&acc)[2][16], const XOp (&x)[
     }
 }
 
+// the same with the fragments of group q + 1 requested before group q's 24 MFMAs (rgb.0^T: 12.6 k cycles for 6.1 k of MFMAs without)
+template <bool ZERO>
+__device__ __forceinline__ void step_mma16b_groups(f32x4 (&acc)[2][16], const XOp (&x)[2], const char* ws) {
+    Frag16B fa, fb;
+    load16b(fa, ws);
+    load16b(fb, ws + 8192);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16b<0, ZERO, false>(acc, acc, x, fa);
+    __builtin_amdgcn_sched_barrier(0);
+    load16b(fa, ws + 16384);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16b<4, ZERO, false>(acc, acc, x, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    load16b(fb, ws + 24576);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16b<8, ZERO, false>(acc, acc, x, fa);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16b<12, ZERO, false>(acc, acc, x, fb);
+}
+
 // Latent-term gradient of one layer in this layout: the two column blocks are added, then the reduce-scatter over the 16 point lanes of a
 // DPP row (A: row_mirror, tiles T | T + 8; B: row_half_mirror, T | T + 4; C, D: quad sums): lane i of row g ends with the sums of tiles
 // 8 b3 + 4 b2 + {0..3}, features 16 T + 4 g + r; one lane per quad parks them in LDS.  192 VALU instructions (the 32x32 form: 416).
@@ -1512,6 +1558,7 @@ bf16_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float
     const int n_relu = n_relu_layers(sb, tb);
     const int li_encshape = sb + 1, li_view = sb + 2, li_last = sb + tb + 2;
     float* vec = reinterpret_cast<float*>(lds + OFF_VEC);
+    SNR_BSTAMP(0);
 
     // ---- everything that needs an ordinary global load happens before the DMA ring starts
     vec[VEC_SIGW + tid] = io.packed[L.sigma_w + tid];
@@ -1610,6 +1657,7 @@ bf16_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float
         dpre2[cb] = c[0]; gr2[cb] = c[1]; gg2[cb] = c[2]; gb2[cb] = c[3];
     }
     __syncthreads();
+    SNR_BSTAMP(1);
 
     Ring ring;
     const int total_chunks = 4 + 8 * tb + 9 + 8 * (sb + 1) + 2;       // enc_viewdir^T: 8 chunks + 1 for its direction tiles
@@ -1660,13 +1708,14 @@ bf16_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int t = 0; t < 2; ++t) accD[cb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    SNR_BSTAMP(2);
     // ---- rgb.0^T : K = 128 (4 k32-steps, one chunk each) -> accA
     {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const char* w = ring_acquire(ring, lds) + lane * 16;
             ring_pieces<0, 8>(ring, voff);
-            if (s == 0) step_mma16b<true>(accA, x[s], w); else step_mma16b<false>(accA, x[s], w);
+            if (s == 0) step_mma16b_groups<true>(accA, x[s], w); else step_mma16b_groups<false>(accA, x[s], w);
         }
     }
 
@@ -1689,10 +1738,16 @@ bf16_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float
         }
         return c;
     };
+    SNR_BSTAMP(3);
 #pragma unroll 1
-    for (int li = li_last; li >= 1; --li) layer_bwd16<16, DUMP>(accA, accD, x, ring, lds, epi_of(li), li == li_view, lane);
+    for (int li = li_last; li >= 1; --li) {
+        layer_bwd16<16, DUMP>(accA, accD, x, ring, lds, epi_of(li), li == li_view, lane);
+        SNR_BSTAMP(4 + li_last - li);
+    }
+    SNR_BSTAMP(11);
     // ---- enc_xyz^T : 256 -> 64 positional-encoding features (four tiles)
     layer_bwd16<4, DUMP>(accA, accD, x, ring, lds, epi_of(0), false, lane);
+    SNR_BSTAMP(12);
 
     // ---- the parked latent-term gradients of this wave tile -> global partials (the ring is idle now)
     if (io.partial && tile_live) {
@@ -1738,6 +1793,7 @@ bf16_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float
     if (h == 0) { hx += sc[0]; hy += sc[1]; hz += sc[2]; }
     gx = sum_halves(gx); gy = sum_halves(gy); gz = sum_halves(gz);
     hx = sum_halves(hx); hy = sum_halves(hy); hz = sum_halves(hz);
+    SNR_BSTAMP(13);
 
     if (MODE == 0) {
         if (live && h == 0) {
@@ -1747,6 +1803,7 @@ bf16_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float
         return;
     }
     ray_grad_tail(g, io.d_rays_o, io.d_rays_d, io.d_t, comp, tile128, ray, gp, live, tval, uval, zc, gx, gy, gz, hx, hy, hz, gzc);
+    SNR_BSTAMP(14);
 }
 
 // ------------------------------------------------------------------------------------------ packing
