@@ -111,7 +111,7 @@ class _DecoderBase(nn.Module):
         pp = self._per_point_params()
         key = tuple((p.data_ptr(), p._version) for p in pp.values())      # (a move to another device changes data_ptr)
         dev = next(iter(pp.values())).device
-        sk = (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+        sk = (str(dev), ops.raw_stream(dev) if dev.type == "cuda" else 0)
         with _CACHE_LOCK:
             # One entry per (device, stream): a buffer packed a moment ago by another thread on ITS stream may not be written yet as far
             # as this thread's stream is concerned (re-entrancy: one thread per GPU under nn.DataParallel, or a caller's own thread pool
@@ -195,7 +195,7 @@ class _DecoderBase(nn.Module):
         lat, nxt = self._latent_params()
         ps = [q for l in lat + nxt for q in (_leaf(l, "weight"), _leaf(l, "bias"))]
         dev = ps[0].device
-        key = tuple((q.data_ptr(), q._version) for q in ps) + (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+        key = tuple((q.data_ptr(), q._version) for q in ps) + (str(dev), ops.raw_stream(dev) if dev.type == "cuda" else 0)
         with _CACHE_LOCK:
             return self._stacked_locked(lat, nxt, ps, key)
 

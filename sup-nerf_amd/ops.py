@@ -132,8 +132,19 @@ def _ptr(t: Optional[torch.Tensor], dtype=torch.float32) -> int:
     return _p(t).value or 0
 
 
+def raw_stream(dev) -> int:
+    """The current HIP stream of `dev` as an integer handle.  torch.cuda.current_stream() builds a Python Stream object per call (5 us; the
+    public render functions ask ~18 times per optimiser iteration); the raw getter behind it does not."""
+    d = dev if isinstance(dev, torch.device) else torch.device(dev)
+    idx = d.index if d.index is not None else torch.cuda.current_device()
+    try:
+        return int(torch._C._cuda_getCurrentRawStream(idx))
+    except AttributeError:      # (a torch build without the private getter)
+        return int(torch.cuda.current_stream(d).cuda_stream)
+
+
 def _stream(dev):
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return C.c_void_p(raw_stream(dev))
 
 
 # ------------------------------------------------------------------------------------ weights
@@ -719,7 +730,7 @@ def _packed_for(names, weights, shape_blocks, texture_blocks):
     ``ref() is w`` is required for every one -- (data_ptr, _version) alone would also match a NEW model whose weights the caching
     allocator placed at a freed model's addresses (same construction, same version counters), and the step would silently run on the
     old model's weights."""
-    dev = (weights[0].device, torch.cuda.current_stream(weights[0].device).cuda_stream if weights[0].is_cuda else 0)   # (one slot per device AND stream)
+    dev = (weights[0].device, raw_stream(weights[0].device) if weights[0].is_cuda else 0)   # (one slot per device AND stream)
     key = (shape_blocks, texture_blocks) + tuple((w.data_ptr(), w._version) for w in weights)
     with _PACK_LOCK:
         hit = _PACK_CACHE.get(dev)

@@ -55,7 +55,7 @@ def _stream_key(device):
     d = torch.device(device) if not isinstance(device, torch.device) else device
     if d.type != "cuda":
         return (str(d), 0)
-    return (str(d), torch.cuda.current_stream(d).cuda_stream)
+    return (str(d), ops.raw_stream(d))
 
 
 def _cam_table(K, px, py, like, key=None):
