@@ -1,19 +1,18 @@
 // Split-bf16 ("bf16x3") variant of the fused decoder kernels for gfx950.
 //
-// Same mathematics and the same register-resident layer chain as the fp32 kernels (snr_mlp.hip), but every
-// fp32 operand is carried as hi = bf16(x), lo = bf16(x - hi) and every product as
+// Same mathematics and the same register-resident layer chain as the fp32 kernels (snr_mlp*.hip), but every fp32 operand is carried as two
+// 16-bit pieces, hi = round16(x), lo = round16(x - hi) (fp16 in the forward chain, bf16 in the backward chain), and every product as
 //      w*x  ~=  w_hi*x_hi + w_hi*x_lo + w_lo*x_hi            (fp32 accumulate, dropped term <= 2^-18 |w x|)
-// on v_mfma_f32_32x32x16_bf16: 3 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64 cycles (5.3x less matrix-pipe time)
-// at ~2^-17 relative operand error, two orders of magnitude inside the path's tolerance (PSNR 0.01 dB, depth 1e-4 m).
+// on v_mfma_f32_16x16x32_{f16,bf16} (both kernels since round 4; rounds 1-2 ran on 32x32x16): 3 MFMAs at the 16-bit rate replace the
+// fp32 MFMAs at 1/16 of it, at ~2^-17 (bf16) / 2^-22 (fp16) relative operand error, inside the path's tolerance (PSNR 0.01 dB, depth 1e-4 m).
 //
-// Restructured around the 5x shorter matrix time:
-//   * weights are stored as the lane-linear LDS image [k16-step][tile][hi/lo][lane][8 bf16] -> A fragments are plain
+// Structure:
+//   * weights are stored as the lane-linear LDS image [k32-step][16-row tile][hi/lo][lane][8 x 16 bit] -> A fragments are plain
 //     conflict-free ds_read_b128 at immediate offsets; staging is LDS-DMA into a 3-deep ring with counted vmcnt
 //     (two 32 KiB chunks in flight across raw s_barriers);
-//   * TWO accumulator sets (2 x 128 AGPRs) and ONE operand set (128 VGPRs): layer l+1 consumes operand step s =
-//     (tile s/2, half s%2) of layer l's finished accumulators, so layer l's epilogue (ReLU / mask / latent add /
-//     hi-lo split) is spread over layer l+1's steps and issued in the shadow of its MFMAs; an operand step is dead
-//     as soon as the layer has used it (k-outer order), so the next layer's operands overwrite it in place;
+//   * TWO accumulator sets: layer l+1 consumes operand steps made from layer l's finished accumulators, so layer l's epilogue (ReLU / mask /
+//     latent add / hi-lo split) is spread over layer l+1's steps; the last step of a layer deposits the finished sums in the dead
+//     previous set;
 //   * biases, latent terms and the two small heads are staged in LDS once, so no compiler-tracked global load
 //     drains the DMA queue inside the layer chain.
 // Limits of this variant (the fp32 kernels have none of them): shape_blocks + texture_blocks <= 4 and
@@ -124,88 +123,16 @@ __device__ __forceinline__ const char* ring_acquire(Ring& r, char* lds) {
     return p;
 }
 
-// ------------------------------------------------------------------------------------------ matrix core
-// Layer image in the stream: [k16-step s][output tile t][plane hi/lo][lane][8 bf16]; a chunk = a few whole steps.
-// One step: acc[t] += W_t[:, 16s..16s+15] * x   for t < NT, three split products each.
-template <int NT, int NA>
-__device__ __forceinline__ void step_mma(f32x16 (&acc)[NA], const XOp& x, const char* ws /* chunk + step offset + lane*16 */) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ws + (2 * t) * 1024);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ws + (2 * t + 1) * 1024);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x.hi, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x.lo, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, x.hi, acc[t], 0, 0, 0);
-    }
-}
-
-// A fragments of half a step (NTH tiles, hi and lo planes): loaded half a step ahead of the MFMAs that use them
-template <int NTH> struct Frags { bf16x8 hi[NTH], lo[NTH]; };
-template <int NTH, int T0>
-__device__ __forceinline__ void load_frags(Frags<NTH>& f, const char* ws) {
-#pragma unroll
-    for (int t = 0; t < NTH; ++t) {
-        f.hi[t] = *reinterpret_cast<const bf16x8*>(ws + (2 * (T0 + t)) * 1024);
-        f.lo[t] = *reinterpret_cast<const bf16x8*>(ws + (2 * (T0 + t) + 1) * 1024);
-    }
-}
-// the same, the finished sums going to `out` (the last operand step of a layer: see layer_fwd)
-template <int NTH, int T0, int NA>
-__device__ __forceinline__ void mma_half_to(f32x16 (&out)[NA], const f32x16 (&acc)[NA], const XOp& x, const Frags<NTH>& f) {
-#pragma unroll
-    for (int t = 0; t < NTH; ++t) {
-        f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.hi[t], x.hi, acc[T0 + t], 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.hi[t], x.lo, a, 0, 0, 0);
-        out[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.lo[t], x.hi, a, 0, 0, 0);
-    }
-}
-template <int NTH, int T0, int NA>
-__device__ __forceinline__ void mma_half(f32x16 (&acc)[NA], const XOp& x, const Frags<NTH>& f) {
-#pragma unroll
-    for (int t = 0; t < NTH; ++t) {
-        acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.hi[t], x.hi, acc[T0 + t], 0, 0, 0);
-        acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.hi[t], x.lo, acc[T0 + t], 0, 0, 0);
-        acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.lo[t], x.hi, acc[T0 + t], 0, 0, 0);
-    }
-}
-
+// ------------------------------------------------------------------------------------------ operand pieces
 __device__ __forceinline__ void split_store(float v, XOp& o, int j) {
     const __bf16 hi = (__bf16)v;
     o.hi[j] = hi;
     o.lo[j] = (__bf16)(v - (float)hi);
 }
 
-template <int NT, int NA>
-__device__ __forceinline__ void acc_zero(f32x16 (&acc)[NA]) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-}
-
 // pin an operand step where it is produced: without this LLVM sinks the whole epilogue down to its use in the next
 // step (behind the barrier), which serialises it with that step's MFMAs instead of hiding it under this step's
 __device__ __forceinline__ void pin(XOp& o) { asm volatile("" : "+v"(o.hi), "+v"(o.lo)); }
-
-// interleave request for one half-step region of the backward layer body (32x32x16 shape): after every MFMA a few VALU ops, so the
-// previous layer's epilogue is spread under the MFMAs instead of in blocks.  Measured (tools/ab_time.py, interleaved rounds), ~34 ops
-// per 12 MFMAs: 3 VALU and no LDS-read request (-1 % against 4).  (The forward's request is SNR_INTERLEAVE16 below.)
-#ifndef SNR_ILB_DS
-#define SNR_ILB_DS 0
-#endif
-#ifndef SNR_ILB_VALU
-#define SNR_ILB_VALU 3
-#endif
-#ifndef SNR_ILB_MFMA
-#define SNR_ILB_MFMA 1
-#endif
-#define SNR_INTERLEAVE_(N_MFMA, DS, VALU)                                                \
-    _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA) / SNR_ILB_MFMA; ++g_) {             \
-        __builtin_amdgcn_sched_group_barrier(0x008, SNR_ILB_MFMA, 0);                    \
-        if (DS) __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);                      \
-        if (VALU) __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);                  \
-    }
-#define SNR_INTERLEAVE_B(N_MFMA) SNR_INTERLEAVE_(N_MFMA, SNR_ILB_DS, SNR_ILB_VALU)
 
 // ------------------------------------------------------------------------------------------ forward kernel (v_mfma_f32_16x16x32_bf16)
 // Round 3: the forward chain runs on the 16x16x32 shape.  Same structure as before -- transposed GEMMs Y^T = W X^T, the accumulators of
@@ -943,408 +870,24 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
 }
 
 // ------------------------------------------------------------------------------------------ backward
-// Latent-term gradient of one layer: sum every feature of the 8 finished accumulator tiles over the wave's 32 points; the 256 sums
-// are parked in LDS (`out`) until the kernel's last phase stores them, so no global store is queued between the hand-counted DMA
-// waits of the layer chain.  History: a register butterfly of 16 ds_bpermute per tile inside the MFMA pipeline cost 35-45 k cycles
-// per latent layer; a transpose through a wave-private LDS scratch ~4 k; this version ~3 k.
-// On the VALU alone (no LDS round trips): a reduce-scatter over the 32 point lanes with DPP row operations.
-// Each step pairs lanes (row_mirror: i <-> 15-i, row_half_mirror: j <-> 7-j inside a group of 8) and pairs registers; the lanes of one
-// half of a pair sum register set 0, the other half set 1 (bank_mask picks the halves), so every step halves the live registers.
-// The two in-quad levels are plain sums (bank_mask cannot split a quad), the two rows of a half meet through v_permlane16_swap.
-//   A  tiles t | t+4      lanes i<8 | i>=8        64 -> 32 registers (per half of the 16 accumulator registers)
-//   B  tiles t | t+2      j<4 | j>=4              32 -> 16
-//   C, D  quad sums                                16
-//   E  tiles 0 | 1        even | odd row          16 -> 8
-// so lane (h, rho = row parity, A = bit 3, B = bit 2) ends up with the 32-point sums of tile rho + 2B + 4A, registers r = 0..15, i.e.
-// features 32*tile + 8*(r>>2) + 4h + (r&3); one lane per quad stores them.  All through asm volatile: the statements keep their order,
+// DPP row operations of the latent-gradient reduce-scatter (reduce_tiles16_dpp).  Through asm volatile: the statements keep their order,
 // which keeps every DPP read >= 2 instructions behind the write of its source (the hazard the compiler would otherwise pad).
 #define SNR_DPP_SELF(R, CTRL, BANK) asm volatile("v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:" BANK : "+v"(R))
 #define SNR_DPP_FROM(R0, R1, CTRL, BANK) asm volatile("v_add_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:" BANK : "+v"(R0) : "v"(R1))
-__device__ __forceinline__ void reduce_tiles_dpp(const f32x16 (&acc)[8], float* __restrict__ out /*LDS, 256*/, int lane) {
-    const int h = lane >> 5, tile = ((lane >> 4) & 1) + 2 * ((lane >> 2) & 1) + 4 * ((lane >> 3) & 1);
-#pragma unroll
-    for (int rh = 0; rh < 2; ++rh) {
-        float v[8][8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { v[t][k] = acc[t][8 * rh + k]; asm volatile("" : "+v"(v[t][k])); }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { SNR_DPP_SELF(v[t][k], "row_mirror", "0x3"); SNR_DPP_FROM(v[t][k], v[t + 4][k], "row_mirror", "0xc"); }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { SNR_DPP_SELF(v[t][k], "row_half_mirror", "0x5"); SNR_DPP_FROM(v[t][k], v[t + 2][k], "row_half_mirror", "0xa"); }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) SNR_DPP_SELF(v[t][k], "quad_perm:[1,0,3,2]", "0xf");
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) SNR_DPP_SELF(v[t][k], "quad_perm:[2,3,0,1]", "0xf");
-        float s[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(v[0][k]), "+v"(v[1][k]));
-            s[k] = v[0][k] + v[1][k];
-        }
-        if ((lane & 3) == 0) {
-            *reinterpret_cast<f32x4*>(out + 32 * tile + 8 * (2 * rh) + 4 * h) = f32x4{s[0], s[1], s[2], s[3]};
-            *reinterpret_cast<f32x4*>(out + 32 * tile + 8 * (2 * rh + 1) + 4 * h) = f32x4{s[4], s[5], s[6], s[7]};
-        }
-    }
-}
-
-// What happens to a finished gradient tile (wrt the input of the layer above = output of layer l [+ latent]):
-// per-object reduction for the latent gradient, layer l's ReLU bits, the density-head term below enc_shape.
-struct BwdEpi {
-    uint32_t m[4];        // ReLU bits of layer l (all ones when it has no activation)
-    const float* wsig;    // LDS: density-head weights (only below enc_shape: null otherwise)
-    float dpre;           // d loss / d (pre-softplus density) of this lane's point
-    float* dzl;           // LDS: where this wave parks the layer's latent-term gradient (256 floats), or null
-    float* dump;          // DUMP (training): this lane's row of the pre-activation gradient dump, [point][256] + 4h, or null
-#ifdef SNR_STAMPS
-    unsigned long long* st;   // diagnostics: this wave tile's stamp row (lane 0 of live tiles), or null
-#endif
-};
-#ifdef SNR_STAMPS
-#define SNR_LSTAMP(c, i) do { if ((c).st) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); (c).st[i] = t_; } } while (0)
-#else
-#define SNR_LSTAMP(c, i) do {} while (0)
-#endif
-template <int T, int HALF, int JJ, bool DUMP = false>
-__device__ __forceinline__ void bwd_quarter(const f32x16& acc, XOp& out, const BwdEpi& c, int lane) {
-    const int j = 2 * HALF + JJ;
-    f32x4 dv;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int r = 4 * j + e;
-        float v = acc[r];
-        v = ((c.m[T >> 1] >> ((T & 1) * 16 + r)) & 1u) ? v : 0.f;      // (v_bfe_i32 + v_and instead of test + select: measured, 0.5979 -> 0.5970 ms, nothing)
-        split_store(v, out, r & 7);
-        if (DUMP) dv[e] = v;
-    }
-    // training: the gradient wrt this layer's pre-activation (features 32T + 8j + 4h .. +3) goes to HBM for the weight-gradient product
-    if (DUMP) { if (c.dump) *reinterpret_cast<f32x4*>(c.dump + 32 * T + 8 * j) = dv; }
-    if (JJ == 1) pin(out);
-}
-template <int T, int HALF, bool DUMP = false>
-__device__ __forceinline__ void bwd_half_tile(const f32x16& acc, XOp& out, const BwdEpi& c, int h, int lane) {
-    bwd_quarter<T, HALF, 0, DUMP>(acc, out, c, lane);
-    bwd_quarter<T, HALF, 1, DUMP>(acc, out, c, lane);
-}
-
-// One transposed layer: 16 operand steps from acc, NT output tiles back into acc (one code instance for the whole chain, like
-// layer_fwd); same half-step pipeline.  With
-// `ninth` (enc_viewdir^T) a ninth output tile, the gradient of the 32 direction features, follows from one more chunk: its 16
-// steps x (hi, lo) KiB are packed behind the layer's 8 regular chunks and multiply the operand steps still held in x.
-template <int NT, bool DUMP = false>
-__device__ __forceinline__ void layer_bwd(f32x16 (&accP)[8], f32x16& acc9, XOp (&x)[16], Ring& ring, char* lds,
-                                          const BwdEpi& c, bool ninth, int tid, int lane) {
-    f32x16 accC[8];
-    const int h = lane >> 5;
-    const unsigned voff = lane * 16u + 4096u;
-    constexpr int NTH = NT / 2;
-    constexpr int SPC = (NT == 8) ? 2 : 8;                  // steps per chunk (NT == 2: enc_xyz^T, 8 steps of 4 KiB)
-    constexpr int step_bytes = NT * 2 * 1024;
-    constexpr bool TAIL = (NT != 8);                        // enc_xyz^T: the stream ends with this layer
-    constexpr int NCH = 16 / SPC;
-    if (c.dzl) reduce_tiles_dpp(accP, c.dzl, lane);
-    if (c.wsig) {       // below enc_shape the density head adds d_pre * w_sigma (one pass here instead of an fma + a vector load in every
-                        // layer's epilogue)
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(c.wsig + 32 * t + 8 * j + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) accP[t][4 * j + e] = fmaf(c.dpre, wv[e], accP[t][4 * j + e]);
-            }
-    }
-    if (NT == 2) SNR_LSTAMP(c, 10);
-    acc_zero<NT, 8>(accC);
-    bwd_half_tile<0, 0, DUMP>(accP[0], x[0], c, h, lane);
-    Frags<NTH> fa, fb;
-    const char* w = ring_acquire<TAIL && NCH == 1>(ring, lds) + lane * 16;
-    load_frags<NTH, 0>(fa, w);
-    ring_pieces_in<0, SPC, 0, NCH, TAIL>(ring, voff);
-#define SNR_BSTEP(S)                                                                                                   \
-    {                                                                                                                  \
-        const char* ws = w + ((S) % SPC) * step_bytes;                                                                 \
-        load_frags<NTH, NTH>(fb, ws);                                                                                  \
-        if constexpr ((S) == 15) mma_half_to<NTH, 0, 8>(accP, accC, x[S], fa); else mma_half<NTH, 0, 8>(accC, x[S], fa);       \
-        ring_pieces_in<(2 * (S) + 1) % (2 * SPC), SPC, (2 * (S) + 1) / (2 * SPC), NCH, TAIL>(ring, voff);              \
-        if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 0, DUMP>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, lane); \
-        SNR_INTERLEAVE_B(3 * NTH)                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if constexpr (((S) + 1) % SPC != 0) load_frags<NTH, 0>(fa, ws + step_bytes);                                   \
-        else if constexpr ((S) + 1 < 16) { w = ring_acquire<TAIL && ((S) + 1) / SPC == NCH - 1>(ring, lds) + lane * 16; load_frags<NTH, 0>(fa, w); } \
-        if constexpr ((S) == 15) mma_half_to<NTH, NTH, 8>(accP, accC, x[S], fb); else mma_half<NTH, NTH, 8>(accC, x[S], fb);   \
-        if constexpr ((S) + 1 < 16 || ((2 * (S) + 2) % (2 * SPC)) != 0)                                                \
-            ring_pieces_in<(2 * (S) + 2) % (2 * SPC), SPC, (2 * (S) + 2) / (2 * SPC), NCH, TAIL>(ring, voff);          \
-        if constexpr ((S) + 1 < 16) bwd_quarter<(((S) + 1) >> 1), (((S) + 1) & 1), 1, DUMP>(accP[((S) + 1) >> 1], x[((S) + 1) & 15], c, lane); \
-        SNR_INTERLEAVE_B(3 * NTH)                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-    }
-    SNR_BSTEP(0) SNR_BSTEP(1) SNR_BSTEP(2) SNR_BSTEP(3) SNR_BSTEP(4) SNR_BSTEP(5) SNR_BSTEP(6) SNR_BSTEP(7)
-    if (NT == 2) SNR_LSTAMP(c, 15);
-    SNR_BSTEP(8) SNR_BSTEP(9) SNR_BSTEP(10) SNR_BSTEP(11) SNR_BSTEP(12) SNR_BSTEP(13) SNR_BSTEP(14) SNR_BSTEP(15)
-#undef SNR_BSTEP
-    if (NT == 8 && ninth) {
-        w = ring_acquire(ring, lds) + lane * 16;
-        ring_pieces<0, 8>(ring, voff);
-#pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(w + s2 * 2048);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(w + s2 * 2048 + 1024);
-            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x[s2].hi, acc9, 0, 0, 0);
-            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, x[s2].lo, acc9, 0, 0, 0);
-            acc9 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, x[s2].hi, acc9, 0, 0, 0);
-        }
-    }
-}
-
 #ifdef SNR_STAMPS
 #define SNR_BSTAMP(i) do { if (io.d_t && lane == 0 && tile32 * 32 < io.n_points) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     reinterpret_cast<unsigned long long*>(io.d_t)[tile32 * 16 + (i)] = t_; } } while (0)
 #else
 #define SNR_BSTAMP(i) do {} while (0)
 #endif
-template <int MODE, bool DUMP = false>      // DUMP (training): io.gdump receives the gradient wrt every MFMA layer's pre-activation
-__global__ void __launch_bounds__(256, 1)
-bf16_bwd_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float* __restrict__ viewdir, RayGeom g) {
-    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 31, h = lane >> 5;
-    const long long tile128 = blockIdx.x;
-    const long long tile32 = tile128 * 4 + wave;
-    const long long gp_raw = tile128 * 128 + wave * 32 + p;
-    const bool live = gp_raw < io.n_points;
-    const long long gp = live ? gp_raw : io.n_points - 1;
-    const int sb = io.sb, tb = io.tb;
-    const int n_relu = n_relu_layers(sb, tb);
-    const int li_encshape = sb + 1, li_view = sb + 2, li_last = sb + tb + 2;
-    float* vec = reinterpret_cast<float*>(lds + OFF_VEC);
-    SNR_BSTAMP(0);
 
-    // ---- everything that needs an ordinary global load happens before the DMA ring starts
-    vec[VEC_SIGW + tid] = io.packed[L.sigma_w + tid];
-    vec[VEC_ZERO + tid] = 0.f;
-    for (int i = tid; i < 384; i += 256) vec[VEC_RGBW + i] = io.packed[L.rgb2_w + i];
-    const bool tile_live = tile32 * 32 < io.n_points;         // wave tiles past the end (last workgroup) read and store nothing
-    uint4 mk[MAX_LAYERS - 1];                                  // ReLU bits of every ReLU layer of this wave tile
-#pragma unroll
-    for (int s = 0; s < MAX_LAYERS - 1; ++s) mk[s] = (s < n_relu && tile_live) ? io.masks[(tile32 * n_relu + s) * 64 + lane] : make_uint4(0, 0, 0, 0);
-    float px_, py_, pz_, dx, dy, dz, tval = 0.f, zc = 0.f, uval = 0.f;
-    long long ray = 0;
-    if (MODE == 0) {
-        px_ = xyz[gp * 3]; py_ = xyz[gp * 3 + 1]; pz_ = xyz[gp * 3 + 2];
-        dx = viewdir[gp * 3]; dy = viewdir[gp * 3 + 1]; dz = viewdir[gp * 3 + 2];
-    } else {
-        ray = gp / g.S;
-        const SamplePoint sp = make_sample(g, ray, (int)(gp - ray * g.S));
-        px_ = sp.x; py_ = sp.y; pz_ = sp.z; dx = sp.dx; dy = sp.dy; dz = sp.dz; zc = sp.zc; tval = sp.t; uval = sp.u;
-    }
-    const float sig_gp = io.sigmas[gp];       // (issued here: behind the composite's barriers it would be one more exposed round trip)
-    float gs = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gzc = 0.f;
-    if (MODE == 0) {
-        if (live) {
-            gs = io.d_sigmas ? io.d_sigmas[gp] : 0.f;
-            if (io.d_rgbs) { gr = io.d_rgbs[gp * 3]; gg = io.d_rgbs[gp * 3 + 1]; gb = io.d_rgbs[gp * 3 + 2]; }
-        }
-    } else {
-        float* comp = reinterpret_cast<float*>(lds + OFF_COMP);
-        if (lane < 32) comp[(wave * 32 + p) * COMP_STRIDE + 5] = zc;
-        __syncthreads();
-        const int S = g.S;
-        const int rays_here = 128 / S;
-        const bool white = g.flags & SNR_WHITE_BKGD;
-        for (int r = wave; r < rays_here; r += 4) {
-            const long long rr = tile128 * rays_here + r;
-            if (rr >= g.n_rays) break;
-            float* c0 = comp + r * S * COMP_STRIDE;
-            const float* srow = io.sigmas + rr * S;
-            const float* crow = io.rgbs + rr * S * 3;
-            const float ur = io.d_rgb ? io.d_rgb[rr * 3] : 0.f, ug = io.d_rgb ? io.d_rgb[rr * 3 + 1] : 0.f,
-                        ub = io.d_rgb ? io.d_rgb[rr * 3 + 2] : 0.f;
-            const float ud = io.d_depth ? io.d_depth[rr] : 0.f, ua = io.d_acc ? io.d_acc[rr] : 0.f;
-            if (S <= 64) composite_ray_bwd<1>(S, lane, white, ur, ug, ub, ud, ua,
-                [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
-                    s_ = srow[k]; r_ = crow[3 * k]; g_ = crow[3 * k + 1]; b_ = crow[3 * k + 2];
-                    z_ = c0[k * COMP_STRIDE + 5];
-                    zn_ = (k < S - 1) ? c0[(k + 1) * COMP_STRIDE + 5] : 0.f;
-                },
-                [&](int k, float ds, float dcr, float dcg, float dcb, float dzz) {
-                    float* c = c0 + k * COMP_STRIDE;
-                    c[0] = ds; c[1] = dcr; c[2] = dcg; c[3] = dcb; c[4] = dzz;
-                });
-            else composite_ray_bwd<2>(S, lane, white, ur, ug, ub, ud, ua,
-                [&](int k, float& s_, float& r_, float& g_, float& b_, float& z_, float& zn_) {
-                    s_ = srow[k]; r_ = crow[3 * k]; g_ = crow[3 * k + 1]; b_ = crow[3 * k + 2];
-                    z_ = c0[k * COMP_STRIDE + 5];
-                    zn_ = (k < S - 1) ? c0[(k + 1) * COMP_STRIDE + 5] : 0.f;
-                },
-                [&](int k, float ds, float dcr, float dcg, float dcb, float dzz) {
-                    float* c = c0 + k * COMP_STRIDE;
-                    c[0] = ds; c[1] = dcr; c[2] = dcg; c[3] = dcb; c[4] = dzz;
-                });
-        }
-        __syncthreads();
-        if (live) {
-            const float* c = comp + (wave * 32 + p) * COMP_STRIDE;
-            gs = c[0]; gr = c[1]; gg = c[2]; gb = c[3]; gzc = c[4];
-        }
-    }
-    const float dpre = gs * (1.f - expf(-sig_gp));
-    __syncthreads();
-    SNR_BSTAMP(1);
-
-    Ring ring;
-    const int total_chunks = 4 + 8 * tb + 9 + 8 * (sb + 1) + 2;       // enc_viewdir^T: 8 chunks + 1 for its ninth tile
-    const unsigned voff = lane * 16u + 4096u;
-    ring_start(ring, reinterpret_cast<const char*>(io.packed + L.bf_bwd), total_chunks, lds, voff);
-
-    XOp x[16];
-    auto mask_words = [&](int slot, uint32_t (&m)[4]) {        // runtime slot out of the register array (static unroll)
-        m[0] = m[1] = m[2] = m[3] = 0xffffffffu;
-#pragma unroll
-        for (int s = 0; s < MAX_LAYERS - 1; ++s) if (s == slot) { m[0] = mk[s].x; m[1] = mk[s].y; m[2] = mk[s].z; m[3] = mk[s].w; }
-    };
-    // ---- colour head backward on the VALU: g_h = W2^T d_rgb masked by rgb.0's ReLU -> 8 operand steps
-    {
-        uint32_t m[4];
-        mask_words(n_relu - 1, m);
-        const float* w2 = vec + VEC_RGBW;
-        float* hdump = (DUMP && live) ? io.gdump + ((long long)(li_last + 1) * io.n_points + gp) * 256 + 4 * h : nullptr;   // rgb.0's G, 128 columns
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n0 = 32 * t + 8 * j + 4 * h;
-                const f32x4 wr = *reinterpret_cast<const f32x4*>(w2 + n0);
-                const f32x4 wg = *reinterpret_cast<const f32x4*>(w2 + 128 + n0);
-                const f32x4 wb = *reinterpret_cast<const f32x4*>(w2 + 256 + n0);
-                f32x4 dv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * j + e;
-                    float v = wr[e] * gr + wg[e] * gg + wb[e] * gb;
-                    v = ((m[t >> 1] >> ((t & 1) * 16 + r)) & 1u) ? v : 0.f;
-                    dv[e] = v;
-                    split_store(v, x[2 * t + (r >> 3)], r & 7);
-                }
-                if (DUMP) { if (hdump) *reinterpret_cast<f32x4*>(hdump + 32 * t + 8 * j) = dv; }
-            }
-    }
-
-    f32x16 accA[8], acc9;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc9[r] = 0.f;
-    SNR_BSTAMP(2);
-    // ---- rgb.0^T : K = 128 (8 steps) -> accA
-    acc_zero<8, 8>(accA);
-    {
-        const char* w = nullptr;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            if ((s & 1) == 0) { w = ring_acquire(ring, lds) + lane * 16; ring_pieces<0, 4>(ring, voff); }
-            else ring_pieces<4, 4>(ring, voff);
-            step_mma<8, 8>(accA, x[s], w + (s & 1) * 16 * 1024);
-        }
-    }
-
-    auto epi_of = [&](int l) {      // how the gradient wrt (output of layer l [+ latent]) becomes the operand of W_l^T
-        BwdEpi c;
-        mask_words(l == li_encshape ? -1 : relu_slot(l, sb), c.m);
-        c.wsig = (l == li_encshape) ? vec + VEC_SIGW : nullptr;
-        c.dpre = (l == li_encshape) ? dpre : 0.f;
-        const int la = latent_after(l, sb, tb);
-        c.dzl = (la >= 0 && io.partial) ? reinterpret_cast<float*>(lds + OFF_LAT) + (wave * MAX_LAT + la) * 256 : nullptr;
-        c.dump = nullptr;
-        if (DUMP) {      // slot l = gradient wrt the pre-activation of MFMA layer l
-            int t = threadIdx.x; asm volatile("" : "+v"(t));
-            const long long gpd = tile128 * 128 + wave * 32 + (t & 31);
-            if (gpd < io.n_points) c.dump = io.gdump + ((long long)l * io.n_points + gpd) * 256 + 4 * ((t & 63) >> 5);
-        }
-#ifdef SNR_STAMPS
-        c.st = (io.d_t && lane == 0 && tile32 * 32 < io.n_points) ? reinterpret_cast<unsigned long long*>(io.d_t) + tile32 * 16 : nullptr;
-#endif
-        return c;
-    };
-    SNR_BSTAMP(3);
-#pragma unroll 1
-    for (int li = li_last; li >= 1; --li) {
-        layer_bwd<8, DUMP>(accA, acc9, x, ring, lds, epi_of(li), li == li_view, tid, lane);
-        SNR_BSTAMP(4 + li_last - li);
-    }
-    SNR_BSTAMP(11);
-    // ---- enc_xyz^T : 256 -> 64 positional-encoding features (two tiles, fp32)
-    layer_bwd<2, DUMP>(accA, acc9, x, ring, lds, epi_of(0), false, tid, lane);
-
-    SNR_BSTAMP(12);
-    // ---- the parked latent-term gradients of this wave tile -> global partials (the ring is idle now)
-    if (io.partial && tile_live) {
-        const float* dzl = reinterpret_cast<const float*>(lds + OFF_LAT) + wave * MAX_LAT * 256;
-        for (int la = 0; la < L.n_lat; ++la)
-            *reinterpret_cast<f32x4*>(io.partial + (tile32 * L.n_lat + la) * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(dzl + la * 256 + lane * 4);
-    }
-    // ---- positional-encoding backward through the scratch rows (they alias ring buffer 2; the ring retired its last DMA at the
-    // final acquire)
-    __syncthreads();
-    float* sc = reinterpret_cast<float*>(lds + OFF_PE) + (wave * 32 + p) * PE_ROWF;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        sc[8 * (r >> 2) + 4 * h + (r & 3)] = accA[0][r];
-        sc[32 + 8 * (r >> 2) + 4 * h + (r & 3)] = accA[1][r];
-    }
-    float gx = 0.f, gy = 0.f, gz = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
-#pragma unroll 1
-    for (int i = 0; i < 15; ++i) {
-        const int q = 15 * h + i, a = q % 3, f = q / 3;
-        float sn, cs;
-        pe_sincos(ldexpf(pick3(px_, py_, pz_, a), f), &sn, &cs);
-        const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * XYZ_FREQ + q] * sn, f);
-        gx += a == 0 ? v : 0.f; gy += a == 1 ? v : 0.f; gz += a == 2 ? v : 0.f;
-    }
-    if (h == 0) { gx += sc[0]; gy += sc[1]; gz += sc[2]; }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sc[8 * (r >> 2) + 4 * h + (r & 3)] = acc9[r];
-#pragma unroll 1
-    for (int i = 0; i < 6; ++i) {
-        const int q = 6 * h + i, a = q % 3, f = q / 3;
-        float sn, cs;
-        pe_sincos(ldexpf(pick3(dx, dy, dz, a), f), &sn, &cs);
-        const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * DIR_FREQ + q] * sn, f);
-        hx += a == 0 ? v : 0.f; hy += a == 1 ? v : 0.f; hz += a == 2 ? v : 0.f;
-    }
-    if (h == 0) { hx += sc[0]; hy += sc[1]; hz += sc[2]; }
-    gx = sum_halves(gx); gy = sum_halves(gy); gz = sum_halves(gz);
-    hx = sum_halves(hx); hy = sum_halves(hy); hz = sum_halves(hz);
-    SNR_BSTAMP(13);
-
-    if (MODE == 0) {
-        if (live && h == 0) {
-            if (io.d_xyz) { io.d_xyz[gp * 3] = gx; io.d_xyz[gp * 3 + 1] = gy; io.d_xyz[gp * 3 + 2] = gz; }
-            if (io.d_dir) { io.d_dir[gp * 3] = hx; io.d_dir[gp * 3 + 1] = hy; io.d_dir[gp * 3 + 2] = hz; }
-        }
-        return;
-    }
-    ray_grad_tail(g, io.d_rays_o, io.d_rays_d, io.d_t, reinterpret_cast<float*>(lds + OFF_COMP), tile128, ray, gp, live, tval, uval, zc,
-                  gx, gy, gz, hx, hy, hz, gzc);
-    SNR_BSTAMP(14);
-}
-
-// ------------------------------------------------------------------------------------------ backward on v_mfma_f32_16x16x32_bf16
 // Round 4: the backward chain on the shape the forward took in round 3 (the chip holds a higher clock on it in MFMA-dense loops, see the
-// forward's header).  Same structure as bf16_bwd_kernel above -- G_in = W^T G_out per layer, the finished sums of a layer are the next
+// forward's header; rounds 1-3 ran it on v_mfma_f32_32x32x16_bf16: 0.603 against 0.588 ms, then the mask change below).  G_in = W^T G_out per layer, the finished sums of a layer are the next
 // layer's B operands, all eight operand steps of a layer stay in registers (enc_viewdir^T's direction tiles multiply them afterwards),
 // the previous layer's ReLU mask + hi/lo split spread under the MFMAs, bf16 pieces (gradients need the exponent range) -- on tiles of
 // 16 features x 16 points: the wave's 32 points are two column blocks c; register r of lane (n = lane & 15, g = lane >> 4) of tile T of
 // block c = feature 16 T + 4 g + r of point 16 c + n; operand step S (32 k) = tiles 2S, 2S+1.  Chunk = one k32-step of the 16 output
-// tiles (32 KiB, four groups of four tiles); the transposed stream is packed for this shape (pack_bf16_kernel, transpose == 2).
-// -DSNR_BWD_BF32 builds the 32x32x16 kernel of rounds 1-3 instead (A/B timing).
+// tiles (32 KiB, four groups of four tiles); the transposed stream is packed for this shape (pack_bf16_kernel, transpose != 0).
 struct Frag16B { bf16x8 hi[4], lo[4]; };
 __device__ __forceinline__ void load16b(Frag16B& f, const char* wq /* chunk + group offset + lane*16 */) {
 #pragma unroll
@@ -1809,9 +1352,7 @@ bf16_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float
 // ------------------------------------------------------------------------------------------ packing
 // One thread per (k-step, tile, lane, j): writes the hi and the lo element of the layer image
 //   [s][tile][plane hi/lo][lane][8].
-//   backward (transpose == 1, v_mfma_f32_32x32x16_bf16): k16-steps, 32-row tiles; value = W[k][row], row = input feature, k = output
-//     feature 16 s + 8 (j >> 2) + 4 (lane >> 5) + (j & 3) -- the order in which a 32x32 accumulator tile re-enters the MFMA as B operand;
-//   backward (transpose == 2, v_mfma_f32_16x16x32_bf16, the shipped backward): k32-steps, 16-row tiles; value = W[k][row], row = 16 tile +
+//   backward (transpose != 0, v_mfma_f32_16x16x32_bf16): k32-steps, 16-row tiles; value = W[k][row], row = 16 tile +
 //     (lane & 15) = input feature, k = output feature 32 s + 16 (j >> 2) + 4 (lane >> 4) + (j & 3);
 //   forward (transpose == 0, v_mfma_f32_16x16x32_bf16): k32-steps, 16-row tiles; value = W[row][k], row = 16 tile + (lane & 15) = output
 //     feature, k = input feature 32 s + 16 (j >> 2) + 4 (lane >> 4) + (j & 3) -- the order in which the 16x16 accumulator tiles 2s, 2s+1
@@ -1829,13 +1370,9 @@ __global__ void pack_bf16_kernel(const float* __restrict__ Wt, int n_out, int k_
             const int row = 16 * (tile0 + tile) + (lane & 15);
             const int k = k_off + 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
             if (row < n_out && k < k_in) v = Wt[(long long)row * k_in + k];
-        } else if (transpose == 2) {      // backward on 16x16x32: 16-row tiles of input features, k32-steps over the layer's outputs
+        } else {                          // backward: 16-row tiles of input features, k32-steps over the layer's outputs
             const int row = 16 * (tile0 + tile) + (lane & 15);
             const int k = 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
-            if (row < k_in && k < n_out) v = Wt[(long long)k * k_in + row];
-        } else {
-            const int row = 32 * (tile0 + tile) + (lane & 31), hh = lane >> 5;
-            const int k = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
             if (row < k_in && k < n_out) v = Wt[(long long)k * k_in + row];
         }
         const long long base = (((long long)s * n_tiles + tile) * 2) * 512;      // 16-bit elements; plane stride 512
@@ -1898,16 +1435,6 @@ int snr_bf16_pack_(const float* const* W /* per-point weight tensors in MFMA-lay
         const bool is_xyz = li == 0, is_view = li == sb + 2, is_rgb0 = li == n_layers - 1;
         const int n_out = is_rgb0 ? 128 : 256;
         const int k_in = is_xyz ? D_XYZ : (is_view ? 256 + D_DIR : 256);
-#ifdef SNR_BWD_BF32      /* the 32x32x16 backward of rounds 1-3 */
-        const int KS = n_out / 16;                                 // reduction over the layer's outputs
-        const int n_tiles = is_xyz ? 2 : 8;                        // tiles of 32 input features
-        launch(W[li], n_out, k_in, 1, n_tiles, KS, reinterpret_cast<__bf16*>(b));
-        b += (long long)n_tiles * 2 * KS * 1024;
-        if (is_view) {                                             // the direction features: ninth tile, a chunk of its own
-            launch(W[li], n_out, k_in, 1, 1, KS, reinterpret_cast<__bf16*>(b), 8);
-            b += 2ll * KS * 1024;
-        }
-#else
         const int KS = n_out / 32;                                 // k32-steps over the layer's outputs
         const int n_tiles = is_xyz ? 4 : 16;                       // tiles of 16 input features
         launch(W[li], n_out, k_in, 2, n_tiles, KS, reinterpret_cast<__bf16*>(b));
@@ -1916,7 +1443,6 @@ int snr_bf16_pack_(const float* const* W /* per-point weight tensors in MFMA-lay
             launch(W[li], n_out, k_in, 2, 2, KS, reinterpret_cast<__bf16*>(b), 16);
             b += 2ll * 2 * KS * 1024;
         }
-#endif
     }
     if (b - reinterpret_cast<char*>(packed + L.bf_bwd) != L.bf_bwd_bytes) return SNR_E_SHAPE;
     return snr_check_launch_();
@@ -1944,11 +1470,7 @@ int snr_bf16_launch_fwd_(int mode, const DecoderIO& io, const Layout& L, const f
 
 int snr_bf16_launch_bwd_(int mode, const BwdIO& io, const Layout& L, const float* xyz, const float* viewdir, const RayGeom& g, void* stream_) {
     const unsigned grid = (unsigned)((io.n_points + 127) / 128);
-#ifdef SNR_BWD_BF32
-#define SNR_BWD_KERNEL bf::bf16_bwd_kernel
-#else
 #define SNR_BWD_KERNEL bf::bf16_bwd16_kernel
-#endif
     if (io.gdump) {
         if (mode != 0) return SNR_E_ARG;
         SNR_BWD_KERNEL<0, true><<<grid, 256, 0, (hipStream_t)stream_>>>(io, L, xyz, viewdir, g);

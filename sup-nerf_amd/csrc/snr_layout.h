@@ -51,11 +51,11 @@ struct Layout {
 };
 
 // ---- split-bf16 ("bf16x3") streams -------------------------------------------------------------------
-// Every fp32 weight w is stored as hi = bf16(w), lo = bf16(w - hi).  A chunk holds the weights of TPC
-// 32-row output tiles for the layer's whole reduction depth K = 16*KS as the exact LDS image the kernel reads:
-//   [tile][plane hi/lo][k16-step s][lane 0..63][8 bf16]          (1 KiB per (plane, s): lane-linear)
-// where element j of lane (n = lane&31, h = lane>>5) is W[row 32*tile + n][k = 16 s + 8 (j>>2) + 4 h + (j&3)] --
-// the k order in which a 32x32 fp32 accumulator tile re-enters v_mfma_f32_32x32x16_bf16 as the B operand.
+// Every fp32 weight w is stored as hi = round16(w), lo = round16(w - hi) (fp16 in the forward stream, bf16 in the backward stream).  A chunk
+// holds the weights of whole k32-steps as the exact LDS image the kernels read:
+//   [k32-step s][16-row tile][plane hi/lo][lane 0..63][8 x 16 bit]          (1 KiB per (tile, plane): lane-linear)
+// where element j of lane (n = lane&15, g = lane>>4) is W[row 16*tile + n][k = 32 s + 16 (j>>2) + 4 g + (j&3)] (backward: W^T) --
+// the k order in which the 16x16 fp32 accumulator tiles 2s, 2s+1 re-enter v_mfma_f32_16x16x32_* as the B operand.
 constexpr int BF_CHUNK = 32768;          // bytes of every chunk except the forward enc_viewdir ones
 constexpr int BF_CHUNK_VIEW = 36864;     // 18 k16-steps
 
@@ -80,7 +80,7 @@ SNR_HD inline Layout make_layout(int sb, int tb) {
     L.rgb2_b = o; o += 4;
     // forward: enc_xyz 2 chunks (4 tiles each, K=64), 8 per 256-layer, 8 x enc_viewdir (K=288), rgb.0 4 chunks
     L.bf_fwd_bytes = 2ll * BF_CHUNK + (int64_t)(sb + 1 + tb) * 8 * BF_CHUNK + 8ll * BF_CHUNK_VIEW + 4ll * BF_CHUNK;
-    // backward: rgb.0^T 4 chunks (2 tiles each, K=128), 8 per 256-layer, enc_viewdir^T 9 tiles, enc_xyz^T 2 tiles
+    // backward: rgb.0^T 4 chunks (one k32-step of 16 tiles each, K=128), 8 per 256-layer, enc_viewdir^T 8 + 1 (its two direction tiles), enc_xyz^T 2 (four steps of 4 tiles each)
     L.bf_bwd_bytes = 4ll * BF_CHUNK + (int64_t)tb * 8 * BF_CHUNK + 9ll * BF_CHUNK + (int64_t)(sb + 1) * 8 * BF_CHUNK + 2ll * BF_CHUNK;
     o = (o + 3) & ~3ll;                       // 16-byte alignment for the LDS-DMA source
     L.bf_fwd = o; o += L.bf_fwd_bytes / 4;
