@@ -145,3 +145,18 @@ def test_two_devices_two_threads_bit_equal_to_serial():
         assert torch.equal(a, b)
     ref0 = _run(A, [models[0]], [devs[0]], [objs[1]], concurrent=False)[0]       # the same object on the other device: same bits
     assert torch.equal(ref0, serial[1])
+
+
+@pytest.mark.gpu
+def test_raw_stream_follows_the_stream_context():
+    """Every cache key and every launch takes the current stream through ops.raw_stream (the private raw getter, no Python Stream object per
+    call): it must be the stream torch itself would launch on, inside a torch.cuda.stream() context and on a non-default device index alike."""
+    import supnerf_amd as A
+    dev = torch.device("cuda:0")
+    assert A.ops.raw_stream(dev) == torch.cuda.current_stream(dev).cuda_stream
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        assert A.ops.raw_stream(dev) == side.cuda_stream
+        assert A.ops.raw_stream("cuda") == side.cuda_stream
+        assert A.utils._stream_key(dev) == (str(dev), side.cuda_stream)
+    assert A.ops.raw_stream(dev) == torch.cuda.current_stream(dev).cuda_stream
