@@ -639,8 +639,15 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
         float* scw = reinterpret_cast<float*>(lds + OFF_PE) + (wave * 32) * PE_ROWF;
         float* sc = scw + p * PE_ROWF;
 #pragma unroll 1
-        for (int i = 0; i < 15; ++i) {
+        for (int i = 0; i < 14; i += 2) {                  // two (frequency, axis) pairs per trip: packed arithmetic (pe_sincos2)
             const int q = 15 * h + i;
+            f32x2 sn, cs;
+            pe_sincos2(f32x2{ldexpf(pick3(px, py, pz, q % 3), q / 3), ldexpf(pick3(px, py, pz, (q + 1) % 3), (q + 1) / 3)}, &sn, &cs);
+            sc[3 + q] = sn[0]; sc[3 + 3 * XYZ_FREQ + q] = cs[0];
+            sc[4 + q] = sn[1]; sc[4 + 3 * XYZ_FREQ + q] = cs[1];
+        }
+        {
+            const int q = 15 * h + 14;
             float sn, cs;
             pe_sincos(ldexpf(pick3(px, py, pz, q % 3), q / 3), &sn, &cs);
             sc[3 + q] = sn; sc[3 + 3 * XYZ_FREQ + q] = cs;
@@ -663,11 +670,12 @@ bf16_fwd_kernel(DecoderIO io, Layout L, const float* __restrict__ xyz, const flo
                     for (int j = 0; j < 8; ++j) split_store_f(pv[s][c][j], x0[s][c], j);
         }
 #pragma unroll 1
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 6; i += 2) {
             const int q = 6 * h + i;
-            float sn, cs;
-            pe_sincos(ldexpf(pick3(dx, dy, dz, q % 3), q / 3), &sn, &cs);
-            sc[3 + q] = sn; sc[3 + 3 * DIR_FREQ + q] = cs;
+            f32x2 sn, cs;
+            pe_sincos2(f32x2{ldexpf(pick3(dx, dy, dz, q % 3), q / 3), ldexpf(pick3(dx, dy, dz, (q + 1) % 3), (q + 1) / 3)}, &sn, &cs);
+            sc[3 + q] = sn[0]; sc[3 + 3 * DIR_FREQ + q] = cs[0];
+            sc[4 + q] = sn[1]; sc[4 + 3 * DIR_FREQ + q] = cs[1];
         }
         if (h == 0) {
             sc[0] = dx; sc[1] = dy; sc[2] = dz;
@@ -1310,13 +1318,24 @@ bf16_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float
 #pragma unroll
             for (int r = 0; r < 4; ++r) scw[(16 * cb + n16) * PE_ROWF + 16 * T + 4 * gq + r] = accA[cb][T][r];
     float gx = 0.f, gy = 0.f, gz = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
+    auto pe_grad = [&](int q, int n_freq, float vx, float vy, float vz, float sn, float cs, float& ax, float& ay, float& az) {
+        const int a = q % 3, f = q / 3;
+        const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * n_freq + q] * sn, f);
+        ax += a == 0 ? v : 0.f; ay += a == 1 ? v : 0.f; az += a == 2 ? v : 0.f;
+    };
 #pragma unroll 1
-    for (int i = 0; i < 15; ++i) {
-        const int q = 15 * h + i, a = q % 3, f = q / 3;
+    for (int i = 0; i < 14; i += 2) {                  // two (frequency, axis) pairs per trip: packed arithmetic (pe_sincos2)
+        const int q = 15 * h + i;
+        f32x2 sn, cs;
+        pe_sincos2(f32x2{ldexpf(pick3(px_, py_, pz_, q % 3), q / 3), ldexpf(pick3(px_, py_, pz_, (q + 1) % 3), (q + 1) / 3)}, &sn, &cs);
+        pe_grad(q, XYZ_FREQ, px_, py_, pz_, sn[0], cs[0], gx, gy, gz);
+        pe_grad(q + 1, XYZ_FREQ, px_, py_, pz_, sn[1], cs[1], gx, gy, gz);
+    }
+    {
+        const int q = 15 * h + 14;
         float sn, cs;
-        pe_sincos(ldexpf(pick3(px_, py_, pz_, a), f), &sn, &cs);
-        const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * XYZ_FREQ + q] * sn, f);
-        gx += a == 0 ? v : 0.f; gy += a == 1 ? v : 0.f; gz += a == 2 ? v : 0.f;
+        pe_sincos(ldexpf(pick3(px_, py_, pz_, q % 3), q / 3), &sn, &cs);
+        pe_grad(q, XYZ_FREQ, px_, py_, pz_, sn, cs, gx, gy, gz);
     }
     if (h == 0) { gx += sc[0]; gy += sc[1]; gz += sc[2]; }
 #pragma unroll
@@ -1326,12 +1345,12 @@ bf16_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const float
 #pragma unroll
             for (int r = 0; r < 4; ++r) scw[(16 * cb + n16) * PE_ROWF + 16 * t + 4 * gq + r] = accD[cb][t][r];
 #pragma unroll 1
-    for (int i = 0; i < 6; ++i) {
-        const int q = 6 * h + i, a = q % 3, f = q / 3;
-        float sn, cs;
-        pe_sincos(ldexpf(pick3(dx, dy, dz, a), f), &sn, &cs);
-        const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * DIR_FREQ + q] * sn, f);
-        hx += a == 0 ? v : 0.f; hy += a == 1 ? v : 0.f; hz += a == 2 ? v : 0.f;
+    for (int i = 0; i < 6; i += 2) {
+        const int q = 6 * h + i;
+        f32x2 sn, cs;
+        pe_sincos2(f32x2{ldexpf(pick3(dx, dy, dz, q % 3), q / 3), ldexpf(pick3(dx, dy, dz, (q + 1) % 3), (q + 1) / 3)}, &sn, &cs);
+        pe_grad(q, DIR_FREQ, dx, dy, dz, sn[0], cs[0], hx, hy, hz);
+        pe_grad(q + 1, DIR_FREQ, dx, dy, dz, sn[1], cs[1], hx, hy, hz);
     }
     if (h == 0) { hx += sc[0]; hy += sc[1]; hz += sc[2]; }
     gx = sum_halves(gx); gy = sum_halves(gy); gz = sum_halves(gz);

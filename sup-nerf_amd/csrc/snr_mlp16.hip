@@ -237,20 +237,24 @@ decoder_fwd16_kernel(DecoderIO io, Layout L, Lds16 lo, const float* __restrict__
         float* sc = lds + lo.scratch + wave * PE_WAVE16 + n * PE_ROW;
         // 30 (frequency, axis) pairs of the xyz encoding, 8 per lane group (the fourth takes 6); 12 of the direction encoding, 3 each
 #pragma unroll 1
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 8; i += 2) {                   // two pairs per trip on packed arithmetic (pe_sincos2: half the VALU instructions)
             const int q = 8 * g + i;
             if (q < 3 * XYZ_FREQ) {
-                float sn, cs;
-                pe_sincos(ldexpf(pick3(px, py, pz, q % 3), q / 3), &sn, &cs);
-                sc[3 + q] = sn; sc[3 + 3 * XYZ_FREQ + q] = cs;
+                f32x2 sn, cs;
+                pe_sincos2(f32x2{ldexpf(pick3(px, py, pz, q % 3), q / 3), ldexpf(pick3(px, py, pz, (q + 1) % 3), (q + 1) / 3)}, &sn, &cs);
+                sc[3 + q] = sn[0]; sc[3 + 3 * XYZ_FREQ + q] = cs[0];
+                sc[4 + q] = sn[1]; sc[4 + 3 * XYZ_FREQ + q] = cs[1];
             }
         }
-#pragma unroll 1
-        for (int i = 0; i < 3; ++i) {
-            const int q = 3 * g + i;
-            float sn, cs;
-            pe_sincos(ldexpf(pick3(dx, dy, dz, q % 3), q / 3), &sn, &cs);
-            sc[64 + 3 + q] = sn; sc[64 + 3 + 3 * DIR_FREQ + q] = cs;
+        {
+            const int q = 3 * g;
+            f32x2 sn, cs;
+            pe_sincos2(f32x2{ldexpf(pick3(dx, dy, dz, q % 3), q / 3), ldexpf(pick3(dx, dy, dz, (q + 1) % 3), (q + 1) / 3)}, &sn, &cs);
+            sc[64 + 3 + q] = sn[0]; sc[64 + 3 + 3 * DIR_FREQ + q] = cs[0];
+            sc[64 + 4 + q] = sn[1]; sc[64 + 4 + 3 * DIR_FREQ + q] = cs[1];
+            float s1, c1;
+            pe_sincos(ldexpf(pick3(dx, dy, dz, (q + 2) % 3), (q + 2) / 3), &s1, &c1);
+            sc[64 + 5 + q] = s1; sc[64 + 5 + 3 * DIR_FREQ + q] = c1;
         }
         if (g == 0) {
             sc[0] = px; sc[1] = py; sc[2] = pz; sc[63] = 0.f;

@@ -467,24 +467,30 @@ decoder_bwd16_kernel(BwdIO io, Layout L, const float* __restrict__ xyz, const fl
     SNR16_BSTAMP(3);
 #endif
     float gx = 0.f, gy = 0.f, gz = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
+    auto pe_grad = [&](const float* row, int q, int n_freq, float sn, float cs, float& ax, float& ay, float& az) {
+        const int a = q % 3, f = q / 3;
+        const float v = ldexpf(row[3 + q] * cs - row[3 + 3 * n_freq + q] * sn, f);
+        ax += a == 0 ? v : 0.f; ay += a == 1 ? v : 0.f; az += a == 2 ? v : 0.f;
+    };
 #pragma unroll 1
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 8; i += 2) {                   // two pairs per trip on packed arithmetic (pe_sincos2)
         const int q = 8 * g + i;
         if (q < 3 * XYZ_FREQ) {
-            const int a = q % 3, f = q / 3;
-            float sn, cs;
-            pe_sincos(ldexpf(pick3(x, y, z, a), f), &sn, &cs);
-            const float v = ldexpf(sc[3 + q] * cs - sc[3 + 3 * XYZ_FREQ + q] * sn, f);
-            gx += a == 0 ? v : 0.f; gy += a == 1 ? v : 0.f; gz += a == 2 ? v : 0.f;
+            f32x2 sn, cs;
+            pe_sincos2(f32x2{ldexpf(pick3(x, y, z, q % 3), q / 3), ldexpf(pick3(x, y, z, (q + 1) % 3), (q + 1) / 3)}, &sn, &cs);
+            pe_grad(sc, q, XYZ_FREQ, sn[0], cs[0], gx, gy, gz);
+            pe_grad(sc, q + 1, XYZ_FREQ, sn[1], cs[1], gx, gy, gz);
         }
     }
-#pragma unroll 1
-    for (int i = 0; i < 3; ++i) {
-        const int q = 3 * g + i, a = q % 3, f = q / 3;
-        float sn, cs;
-        pe_sincos(ldexpf(pick3(dx, dy, dz, a), f), &sn, &cs);
-        const float v = ldexpf(sc[64 + 3 + q] * cs - sc[64 + 3 + 3 * DIR_FREQ + q] * sn, f);
-        hx += a == 0 ? v : 0.f; hy += a == 1 ? v : 0.f; hz += a == 2 ? v : 0.f;
+    {
+        const int q = 3 * g;
+        f32x2 sn, cs;
+        pe_sincos2(f32x2{ldexpf(pick3(dx, dy, dz, q % 3), q / 3), ldexpf(pick3(dx, dy, dz, (q + 1) % 3), (q + 1) / 3)}, &sn, &cs);
+        pe_grad(sc + 64, q, DIR_FREQ, sn[0], cs[0], hx, hy, hz);
+        pe_grad(sc + 64, q + 1, DIR_FREQ, sn[1], cs[1], hx, hy, hz);
+        float s1, c1;
+        pe_sincos(ldexpf(pick3(dx, dy, dz, (q + 2) % 3), (q + 2) / 3), &s1, &c1);
+        pe_grad(sc + 64, q + 2, DIR_FREQ, s1, c1, hx, hy, hz);
     }
     if (g == 0) { gx += sc[0]; gy += sc[1]; gz += sc[2]; hx += sc[64]; hy += sc[65]; hz += sc[66]; }
     gx += __shfl_xor(gx, 16, 64); gx += __shfl_xor(gx, 32, 64);
