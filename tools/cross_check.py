@@ -35,6 +35,23 @@ for case in range(40):
         out = model.fused_render(leaves[0], leaves[1], tt, div, zs, leaves[2], leaves[3], cfg)
         sum((a * b).sum() for a, b in zip(out, wts)).backward()
         res[prec] = [o.detach() for o in out] + [l.grad for l in leaves]
+    # mask-matched: ONE exact-fp32 forward saves sigmas / colours / ReLU bits, both backward kernels differentiate that same piecewise-linear
+    # function -- what is left between them is arithmetic, not ReLU flips (the comparison above lets each arithmetic save its own bits)
+    with torch.no_grad():
+        lat = model.latent_terms(sc, tc).contiguous()
+        pk = model.packed_weights()
+        cfg32 = ops.RenderCfg(S, z_mode, per, 3, 1, frame=U._frame(False, False, True), white_bkgd=white, metric_z=metric, precision="fp32")
+        _, _, _, sig, rgbs, masks = ops.render_fwd(ro, vd, t, div, zs, lat, pk, cfg32, save_for_bwd=True)
+        mm = {}
+        for prec in ("fp32", "bf16x3"):
+            cfg_b = ops.RenderCfg(S, z_mode, per, 3, 1, frame=U._frame(False, False, True), white_bkgd=white, metric_z=metric, precision=prec)
+            mm[prec] = ops.render_bwd(ro, vd, t, div, zs, lat, pk, cfg_b, sig, rgbs, masks, wts[0], wts[1], wts[2], need_t=(z_mode == ops.Z_PER_RAY))
+        for nme, a, b in zip(("mm d_rays_o", "mm d_rays_d", "mm d_t", "mm d_latent"), mm["fp32"], mm["bf16x3"]):
+            if a is None: continue
+            rel = float((a - b).abs().max() / (a.abs().max() + 1e-12))
+            if not torch.isfinite(b).all(): rel = float("inf")
+            if rel > worst.get(nme, (0,))[0]:
+                worst[nme] = (rel, dict(S=S, B=B, per=per, z_mode=z_mode, white=white, metric=metric))
     names = ["rgb", "depth", "acc", "d_rays_o", "d_rays_d", "d_shape", "d_texture", "d_t"]
     for nme, a, b in zip(names, res["fp32"], res["bf16x3"]):
         rel = float((a - b).abs().max() / (a.abs().max() + 1e-12))
@@ -45,4 +62,4 @@ for case in range(40):
     n_cases += 1
 print(n_cases, "cases; worst relative difference bf16x3 vs fp32 (max-norm):")
 for k, v in worst.items():
-    print(f"  {k:10s} {v[0]:.2e}   at {v[1]}")
+    print(f"  {k:12s} {v[0]:.2e}   at {v[1]}")
