@@ -1,8 +1,8 @@
 // Backward of the fused decoder / render kernels, exact fp32, TWO waves per SIMD: the counterpart of snr_mlp16.hip (forward) for
 // snr_mlp_bwd.hip's one-wave-per-SIMD kernel.  Same mathematics, same transposed weight stream (snr_layout.h: L.bwd), same saved ReLU
-// bits / sigma / rgb, same outputs (latent-gradient partials per wave tile, d xyz / d viewdir or d rays_o / d rays_d / d t).
+// bits / sigma / rgb, same outputs (latent-gradient partials per workgroup, d xyz / d viewdir or d rays_o / d rays_d / d t).
 //
-//   * Workgroup = 4 waves = 64 consecutive sample points, 256 threads, 73 KiB of LDS -> two independent workgroups per CU; wave w owns
+//   * Workgroup = 4 waves = 64 consecutive sample points, 256 threads, 77 KiB of LDS -> two independent workgroups per CU; wave w owns
 //     points 16 w .. 16 w + 15, lane (n = lane & 15, g = lane >> 4), accumulator register r of tile T = feature 16 T + 4 g + r of point n.
 //   * Every layer is G_in = W^T G_out on v_mfma_f32_16x16x4_f32, k-outer over the previous layer's tiles like the forward: input tile T's
 //     four operand registers are made from accP[T] -- the saved ReLU bit applied as v_bfe_i32 + v_and, two VALU instructions per value, no
