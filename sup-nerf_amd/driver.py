@@ -452,10 +452,14 @@ def _optimize_fused(model, dev, objs, hpams, shapecodes0, texturecodes0, seeds, 
                 prec = model._auto_precision(model.precision, n * S, probe)
                 cfg.precision = prec
                 cfg_l.precision = prec if (prec != "bf16x3" or ops.split_supported(sb, tb, n_l * S)) else "fp32"
-            rgb, depth, acc = ops.FusedRender.apply(rays_o, viewdir, z, c["diag"], None, lat, packed, cfg)
-            loss, lm = ops.LossTail.apply(rgb, acc, c["tgt"], c["occ"], coef, n)
-            if it > reg_iters:  # (the gradients of a render-only iteration are cleared unread, :676,768-769: not computed here)
+            if it > reg_iters:
+                rgb, depth, acc = ops.FusedRender.apply(rays_o, viewdir, z, c["diag"], None, lat, packed, cfg)
+                loss, lm = ops.LossTail.apply(rgb, acc, c["tgt"], c["occ"], coef, n)
                 torch.autograd.backward(loss, ones)
+            else:               # a render-only iteration: its gradients are cleared unread (:676,768-769), so nothing is recorded -- the forward then
+                with torch.no_grad():      # does not save ReLU bits either (the launch that saves them is 9 % slower and writes 208 B per point)
+                    rgb, depth, acc = ops.FusedRender.apply(rays_o, viewdir, z, c["diag"], None, lat, packed, cfg)
+                    loss, lm = ops.LossTail.apply(rgb, acc, c["tgt"], c["occ"], coef, n)
             with torch.no_grad():
                 if from_table:
                     c2o = table[it]
